@@ -1,0 +1,406 @@
+"""
+TEST INFRASTRUCTURE -- NOT PRODUCT CODE.
+
+Big-integer CPU restatement of the deterministic (`rng = nothing`) gate bootstrap of
+nucypher/SGFHE.jl, written as literally as possible against the reference sources so that it is
+"obviously correct".  Only `tests/`, `__graft_entry__.smoke()` and the `cpu_baseline` leg of
+`bench.py` may import anything under `oracle/`.
+
+PARITY STATUS: "parity unpinned" at the bit level against the Julia build.  The reference holds
+no golden vectors / known-answer tests, Julia and DarkIntegers.jl
+(~0.1.0, un-vendored, /root/reference/Project.toml:7,20) are absent from this image, so the
+oracle is pinned (a) mathematically: with `rng = nothing` every step is exact arithmetic on
+canonical representatives of Z_Q / Z_r, so any correct implementation yields the same bytes, and
+(b) by the reference's own property tests restated in tests/test_oracle_properties.py
+(test/internals.test.jl:26-166, test/api.test.jl:45-83).
+
+Every function cites the reference file:line it follows (paths relative to /root/reference).
+Polynomial products use Kronecker substitution on Python integers: an independent algorithm
+from the NTTs used by the C oracle and by the HIP engine.
+"""
+
+from dataclasses import dataclass
+
+MASK64 = (1 << 64) - 1
+
+
+# ----------------------------------------------------------------------------------------------
+# Deterministic PRNG shared (bit for bit) with oracle/sgfhe_oracle.c -- the build's own generator,
+# not Julia's MersenneTwister.
+# ----------------------------------------------------------------------------------------------
+
+class SplitMix64:
+    def __init__(self, seed):
+        self.s = seed & MASK64
+
+    def next(self):
+        self.s = (self.s + 0x9E3779B97F4A7C15) & MASK64
+        z = self.s
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & MASK64
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & MASK64
+        return z ^ (z >> 31)
+
+    def below_wide(self, bound):
+        """Value in [0, bound) from 128 random bits: ((hi << 64) | lo) mod bound; hi drawn first."""
+        hi = self.next()
+        lo = self.next()
+        return ((hi << 64) | lo) % bound
+
+    def below(self, bound):
+        """Value in [0, bound) from one 64-bit draw (bound < 2^63)."""
+        return self.next() % bound
+
+
+# ----------------------------------------------------------------------------------------------
+# Primality / find_modulus
+# ----------------------------------------------------------------------------------------------
+
+_SMALL_PRIMES = (2, 3, 5, 7, 11, 13, 17, 19, 23, 29, 31, 37)
+
+
+def is_prime(x):
+    """Deterministic Miller-Rabin for x < 3.3e24, probabilistic-strong beyond (40 fixed bases).
+    Stands in for Primes.isprime (src/utils.jl:19)."""
+    if x < 2:
+        return False
+    for p in _SMALL_PRIMES:
+        if x % p == 0:
+            return x == p
+    d = x - 1
+    s = 0
+    while d % 2 == 0:
+        d //= 2
+        s += 1
+    bases = _SMALL_PRIMES + (41, 43, 47, 53, 59, 61, 67, 71, 73, 79, 83, 89, 97, 101, 103, 107,
+                             109, 113, 127, 131, 137, 139, 149, 151, 157, 163, 167, 173)
+    for a in bases:
+        if a % x == 0:
+            continue
+        y = pow(a, d, x)
+        if y == 1 or y == x - 1:
+            continue
+        for _ in range(s - 1):
+            y = y * y % x
+            if y == x - 1:
+                break
+        else:
+            return False
+    return True
+
+
+def find_modulus(n, qmin, qmax=None):
+    """src/utils.jl:7-28: smallest prime q >= qmin with q - 1 a multiple of n (q <= qmax)."""
+    j = -((-(qmin - 1)) // n)          # cld(qmin - 1, n)
+    while True:
+        q = j * n + 1
+        if qmax is not None and q > qmax:
+            break
+        if is_prime(q):
+            return q
+        j += 1
+    raise ValueError("Could not find a modulus between %d and %s" % (qmin, qmax))
+
+
+# ----------------------------------------------------------------------------------------------
+# Params
+# ----------------------------------------------------------------------------------------------
+
+@dataclass(frozen=True)
+class Params:
+    """src/fhe.jl:27-99.  `ell` is the decomposition length fixed at fhe.jl:576."""
+    n: int
+    r: int
+    q: int
+    Q: int
+    t: int
+    m: int
+    B: int
+    Dr: int
+    Dq: int
+    DQ_tilde: int
+    ell: int = 2
+
+    @staticmethod
+    def make(n):
+        """Params(n): src/fhe.jl:43-97."""
+        assert n >= 64 and (n & (n - 1)) == 0                       # fhe.jl:45-46
+        r = 16 * n                                                  # fhe.jl:53
+        q = find_modulus(2 * n, r * n)                              # fhe.jl:57
+        t = r.bit_length() - 1 - 1                                  # fhe.jl:61  log2(r) - 1
+        m = r // 2                                                  # fhe.jl:62
+        Qmin = r ** 4 * n ** 2 * 1220                               # fhe.jl:64
+        Qmax = r ** 4 * n ** 2 * 1225                               # fhe.jl:65
+        Q = find_modulus(2 * m, Qmin, Qmax)                         # fhe.jl:69
+        B = r ** 2 * n * 35                                         # fhe.jl:87
+        return Params(n=n, r=r, q=q, Q=Q, t=t, m=m, B=B, Dr=r // 4, Dq=q // 4,
+                      DQ_tilde=Q // 8)                              # fhe.jl:88-90
+
+    @staticmethod
+    def custom(n, Q, B, r=None, m=None, DQ_tilde=None):
+        """Synthetic parameter sets (BASELINE.json configs 3 and 4): same
+        structure (r = 16 n, m = r / 2, ell = 2) with a caller-chosen modulus and gadget base."""
+        r = 16 * n if r is None else r
+        m = r // 2 if m is None else m
+        assert B * B >= Q                                           # src/utils.jl:145
+        return Params(n=n, r=r, q=0, Q=Q, t=r.bit_length() - 2, m=m, B=B, Dr=r // 4, Dq=0,
+                      DQ_tilde=Q // 8 if DQ_tilde is None else DQ_tilde)
+
+
+def gadget_matrix(p):
+    """src/fhe.jl:119-122."""
+    return [[1, 0], [p.B, 0], [0, 1], [0, p.B]]
+
+
+# ----------------------------------------------------------------------------------------------
+# Polynomials in Z_Q[x]/(x^N + 1): plain Python lists of canonical residues
+# ----------------------------------------------------------------------------------------------
+
+def poly_mul(a, b, Q):
+    """DarkIntegers `Polynomial * Polynomial` with negacyclic_modulus: exact product mod
+    (x^N + 1, Q) (call sites src/fhe.jl:195,527-528).  Kronecker substitution."""
+    N = len(a)
+    assert len(b) == N
+    slot = (2 * (Q - 1).bit_length() + N.bit_length() + 8 + 7) // 8      # bytes per slot
+    pa = int.from_bytes(b"".join(c.to_bytes(slot, "little") for c in a), "little")
+    pb = int.from_bytes(b"".join(c.to_bytes(slot, "little") for c in b), "little")
+    prod = (pa * pb).to_bytes(2 * N * slot, "little")
+    out = [0] * N
+    for i in range(N):
+        lo = int.from_bytes(prod[i * slot:(i + 1) * slot], "little")
+        hi = int.from_bytes(prod[(i + N) * slot:(i + N + 1) * slot], "little")
+        out[i] = (lo - hi) % Q
+    return out
+
+
+def poly_mul_schoolbook(a, b, Q):
+    """O(N^2) reference for poly_mul (used only by tests)."""
+    N = len(a)
+    out = [0] * N
+    for i, x in enumerate(a):
+        if x == 0:
+            continue
+        for j, y in enumerate(b):
+            k = i + j
+            if k < N:
+                out[k] = (out[k] + x * y) % Q
+            else:
+                out[k - N] = (out[k - N] - x * y) % Q
+    return out
+
+
+def poly_add(a, b, Q):
+    return [(x + y) % Q for x, y in zip(a, b)]
+
+
+def poly_sub(a, b, Q):
+    return [(x - y) % Q for x, y in zip(a, b)]
+
+
+def mul_by_monomial(a, j, Q):
+    """DarkIntegers mul_by_monomial(p, j): p * x^j mod (x^N + 1), any integer j
+    (docs/src/theory.md:23-32; call sites src/fhe.jl:555,573)."""
+    N = len(a)
+    j %= 2 * N
+    out = [0] * N
+    for i, c in enumerate(a):
+        k = i + j
+        s = (k // N) & 1
+        out[k % N] = (Q - c) % Q if s else c
+    return out
+
+
+def resize(a, new_len):
+    """DarkIntegers resize: zero-pad (src/fhe.jl:185)."""
+    return list(a) + [0] * (new_len - len(a))
+
+
+# ----------------------------------------------------------------------------------------------
+# rescale / reduce_modulus / flatten
+# ----------------------------------------------------------------------------------------------
+
+def rescale(new_max, x, old_max, round_result):
+    """src/utils.jl:78-92."""
+    q, r = divmod(x * new_max, old_max)               # mulhilo + divremhilo, utils.jl:81-82
+    if round_result:
+        if r >= old_max // 2 + (1 if old_max % 2 else 0):       # utils.jl:84
+            q += 1
+            if q == new_max:                                     # utils.jl:86-88
+                q = 0
+    return q
+
+
+def reduce_modulus(new_modulus, x, old_modulus, floor_result=False, new_max=None):
+    """src/utils.jl:107-117 (scalar)."""
+    return rescale(new_modulus if new_max is None else new_max, x, old_modulus, not floor_result)
+
+
+def flatten(a, B, ell, Q):
+    """Deterministic flatten, src/utils.jl:155-189.  Returns `ell` residues mod Q."""
+    s = (B - 1) // 2 if B % 2 else B // 2 - 1                     # utils.jl:162-166
+    pwrs = [B ** i for i in range(ell)]                           # utils.jl:168
+    offset = sum(pwrs) * s                                        # utils.jl:169
+    decomp = [0] * ell
+    a = (a + offset) % Q                                          # utils.jl:179
+    for i in range(ell - 1, 0, -1):                               # utils.jl:170-175
+        quot, a = divmod(a, pwrs[i])                              # `r, a = divrem(...)`: r = quotient
+        decomp[i] = quot
+    decomp[0] = a                                                 # utils.jl:181
+    return [(d - s) % Q for d in decomp]                          # utils.jl:183-185
+
+
+def flatten_poly(a, B, ell, Q):
+    """src/utils.jl:253-264."""
+    results = [[0] * len(a) for _ in range(ell)]
+    for j, c in enumerate(a):
+        d = flatten(c, B, ell, Q)
+        for i in range(ell):
+            results[i][j] = d[i]
+    return results
+
+
+# ----------------------------------------------------------------------------------------------
+# Keys, LWE plumbing
+# ----------------------------------------------------------------------------------------------
+
+def private_key(p, seed):
+    """src/fhe.jl:130-138: n random bits (the build's PRNG, one draw per bit, low bit)."""
+    g = SplitMix64(seed)
+    return [g.next() & 1 for _ in range(p.n)]
+
+
+def bootstrap_key(p, sk, seed, noise=None):
+    """src/fhe.jl:181-201.  Returns key[k][row][col] = list of m residues mod Q.
+    Draw order: for k, for row: a_row[0..m) (128-bit draws), then e_row[0..m) (64-bit draws)."""
+    g = SplitMix64(seed)
+    noise = p.n if noise is None else noise
+    ext_key = resize(sk, p.m)                                     # fhe.jl:185
+    G = gadget_matrix(p)                                          # fhe.jl:190
+    key = []
+    for k in range(p.n):
+        C = []
+        for row in range(4):
+            aj = [g.below_wide(p.Q) for _ in range(p.m)]          # fhe.jl:193
+            ej = [(g.below(2 * noise + 1) - noise) % p.Q for _ in range(p.m)]   # fhe.jl:194
+            bj = poly_add(poly_mul(aj, ext_key, p.Q), ej, p.Q)    # fhe.jl:195
+            aj = list(aj)
+            # fhe.jl:196: `.+ ext_key.coeffs[i] * G` adds to the constant coefficient
+            aj[0] = (aj[0] + ext_key[k] * G[row][0]) % p.Q
+            bj[0] = (bj[0] + ext_key[k] * G[row][1]) % p.Q
+            C.append([aj, bj])
+        key.append(C)
+    return key
+
+
+def lwe_encrypt_bit(p, sk, bit, g):
+    """One LWE of `bit` over Z_r with the noise of src/fhe.jl:318-322 after split_ciphertext
+    (fhe.jl:287-290): a uniform in [0, r)^n, b = <a, s> + w + bit * Dr, |w| <= Dr / 8."""
+    a = [g.below(p.r) for _ in range(p.n)]
+    w_range = p.Dr // 8
+    w = g.below(2 * w_range + 1) - w_range
+    b = (sum(x * s for x, s in zip(a, sk)) + w + bit * p.Dr) % p.r
+    return a, b
+
+
+def lwe_decrypt_bit(p, sk, lwe):
+    """src/fhe.jl:504-507."""
+    a, b = lwe
+    b1 = (b - sum(x * s for x, s in zip(a, sk))) % p.r
+    return ((b1 + p.Dr // 2) % p.r) // p.Dr
+
+
+def extract(a, i, n, Q):
+    """src/fhe.jl:237-244 with the reference's 1-based i."""
+    N = len(a)
+    assert i <= N
+    if i < n:
+        head = [a[k - 1] for k in range(i, 0, -1)]
+        tail = [(Q - a[k - 1]) % Q for k in range(N, N - (n - i - 1) - 1, -1)]
+        return head + tail
+    return [a[k - 1] for k in range(i, i - n, -1)]
+
+
+# ----------------------------------------------------------------------------------------------
+# Bootstrap
+# ----------------------------------------------------------------------------------------------
+
+def external_product(a, b, A, B, ell, Q):
+    """src/fhe.jl:519-530 (deterministic flatten)."""
+    u = flatten_poly(a, B, ell, Q) + flatten_poly(b, B, ell, Q)          # fhe.jl:524-526
+    N = len(a)
+    a_res = [0] * N
+    b_res = [0] * N
+    for i in range(2 * ell):
+        a_res = poly_add(a_res, poly_mul(u[i], A[i][0], Q), Q)           # fhe.jl:527
+        b_res = poly_add(b_res, poly_mul(u[i], A[i][1], Q), Q)           # fhe.jl:528
+    return a_res, b_res
+
+
+def initial_poly(p):
+    """src/fhe.jl:535-548."""
+    coeffs = [0] * p.m
+    for i in range(-(p.Dr - 1), p.Dr):
+        sign = 1 if ((i // p.m) % 2 == 0) else -1
+        coeffs[i % p.m] = (coeffs[i % p.m] + sign) % p.Q
+    return coeffs
+
+
+def mul_by_xj_minus_one(poly, j, Q):
+    """src/fhe.jl:554-556."""
+    return poly_sub(mul_by_monomial(poly, j, Q), poly, Q)
+
+
+def bootstrap_internal(p, bkey, lwe1, lwe2, trace=None):
+    """src/fhe.jl:559-595.  Returns three LWEs over Z_Q: (AND, OR, XOR)."""
+    Q = p.Q
+    ua = [(x + y) % p.r for x, y in zip(lwe1[0], lwe2[0])]               # fhe.jl:566
+    ub = (lwe1[1] + lwe2[1]) % p.r
+    t = initial_poly(p)                                                  # fhe.jl:568
+    a = [0] * p.m                                                        # fhe.jl:570
+    b = [(c * p.DQ_tilde) % Q for c in mul_by_monomial(t, -ub, Q)]       # fhe.jl:572-573
+    G = gadget_matrix(p)
+    for k in range(p.n):                                                 # fhe.jl:579-582
+        A = []
+        for row in range(4):
+            Arow = []
+            for col in range(2):
+                x = mul_by_xj_minus_one(bkey[k][row][col], ua[k], Q)
+                x[0] = (x[0] + G[row][col]) % Q                          # `.+ G`: constant term
+                Arow.append(x)
+            A.append(Arow)
+        a, b = external_product(a, b, A, p.B, p.ell, Q)
+        if trace is not None:
+            trace(k, a, b)
+    m, n = p.m, p.n
+    and_a = extract(a, 3 * m // 4 + 1, n, Q)                             # fhe.jl:585-587
+    and_b = (p.DQ_tilde + b[3 * m // 4]) % Q
+    or_a = [(Q - x) % Q for x in extract(a, m // 4 + 1, n, Q)]           # fhe.jl:588-590
+    or_b = (p.DQ_tilde - b[m // 4]) % Q
+    xor_a = [(x - y) % Q for x, y in zip(or_a, and_a)]                   # fhe.jl:592
+    xor_b = (or_b - and_b) % Q
+    return (and_a, and_b), (or_a, or_b), (xor_a, xor_b)
+
+
+def bootstrap(p, bkey, lwe1, lwe2):
+    """src/fhe.jl:608-621.  Returns three LWEs over Z_r: (AND, OR, XOR)."""
+    out = []
+    for a, b in bootstrap_internal(p, bkey, lwe1, lwe2):
+        out.append(([reduce_modulus(p.r, x, p.Q) for x in a],            # fhe.jl:616-618,644-648
+                    reduce_modulus(p.r, b, p.Q)))
+    return tuple(out)
+
+
+# ----------------------------------------------------------------------------------------------
+# RNS2Number (src/rns.jl) -- config 4 boundary conversions
+# ----------------------------------------------------------------------------------------------
+
+def rns2_from_int(x, m1, m2):
+    """src/rns.jl:16-18."""
+    return x % m1, x % m2
+
+
+def rns2_to_int(v1, v2, m1, m2):
+    """src/rns.jl:32-40."""
+    m = m1 * m2
+    c1 = pow(m2, m1 - 1, m)
+    c2 = pow(m1, m2 - 1, m)
+    return (v1 * c1 + v2 * c2) % m

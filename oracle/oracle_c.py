@@ -1,0 +1,215 @@
+"""
+TEST INFRASTRUCTURE -- NOT PRODUCT CODE.
+
+ctypes binding of oracle/libsgfhe_oracle.so (the C restatement of the reference path, see
+sgfhe_oracle.h).  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+import this module.  128-bit residues are numpy uint64 arrays with a trailing axis of 2
+({lo, hi}).
+"""
+
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libsgfhe_oracle.so")
+
+_u64p = ctypes.POINTER(ctypes.c_uint64)
+_u8p = ctypes.POINTER(ctypes.c_uint8)
+
+
+def build(force=False):
+    if force or not os.path.exists(_LIB_PATH) or (
+            os.path.getmtime(_LIB_PATH) < os.path.getmtime(os.path.join(_HERE, "sgfhe_oracle.c"))):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "libsgfhe_oracle.so"],
+                              stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = ctypes.CDLL(_LIB_PATH)
+        L.sgo_ctx_create.restype = ctypes.c_void_p
+        L.sgo_ctx_create.argtypes = [_u64p]
+        L.sgo_ctx_destroy.argtypes = [ctypes.c_void_p]
+        L.sgo_ctx_uses_ntt.argtypes = [ctypes.c_void_p]
+        L.sgo_find_modulus.argtypes = [ctypes.c_uint64, _u64p, _u64p, _u64p]
+        L.sgo_params_make.argtypes = [ctypes.c_uint64, _u64p]
+        L.sgo_rescale.argtypes = [_u64p, _u64p, _u64p, ctypes.c_int, _u64p]
+        L.sgo_flatten.argtypes = [ctypes.c_void_p, _u64p, _u64p]
+        L.sgo_poly_mul.argtypes = [ctypes.c_void_p, _u64p, _u64p, _u64p]
+        L.sgo_poly_mul_schoolbook.argtypes = [ctypes.c_void_p, _u64p, _u64p, _u64p]
+        L.sgo_external_product.argtypes = [ctypes.c_void_p, _u64p, _u64p, _u64p, _u64p, _u64p]
+        L.sgo_private_key.argtypes = [ctypes.c_void_p, ctypes.c_uint64, _u64p]
+        L.sgo_bootstrap_key.argtypes = [ctypes.c_void_p, _u64p, ctypes.c_uint64, ctypes.c_uint64,
+                                        _u64p, ctypes.c_int]
+        L.sgo_lwe_encrypt_bits.argtypes = [ctypes.c_void_p, _u64p, _u8p, ctypes.c_size_t,
+                                           ctypes.c_uint64, _u64p, _u64p]
+        L.sgo_lwe_decrypt_bit.argtypes = [ctypes.c_void_p, _u64p, _u64p, ctypes.c_uint64]
+        L.sgo_bootstrap_batch.argtypes = [ctypes.c_void_p, _u64p, _u64p, _u64p, _u64p, _u64p,
+                                          ctypes.c_size_t, _u64p, ctypes.c_int, ctypes.c_uint64,
+                                          _u64p, ctypes.c_int]
+        _lib = L
+    return _lib
+
+
+def _p(arr):
+    return arr.ctypes.data_as(_u64p)
+
+
+def to_words(x):
+    """Python int -> [lo, hi]."""
+    return [x & 0xFFFFFFFFFFFFFFFF, (x >> 64) & 0xFFFFFFFFFFFFFFFF]
+
+
+def ints_to_u128(vals):
+    """Sequence of Python ints -> uint64 array [..., 2]."""
+    out = np.empty((len(vals), 2), dtype=np.uint64)
+    for i, v in enumerate(vals):
+        out[i, 0] = v & 0xFFFFFFFFFFFFFFFF
+        out[i, 1] = v >> 64
+    return out
+
+
+def u128_to_ints(arr):
+    flat = np.ascontiguousarray(arr).reshape(-1, 2)
+    return [int(lo) | (int(hi) << 64) for lo, hi in flat]
+
+
+def params_words(n, r, m, ell, Q, B, DQ_tilde):
+    return np.array([n, r, m, ell] + to_words(Q) + to_words(B) + to_words(DQ_tilde),
+                    dtype=np.uint64)
+
+
+def params_make(n):
+    """fhe.jl:43-97 through the C restatement; returns dict."""
+    w = np.zeros(10, dtype=np.uint64)
+    rc = lib().sgo_params_make(n, _p(w))
+    if rc:
+        raise ValueError("sgo_params_make(%d) failed: %d" % (n, rc))
+    return dict(n=int(w[0]), r=int(w[1]), m=int(w[2]), ell=int(w[3]),
+                Q=int(w[4]) | (int(w[5]) << 64), B=int(w[6]) | (int(w[7]) << 64),
+                DQ_tilde=int(w[8]) | (int(w[9]) << 64))
+
+
+class Oracle:
+    """One parameter set of the C restatement."""
+
+    def __init__(self, n, r, m, Q, B, DQ_tilde, ell=2):
+        self.n, self.r, self.m, self.Q, self.B, self.DQ_tilde, self.ell = n, r, m, Q, B, DQ_tilde, ell
+        self._words = params_words(n, r, m, ell, Q, B, DQ_tilde)
+        self._ctx = lib().sgo_ctx_create(_p(self._words))
+        if not self._ctx:
+            raise ValueError("sgo_ctx_create rejected the parameters")
+
+    @classmethod
+    def from_params(cls, p):
+        """p: anything with n, r, m, Q, B, DQ_tilde attributes."""
+        return cls(p.n, p.r, p.m, p.Q, p.B, p.DQ_tilde)
+
+    @classmethod
+    def make(cls, n):
+        d = params_make(n)
+        return cls(d["n"], d["r"], d["m"], d["Q"], d["B"], d["DQ_tilde"])
+
+    def __del__(self):
+        try:
+            if self._ctx:
+                lib().sgo_ctx_destroy(self._ctx)
+                self._ctx = None
+        except Exception:
+            pass
+
+    @property
+    def uses_ntt(self):
+        return bool(lib().sgo_ctx_uses_ntt(self._ctx))
+
+    def flatten(self, a):
+        ain = np.array(to_words(a), dtype=np.uint64)
+        out = np.zeros(4, dtype=np.uint64)
+        lib().sgo_flatten(self._ctx, _p(ain), _p(out))
+        return [int(out[0]) | (int(out[1]) << 64), int(out[2]) | (int(out[3]) << 64)]
+
+    def poly_mul(self, a, b, schoolbook=False):
+        a = np.ascontiguousarray(a, dtype=np.uint64)
+        b = np.ascontiguousarray(b, dtype=np.uint64)
+        out = np.zeros((self.m, 2), dtype=np.uint64)
+        fn = lib().sgo_poly_mul_schoolbook if schoolbook else lib().sgo_poly_mul
+        fn(self._ctx, _p(a), _p(b), _p(out))
+        return out
+
+    def external_product(self, a, b, A):
+        a = np.ascontiguousarray(a, dtype=np.uint64)
+        b = np.ascontiguousarray(b, dtype=np.uint64)
+        A = np.ascontiguousarray(A, dtype=np.uint64)
+        assert A.shape == (4, 2, self.m, 2)
+        ra = np.zeros((self.m, 2), dtype=np.uint64)
+        rb = np.zeros((self.m, 2), dtype=np.uint64)
+        lib().sgo_external_product(self._ctx, _p(a), _p(b), _p(A), _p(ra), _p(rb))
+        return ra, rb
+
+    def private_key(self, seed):
+        sk = np.zeros(self.n, dtype=np.uint64)
+        lib().sgo_private_key(self._ctx, seed, _p(sk))
+        return sk
+
+    def bootstrap_key(self, sk, seed, noise=None, threads=None):
+        """[n][4][2][m][2] uint64 canonical residues (fhe.jl:181-201)."""
+        bkey = np.zeros((self.n, 4, 2, self.m, 2), dtype=np.uint64)
+        sk = np.ascontiguousarray(sk, dtype=np.uint64)
+        lib().sgo_bootstrap_key(self._ctx, _p(sk), seed, self.n if noise is None else noise,
+                                _p(bkey), threads or os.cpu_count() or 1)
+        return bkey
+
+    def lwe_encrypt_bits(self, sk, bits, seed):
+        bits = np.ascontiguousarray(bits, dtype=np.uint8)
+        sk = np.ascontiguousarray(sk, dtype=np.uint64)
+        a = np.zeros((len(bits), self.n), dtype=np.uint64)
+        b = np.zeros(len(bits), dtype=np.uint64)
+        lib().sgo_lwe_encrypt_bits(self._ctx, _p(sk), bits.ctypes.data_as(_u8p), len(bits), seed,
+                                   _p(a), _p(b))
+        return a, b
+
+    def lwe_decrypt_bits(self, sk, a, b):
+        sk = np.ascontiguousarray(sk, dtype=np.uint64)
+        a = np.ascontiguousarray(a, dtype=np.uint64).reshape(-1, self.n)
+        b = np.ascontiguousarray(b, dtype=np.uint64).reshape(-1)
+        return np.array([lib().sgo_lwe_decrypt_bit(self._ctx, _p(sk), _p(a[i]), int(b[i]))
+                         for i in range(len(b))], dtype=np.uint8)
+
+    def bootstrap_batch(self, bkey, a1, b1, a2, b2, raw=False, n_iters=None, want_acc=False,
+                        threads=None):
+        """fhe.jl:559-621 over a batch.  Returns out ([batch][3][n+1] uint64, or [..][2] if raw)
+        and, if want_acc, the accumulators [batch][2][m][2] after `n_iters` iterations."""
+        bkey = np.ascontiguousarray(bkey, dtype=np.uint64)
+        a1 = np.ascontiguousarray(a1, dtype=np.uint64).reshape(-1, self.n)
+        a2 = np.ascontiguousarray(a2, dtype=np.uint64).reshape(-1, self.n)
+        b1 = np.ascontiguousarray(b1, dtype=np.uint64).reshape(-1)
+        b2 = np.ascontiguousarray(b2, dtype=np.uint64).reshape(-1)
+        batch = a1.shape[0]
+        shape = (batch, 3, self.n + 1, 2) if raw else (batch, 3, self.n + 1)
+        out = np.zeros(shape, dtype=np.uint64)
+        acc = np.zeros((batch, 2, self.m, 2), dtype=np.uint64) if want_acc else None
+        rc = lib().sgo_bootstrap_batch(self._ctx, _p(bkey), _p(a1), _p(b1), _p(a2), _p(b2), batch,
+                                       _p(out), 1 if raw else 0,
+                                       self.n if n_iters is None else n_iters,
+                                       _p(acc) if want_acc else None,
+                                       threads or min(batch, os.cpu_count() or 1))
+        if rc:
+            raise RuntimeError("sgo_bootstrap_batch failed: %d" % rc)
+        return (out, acc) if want_acc else out
+
+
+def rescale(new_max, x, old_max, round_result):
+    o = np.zeros(2, dtype=np.uint64)
+    lib().sgo_rescale(_p(np.array(to_words(new_max), dtype=np.uint64)),
+                      _p(np.array(to_words(x), dtype=np.uint64)),
+                      _p(np.array(to_words(old_max), dtype=np.uint64)), int(round_result), _p(o))
+    return int(o[0]) | (int(o[1]) << 64)

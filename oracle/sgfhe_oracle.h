@@ -1,0 +1,81 @@
+/*
+ * TEST INFRASTRUCTURE -- NOT PRODUCT CODE.
+ *
+ * C restatement ("port") of the deterministic gate bootstrap of nucypher/SGFHE.jl, in the
+ * reference's own shape: 128-bit Montgomery residues (DarkIntegers MgModUInt{UInt128,Q},
+ * /root/reference/src/fhe.jl:83-85,104), one full NTT polynomial multiply per
+ * `Polynomial * Polynomial` call site (8 per external product, fhe.jl:527-528).
+ *
+ * PARITY STATUS: "parity unpinned" at the bit level against the Julia build (the reference has
+ * no golden vectors and Julia / DarkIntegers.jl ~0.1.0 are absent here); pinned mathematically
+ * (exact arithmetic on canonical representatives) and by the reference's property tests,
+ * restated in tests/.  Cross-checked bit for bit against oracle/bigint_oracle.py.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
+ *
+ * All 128-bit values cross the ABI as little-endian {lo, hi} uint64 pairs.
+ */
+#ifndef SGFHE_ORACLE_H
+#define SGFHE_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct sgo_ctx sgo_ctx;
+
+/* words = {n, r, m, ell, Q_lo, Q_hi, B_lo, B_hi, DQtilde_lo, DQtilde_hi} (fhe.jl:27-41). */
+sgo_ctx *sgo_ctx_create(const uint64_t *words);
+void sgo_ctx_destroy(sgo_ctx *ctx);
+/* 1 if Q is prime with 2m | Q-1 (NTT multiply), 0 if the schoolbook multiply is used. */
+int sgo_ctx_uses_ntt(const sgo_ctx *ctx);
+
+/* utils.jl:7-28 find_modulus; qmax_* = 0,0 means "no upper bound". Returns 0 on success. */
+int sgo_find_modulus(uint64_t n, const uint64_t *qmin, const uint64_t *qmax, uint64_t *out);
+/* fhe.jl:43-97 Params(n): fills words[10] as for sgo_ctx_create. Returns 0 on success. */
+int sgo_params_make(uint64_t n, uint64_t *words);
+
+/* utils.jl:78-92 rescale(new_max, x, old_max, round_result) on 128-bit operands. */
+void sgo_rescale(const uint64_t *new_max, const uint64_t *x, const uint64_t *old_max,
+                 int round_result, uint64_t *out);
+/* utils.jl:155-189 deterministic flatten of one residue: out[ell] residues mod Q. */
+void sgo_flatten(const sgo_ctx *ctx, const uint64_t *a, uint64_t *out);
+/* Exact negacyclic product mod (x^m + 1, Q): DarkIntegers Polynomial * Polynomial. */
+void sgo_poly_mul(const sgo_ctx *ctx, const uint64_t *a, const uint64_t *b, uint64_t *out);
+void sgo_poly_mul_schoolbook(const sgo_ctx *ctx, const uint64_t *a, const uint64_t *b,
+                             uint64_t *out);
+/* fhe.jl:519-530 external_product(nothing, a, b, A[4][2], B, ell). */
+void sgo_external_product(const sgo_ctx *ctx, const uint64_t *a, const uint64_t *b,
+                          const uint64_t *A, uint64_t *a_res, uint64_t *b_res);
+
+/* Keys and LWE plumbing with the build's SplitMix64 (same draws as bigint_oracle.py). */
+void sgo_private_key(const sgo_ctx *ctx, uint64_t seed, uint64_t *sk /* [n] bits */);
+/* fhe.jl:181-201; bkey is [n][4][2][m] residues (2 words each); noise bound as fhe.jl:194. */
+void sgo_bootstrap_key(const sgo_ctx *ctx, const uint64_t *sk, uint64_t seed, uint64_t noise,
+                       uint64_t *bkey, int threads);
+/* `count` LWEs of bits[count] from one generator seeded with `seed` (fhe.jl:310-328,287-290). */
+void sgo_lwe_encrypt_bits(const sgo_ctx *ctx, const uint64_t *sk, const uint8_t *bits,
+                          size_t count, uint64_t seed, uint64_t *a /* [count][n] */,
+                          uint64_t *b /* [count] */);
+/* fhe.jl:504-507 */
+int sgo_lwe_decrypt_bit(const sgo_ctx *ctx, const uint64_t *sk, const uint64_t *a, uint64_t b);
+
+/*
+ * fhe.jl:559-621.  out is [batch][3][n+1] (a[0..n) then b; order AND, OR, XOR):
+ *   raw == 0: uint64 words in [0, r) after ModRed (fhe.jl:616-618)
+ *   raw == 1: 128-bit residues mod Q ({lo, hi} pairs) as returned by _bootstrap_internal.
+ * n_iters < n truncates the k-loop (timing samples / intermediate checks); acc_out, if not
+ * NULL, receives the accumulator pair [batch][2][m] after the loop.
+ * threads: OpenMP threads over the batch.  Returns 0 on success.
+ */
+int sgo_bootstrap_batch(const sgo_ctx *ctx, const uint64_t *bkey, const uint64_t *a1,
+                        const uint64_t *b1, const uint64_t *a2, const uint64_t *b2, size_t batch,
+                        uint64_t *out, int raw, uint64_t n_iters, uint64_t *acc_out, int threads);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
