@@ -1,0 +1,150 @@
+/*
+ * sgfhe_hip.h -- C ABI of libsgfhe_hip.so, the MI355X (gfx950) gate-bootstrap engine.
+ *
+ * Drop-in boundary for the hot path of nucypher/SGFHE.jl (paths relative to /root/reference):
+ * the reference has no FFI of its own (pure Julia); each entry point
+ * below names the Julia function or data structure whose work it takes over, and
+ * INTEGRATION.md shows the `ccall` stub a maintainer adds on the Julia side.
+ *
+ * Conventions
+ *   - every function returns an int32 status: 0 = OK, negative = sgfhe_status error
+ *   - no exception crosses the boundary; sgfhe_last_error_string() explains the last failure
+ *   - the caller owns every buffer it passes; the library owns device memory behind the handle
+ *   - one ctx per device; a ctx is not thread-safe (one host thread, or an external lock)
+ *   - residues mod Q cross the boundary as canonical representatives in [0, Q), little-endian
+ *     `limbs` x uint64 each, limbs = 2 (16 bytes, the reference's UInt128 storage width) unless
+ *     stated otherwise; LWE words over Z_r are one uint64 each, exactly the memory of
+ *     `Vector{ModUInt{UInt64, r}}` (src/fhe.jl:206-209)
+ */
+#ifndef SGFHE_HIP_H
+#define SGFHE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct sgfhe_ctx sgfhe_ctx;
+
+typedef enum {
+    SGFHE_OK = 0,
+    SGFHE_ERR_INVALID_ARG = -1,   /* NULL pointer, size mismatch, malformed parameter set */
+    SGFHE_ERR_UNSUPPORTED = -2,   /* parameter set outside what the engine implements */
+    SGFHE_ERR_NO_DEVICE = -3,     /* no usable gfx950 device / HIP runtime failure at start-up */
+    SGFHE_ERR_HIP = -4,           /* a HIP runtime call failed (see last_error_string) */
+    SGFHE_ERR_NO_KEY = -5,        /* bootstrap requested before a bootstrap key was uploaded */
+    SGFHE_ERR_OOM = -6            /* host or device allocation failed */
+} sgfhe_status;
+
+/*
+ * Scheme parameters: the fields of `Params` (src/fhe.jl:27-41) that the hot path reads.
+ * Params(n) (src/fhe.jl:43-97) fixes r = 16 n, m = r / 2, ell = 2 (src/fhe.jl:576),
+ * B = 35 r^2 n, DQ_tilde = Q / 8; synthetic sets (BASELINE.json configs 3 / 4) choose their own
+ * Q and B with the same structure.  Q need not be prime: the engine computes the exact integer
+ * negacyclic product in a residue number system of word-size NTT primes and reduces mod Q.
+ */
+typedef struct {
+    uint64_t n;           /* LWE dimension (polynomial length of the small ring) */
+    uint64_t r;           /* LWE modulus, power of two, r = 2 m */
+    uint64_t m;           /* bootstrap polynomial length, power of two, 2^6 .. 2^13 */
+    uint64_t ell;         /* gadget decomposition length; must be 2 */
+    uint64_t Q[2];        /* bootstrap modulus, Q < 2^94 */
+    uint64_t B[2];        /* gadget base, B^2 >= Q, B < 2^62 */
+    uint64_t DQ_tilde[2]; /* Q / 8 for Params(n) */
+} sgfhe_params;
+
+/* flags of sgfhe_bootstrap_batch* */
+#define SGFHE_FLAG_RAW_MODQ 1u /* return _bootstrap_internal's LWEs over Z_Q (fhe.jl:559-595) as
+                                  16-byte residues instead of ModRed words (fhe.jl:616-618) */
+
+/* Library / build information: "sgfhe_hip <version> gfx950". */
+const char *sgfhe_version(void);
+
+/* Create an engine for one parameter set on HIP device `device`.
+ * Replaces: the type-level set-up Julia does when `Params(n)` fixes MgModUInt{LargeType, Q}
+ * (src/fhe.jl:71-85,102-104) -- here: RNS primes, twiddle tables, CRT and flatten constants. */
+int32_t sgfhe_ctx_create(const sgfhe_params *p, int device, sgfhe_ctx **out);
+int32_t sgfhe_ctx_destroy(sgfhe_ctx *ctx);
+const char *sgfhe_last_error_string(const sgfhe_ctx *ctx);
+
+/* Batch-scheduling knob: bootstraps that move through the k-loop in lock-step (0 = default). */
+int32_t sgfhe_set_chunk(sgfhe_ctx *ctx, uint32_t chunk);
+
+/*
+ * Upload a bootstrap key.  `canonical` (host memory) holds value.(p.coeffs) of
+ * `BootstrapKey.key` (src/fhe.jl:176-201) in index order [k in 0..n)[row in 0..4)[col in 0..2)
+ * [coef in 0..m), each residue 2 x uint64 little-endian; n_words = n * 8 * m * 2.
+ * One-time: converts to the device form (per-prime forward NTT, Montgomery-scaled).
+ */
+int32_t sgfhe_bkey_upload(sgfhe_ctx *ctx, const uint64_t *canonical, size_t n_words);
+
+/*
+ * Same for a key held as RNS2Number{UInt64, M1, M2} pairs (src/rns.jl:8-24; type_Q of
+ * Scheme2, src/fhe2.jl:76): each coefficient is (v1, v2) = (x mod m1, x mod m2).  The boundary
+ * conversion is the CRT of src/rns.jl:32-40; requires m1 * m2 == Q.
+ */
+int32_t sgfhe_bkey_upload_rns2(sgfhe_ctx *ctx, const uint64_t *pairs, size_t n_words, uint64_t m1,
+                               uint64_t m2);
+
+/* Device-form key blob (for the one-time RCCL broadcast rank 0 -> peers). */
+int32_t sgfhe_bkey_device_form_bytes(const sgfhe_ctx *ctx, size_t *bytes);
+int32_t sgfhe_bkey_export_device_form(sgfhe_ctx *ctx, void *dst_device);
+int32_t sgfhe_bkey_import_device_form(sgfhe_ctx *ctx, const void *src_device);
+
+/*
+ * bootstrap(bkey, nothing, enc_bit1, enc_bit2) (src/fhe.jl:608-621) over a batch.
+ *   a1, a2 : [batch][n] uint64 in [0, r)   (EncryptedBit.lwe.a, src/fhe.jl:206-209,272-274)
+ *   b1, b2 : [batch]    uint64 in [0, r)   (EncryptedBit.lwe.b)
+ *   out    : [batch][3][n + 1] uint64: a[0..n) then b; gate order AND, OR, XOR
+ *            (with SGFHE_FLAG_RAW_MODQ: [batch][3][n + 1][2], residues mod Q)
+ * Deterministic flatten (rng = nothing, src/utils.jl:155-189).  Host pointers; synchronous.
+ */
+int32_t sgfhe_bootstrap_batch(sgfhe_ctx *ctx, const uint64_t *a1, const uint64_t *b1,
+                              const uint64_t *a2, const uint64_t *b2, size_t batch, uint64_t *out,
+                              uint32_t flags);
+
+/* Same with every buffer resident in device memory; asynchronous on the ctx stream
+ * (sgfhe_sync waits).  `stream` = NULL uses the ctx's own stream. */
+int32_t sgfhe_bootstrap_batch_device(sgfhe_ctx *ctx, const uint64_t *a1, const uint64_t *b1,
+                                     const uint64_t *a2, const uint64_t *b2, size_t batch,
+                                     uint64_t *out, uint32_t flags, void *stream);
+int32_t sgfhe_sync(sgfhe_ctx *ctx);
+
+/*
+ * external_product(nothing, a, b, A, Val(B), Val(2)) (src/fhe.jl:519-530), the operation
+ * test/internals.test.jl:144-166 checks.  a, b: [m][2]; A: [4][2][m][2] (row-major A[row][col]);
+ * a_res, b_res: [m][2].  Host pointers; synchronous.  Parity / debug hook.
+ */
+int32_t sgfhe_external_product(sgfhe_ctx *ctx, const uint64_t *a, const uint64_t *b,
+                               const uint64_t *A, uint64_t *a_res, uint64_t *b_res);
+
+/* Parity / debug hook: run the first n_iters iterations of the k-loop (src/fhe.jl:579-582) and
+ * return the accumulator pair (a, b) as canonical residues, acc: [batch][2][m][2]. */
+int32_t sgfhe_debug_accumulators(sgfhe_ctx *ctx, const uint64_t *a1, const uint64_t *b1,
+                                 const uint64_t *a2, const uint64_t *b2, size_t batch,
+                                 uint64_t n_iters, uint64_t *acc);
+
+/* Parity / debug hook: negacyclic NTT of one polynomial modulo RNS prime `prime_index`.
+ * in/out: [m] uint32 residues; forward maps natural order to the engine's slot order,
+ * inverse maps back (and divides by m).  Host pointers. */
+int32_t sgfhe_debug_ntt(sgfhe_ctx *ctx, uint32_t prime_index, int inverse, const uint32_t *in,
+                        uint32_t *out);
+/* Number of RNS primes and their values (primes[] must hold 8 entries). */
+int32_t sgfhe_debug_primes(const sgfhe_ctx *ctx, uint32_t *count, uint32_t *primes);
+
+/*
+ * Measurement hook for bench.py: HIP-event timings taken on the ctx stream around sampled
+ * launches of the two per-iteration kernels since the last reset.
+ *   stats[0] = average external-product kernel time (ms)   stats[1] = its sampled launches
+ *   stats[2] = average CRT/accumulate kernel time (ms)     stats[3] = its sampled launches
+ *   stats[4] = bootstraps per external-product launch (chunk actually used)
+ */
+int32_t sgfhe_timing_enable(sgfhe_ctx *ctx, int enable);
+int32_t sgfhe_timing_read(sgfhe_ctx *ctx, double *stats, int reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,18 @@
+"""sgfhe.jl_amd -- MI355X-native gate-bootstrap engine for Gao's FHE scheme.
+
+Host-side mirror of the SGFHE.jl API for the bootstrap path (`Params`, `PrivateKey`,
+`BootstrapKey`, `encrypt`, `split_ciphertext`, `decrypt`, `bootstrap`) over the C ABI of
+libsgfhe_hip.so (hand-written HIP for gfx950; include/sgfhe_hip.h).  Import as
+`import sgfhe_jl_amd` (repo-root shim; the directory name contains a dot).
+"""
+
+from ._lib import build, lib, LIB_PATH, EXPORTED_SYMBOLS
+from .engine import Engine, SgfheError, FLAG_RAW_MODQ
+from .params import Params, find_modulus, isprime
+from .scheme import (PrivateKey, BootstrapKey, LWE, RLWE, EncryptedBit, PackedCiphertext, encrypt,
+                     extract, split_ciphertext, decrypt, bootstrap, bootstrap_batch)
+
+__all__ = ["build", "lib", "LIB_PATH", "EXPORTED_SYMBOLS", "Engine", "SgfheError",
+           "FLAG_RAW_MODQ", "Params", "find_modulus", "isprime", "PrivateKey", "BootstrapKey",
+           "LWE", "RLWE", "EncryptedBit", "PackedCiphertext", "encrypt", "extract",
+           "split_ciphertext", "decrypt", "bootstrap", "bootstrap_batch"]

@@ -1,0 +1,89 @@
+"""ctypes loader of libsgfhe_hip.so (C ABI: include/sgfhe_hip.h).
+
+The library is hand-written HIP for gfx950 and is the only compute path of this package: there
+is no CPU fallback.  A missing library is built in-tree with hipcc; a failed build or load
+raises.
+"""
+
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(CSRC, "libsgfhe_hip.so")
+
+_u64p = ctypes.POINTER(ctypes.c_uint64)
+_u32p = ctypes.POINTER(ctypes.c_uint32)
+
+
+class SgfheParams(ctypes.Structure):
+    """struct sgfhe_params of include/sgfhe_hip.h."""
+    _fields_ = [("n", ctypes.c_uint64), ("r", ctypes.c_uint64), ("m", ctypes.c_uint64),
+                ("ell", ctypes.c_uint64), ("Q", ctypes.c_uint64 * 2), ("B", ctypes.c_uint64 * 2),
+                ("DQ_tilde", ctypes.c_uint64 * 2)]
+
+
+def _sources_newer():
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))]
+    srcs.append(os.path.join(_HERE, "..", "include", "sgfhe_hip.h"))
+    return any(os.path.getmtime(s) > t for s in srcs if os.path.exists(s))
+
+
+def build(force=False):
+    """Compile the HIP engine for gfx950 (hipcc cross-compiles without a GPU)."""
+    if force or _sources_newer():
+        subprocess.check_call(["make", "-C", CSRC] + (["-B"] if force else []) + ["libsgfhe_hip.so"])
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        build()
+    L = ctypes.CDLL(LIB_PATH)
+    vp, i32, u32, u64, sz = ctypes.c_void_p, ctypes.c_int32, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_size_t
+    sig = {
+        "sgfhe_version": (ctypes.c_char_p, []),
+        "sgfhe_ctx_create": (i32, [ctypes.POINTER(SgfheParams), ctypes.c_int, ctypes.POINTER(vp)]),
+        "sgfhe_ctx_destroy": (i32, [vp]),
+        "sgfhe_last_error_string": (ctypes.c_char_p, [vp]),
+        "sgfhe_set_chunk": (i32, [vp, u32]),
+        "sgfhe_bkey_upload": (i32, [vp, vp, sz]),
+        "sgfhe_bkey_upload_rns2": (i32, [vp, vp, sz, u64, u64]),
+        "sgfhe_bkey_device_form_bytes": (i32, [vp, ctypes.POINTER(sz)]),
+        "sgfhe_bkey_export_device_form": (i32, [vp, vp]),
+        "sgfhe_bkey_import_device_form": (i32, [vp, vp]),
+        "sgfhe_bootstrap_batch": (i32, [vp, vp, vp, vp, vp, sz, vp, u32]),
+        "sgfhe_bootstrap_batch_device": (i32, [vp, vp, vp, vp, vp, sz, vp, u32, vp]),
+        "sgfhe_sync": (i32, [vp]),
+        "sgfhe_external_product": (i32, [vp, vp, vp, vp, vp, vp]),
+        "sgfhe_debug_accumulators": (i32, [vp, vp, vp, vp, vp, sz, u64, vp]),
+        "sgfhe_debug_ntt": (i32, [vp, u32, ctypes.c_int, vp, vp]),
+        "sgfhe_debug_primes": (i32, [vp, _u32p, _u32p]),
+        "sgfhe_timing_enable": (i32, [vp, ctypes.c_int]),
+        "sgfhe_timing_read": (i32, [vp, ctypes.POINTER(ctypes.c_double), ctypes.c_int]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)          # AttributeError if the library lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+EXPORTED_SYMBOLS = (
+    "sgfhe_version", "sgfhe_ctx_create", "sgfhe_ctx_destroy", "sgfhe_last_error_string",
+    "sgfhe_set_chunk", "sgfhe_bkey_upload", "sgfhe_bkey_upload_rns2",
+    "sgfhe_bkey_device_form_bytes", "sgfhe_bkey_export_device_form",
+    "sgfhe_bkey_import_device_form", "sgfhe_bootstrap_batch", "sgfhe_bootstrap_batch_device",
+    "sgfhe_sync", "sgfhe_external_product", "sgfhe_debug_accumulators", "sgfhe_debug_ntt",
+    "sgfhe_debug_primes", "sgfhe_timing_enable", "sgfhe_timing_read")

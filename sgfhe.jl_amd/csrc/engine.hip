@@ -1,0 +1,751 @@
+// Host side of libsgfhe_hip.so: context set-up (RNS primes, twiddle tables, CRT / flatten
+// constants), bootstrap-key upload, lock-step batch scheduling, and the C ABI of
+// include/sgfhe_hip.h.  Reference citations are relative to /root/reference.
+#include "../../include/sgfhe_hip.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+
+using namespace sgfhe;
+
+namespace {
+
+// ---------------------------------------------------------------- host number theory (word size)
+
+uint32_t mulmod32(uint32_t a, uint32_t b, uint32_t p) { return (uint32_t)((uint64_t)a * b % p); }
+uint32_t powmod32(uint32_t a, uint64_t e, uint32_t p) {
+    uint32_t r = 1 % p;
+    a %= p;
+    while (e) {
+        if (e & 1) r = mulmod32(r, a, p);
+        a = mulmod32(a, a, p);
+        e >>= 1;
+    }
+    return r;
+}
+bool is_prime32(uint32_t x) {
+    if (x < 2) return false;
+    for (uint32_t q : {2u, 3u, 5u, 7u, 11u, 13u}) {
+        if (x % q == 0) return x == q;
+    }
+    uint32_t d = x - 1;
+    int s = 0;
+    while (!(d & 1)) { d >>= 1; s++; }
+    for (uint32_t a : {2u, 3u, 5u, 7u}) {  // deterministic below 3,215,031,751
+        uint32_t y = powmod32(a, d, x);
+        if (y == 1 || y == x - 1) continue;
+        bool comp = true;
+        for (int i = 0; i < s - 1; i++) {
+            y = mulmod32(y, y, x);
+            if (y == x - 1) { comp = false; break; }
+        }
+        if (comp) return false;
+    }
+    return true;
+}
+uint32_t bitrev(uint32_t x, int bits) {
+    uint32_t r = 0;
+    for (int i = 0; i < bits; i++) { r = (r << 1) | (x & 1); x >>= 1; }
+    return r;
+}
+inline u128 ld128(const uint64_t *w) { return ((u128)w[1] << 64) | w[0]; }
+double u128_log2(u128 x) { return log2((double)(uint64_t)(x >> 64) * 18446744073709551616.0 + (double)(uint64_t)x); }
+double u128_dbl(u128 x) { return (double)(uint64_t)(x >> 64) * 18446744073709551616.0 + (double)(uint64_t)x; }
+
+}  // namespace
+
+// ---------------------------------------------------------------- ctx
+
+struct sgfhe_ctx {
+    sgfhe_params par;
+    int device = 0;
+    int logm = 0;
+    uint32_t M = 0, n = 0;
+    u128 Q = 0, B = 0;
+    uint32_t primes[NPR];
+    std::string err;
+    hipStream_t stream = nullptr;
+    // device constants
+    PrimeK *d_primes = nullptr;
+    CrtConst *d_crt = nullptr;
+    uint2 *d_tw = nullptr;  // NPR * 2 * M entries
+    CrtConst h_crt;
+    // key
+    uint32_t *d_key = nullptr;
+    size_t key_bytes = 0;
+    bool have_key = false;
+    // work buffers (sized for `cap` bootstraps)
+    uint32_t chunk = 0, cap = 0;
+    ulonglong2 *d_dig = nullptr;
+    uint32_t *d_yres = nullptr;
+    uint32_t *d_ua = nullptr;
+    // timing
+    bool timing = false;
+    struct EvTriple { hipEvent_t e0, e1, e2; };  // ext = e0 -> e1, crt = e1 -> e2
+    std::vector<EvTriple> ev;
+    double t_ext = 0, t_crt = 0;
+    uint64_t n_ext = 0, n_crt = 0;
+    uint32_t last_chunk = 0;
+};
+
+namespace {
+
+#define HIPCHK(ctx, call)                                                                         \
+    do {                                                                                          \
+        hipError_t e_ = (call);                                                                   \
+        if (e_ != hipSuccess) {                                                                   \
+            char buf_[512];                                                                       \
+            snprintf(buf_, sizeof buf_, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_),    \
+                     __FILE__, __LINE__);                                                         \
+            (ctx)->err = buf_;                                                                    \
+            return SGFHE_ERR_HIP;                                                                 \
+        }                                                                                         \
+    } while (0)
+
+int32_t fail(sgfhe_ctx *ctx, int32_t code, const std::string &msg) {
+    if (ctx) ctx->err = msg;
+    return code;
+}
+
+size_t lds_bytes(int logm, int npoly) { return (size_t)npoly * ((size_t)4 << logm); }
+
+// ---- per-LOGM dispatch ------------------------------------------------------------------------
+
+#define SGFHE_FOR_LOGM(X) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13)
+
+template <int LOGM>
+int32_t launch_extprod_t(sgfhe_ctx *c, const uint32_t *keyk, uint32_t cpad, uint32_t k,
+                         uint32_t mode, hipStream_t st) {
+    const size_t lds = lds_bytes(LOGM, 4);
+    static bool attr_done[16] = {};
+    if (!attr_done[c->device & 15]) {
+        HIPCHK(c, hipFuncSetAttribute((const void *)k_extprod<LOGM>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done[c->device & 15] = true;
+    }
+    hipLaunchKernelGGL(k_extprod<LOGM>, dim3(cpad * NPR), dim3(NttGeom<LOGM>::T), lds, st, c->d_dig,
+                       keyk, c->d_yres, c->d_ua, c->d_primes, k, c->n, mode);
+    HIPCHK(c, hipGetLastError());
+    return SGFHE_OK;
+}
+int32_t launch_extprod(sgfhe_ctx *c, const uint32_t *keyk, uint32_t cpad, uint32_t k,
+                       uint32_t mode, hipStream_t st) {
+    switch (c->logm) {
+#define X(L) case L: return launch_extprod_t<L>(c, keyk, cpad, k, mode, st);
+        SGFHE_FOR_LOGM(X)
+#undef X
+    }
+    return fail(c, SGFHE_ERR_UNSUPPORTED, "unsupported log2(m)");
+}
+
+template <int LOGM>
+int32_t launch_keytr_t(sgfhe_ctx *c, const ulonglong2 *canon, uint32_t *keyhat, uint32_t poly0,
+                       uint32_t npolys, hipStream_t st) {
+    hipLaunchKernelGGL(k_key_transform<LOGM>, dim3(npolys * NPR), dim3(NttGeom<LOGM>::T),
+                       lds_bytes(LOGM, 1), st, canon, keyhat, c->d_primes, c->d_crt, poly0);
+    HIPCHK(c, hipGetLastError());
+    return SGFHE_OK;
+}
+int32_t launch_keytr(sgfhe_ctx *c, const ulonglong2 *canon, uint32_t *keyhat, uint32_t poly0,
+                     uint32_t npolys, hipStream_t st) {
+    switch (c->logm) {
+#define X(L) case L: return launch_keytr_t<L>(c, canon, keyhat, poly0, npolys, st);
+        SGFHE_FOR_LOGM(X)
+#undef X
+    }
+    return fail(c, SGFHE_ERR_UNSUPPORTED, "unsupported log2(m)");
+}
+
+template <int LOGM>
+int32_t launch_dbgntt_t(sgfhe_ctx *c, const uint32_t *in, uint32_t *out, uint32_t pi, int inverse,
+                        hipStream_t st) {
+    hipLaunchKernelGGL(k_debug_ntt<LOGM>, dim3(1), dim3(NttGeom<LOGM>::T), lds_bytes(LOGM, 1), st,
+                       in, out, c->d_primes, pi, (uint32_t)inverse);
+    HIPCHK(c, hipGetLastError());
+    return SGFHE_OK;
+}
+int32_t launch_dbgntt(sgfhe_ctx *c, const uint32_t *in, uint32_t *out, uint32_t pi, int inverse,
+                      hipStream_t st) {
+    switch (c->logm) {
+#define X(L) case L: return launch_dbgntt_t<L>(c, in, out, pi, inverse, st);
+        SGFHE_FOR_LOGM(X)
+#undef X
+    }
+    return fail(c, SGFHE_ERR_UNSUPPORTED, "unsupported log2(m)");
+}
+
+int32_t launch_crt(sgfhe_ctx *c, uint32_t cpad, uint32_t mode, hipStream_t st) {
+    const uint32_t total = cpad * 2 * c->M;
+    hipLaunchKernelGGL(k_crt_acc, dim3((total + 255) / 256), dim3(256), 0, st, c->d_yres, c->d_dig,
+                       c->d_crt, total, (uint32_t)c->logm, mode);
+    HIPCHK(c, hipGetLastError());
+    return SGFHE_OK;
+}
+
+// ---- buffers ------------------------------------------------------------------------------------
+
+uint32_t round_up8(uint32_t x) { return (x + 7u) & ~7u; }
+
+size_t per_bootstrap_bytes(const sgfhe_ctx *c) {
+    return (size_t)2 * c->M * sizeof(ulonglong2) + (size_t)2 * NPR * c->M * 4 + (size_t)c->n * 4;
+}
+
+// Default chunk: keep the per-iteration working set (digits + residues) of a chunk inside the
+// 256 MiB Infinity Cache, and give every CU several workgroups.
+uint32_t default_chunk(const sgfhe_ctx *c) {
+    size_t budget = (size_t)144 << 20;
+    size_t k = budget / per_bootstrap_bytes(c);
+    if (k >= 256) k = (k / 256) * 256;
+    else k = (k / 8) * 8;
+    if (k < 8) k = 8;
+    if (k > 4096) k = 4096;
+    return (uint32_t)k;
+}
+
+int32_t ensure_work(sgfhe_ctx *c, uint32_t cpad) {
+    if (cpad <= c->cap) return SGFHE_OK;
+    if (c->d_dig) { (void)hipFree(c->d_dig); c->d_dig = nullptr; }
+    if (c->d_yres) { (void)hipFree(c->d_yres); c->d_yres = nullptr; }
+    if (c->d_ua) { (void)hipFree(c->d_ua); c->d_ua = nullptr; }
+    c->cap = 0;
+    HIPCHK(c, hipMalloc(&c->d_dig, (size_t)cpad * 2 * c->M * sizeof(ulonglong2)));
+    HIPCHK(c, hipMalloc(&c->d_yres, (size_t)cpad * 2 * NPR * c->M * 4));
+    HIPCHK(c, hipMalloc(&c->d_ua, (size_t)cpad * c->n * 4));
+    c->cap = cpad;
+    return SGFHE_OK;
+}
+
+// ---- timing events ------------------------------------------------------------------------------
+
+void timing_flush(sgfhe_ctx *c) {
+    for (auto &t : c->ev) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, t.e0, t.e1) == hipSuccess) { c->t_ext += ms; c->n_ext++; }
+        if (hipEventElapsedTime(&ms, t.e1, t.e2) == hipSuccess) { c->t_crt += ms; c->n_crt++; }
+        (void)hipEventDestroy(t.e0);
+        (void)hipEventDestroy(t.e1);
+        (void)hipEventDestroy(t.e2);
+    }
+    c->ev.clear();
+}
+
+// ---- the k-loop over one chunk (fhe.jl:579-582) ---------------------------------------------------
+
+int32_t run_iterations(sgfhe_ctx *c, uint32_t cpad, uint64_t n_iters, hipStream_t st) {
+    const size_t slice = (size_t)NPR * 8 * c->M;
+    for (uint64_t k = 0; k < n_iters; k++) {
+        const bool sample = c->timing && (k % 64 == 1) && c->ev.size() < 2048;
+        hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
+        if (sample) {
+            HIPCHK(c, hipEventCreate(&e0));
+            HIPCHK(c, hipEventCreate(&e1));
+            HIPCHK(c, hipEventCreate(&e2));
+            HIPCHK(c, hipEventRecord(e0, st));
+        }
+        int32_t rc = launch_extprod(c, c->d_key + k * slice, cpad, (uint32_t)k, 0, st);
+        if (rc) return rc;
+        if (sample) HIPCHK(c, hipEventRecord(e1, st));
+        rc = launch_crt(c, cpad, 0, st);
+        if (rc) return rc;
+        if (sample) {
+            HIPCHK(c, hipEventRecord(e2, st));
+            c->ev.push_back({e0, e1, e2});
+        }
+    }
+    return SGFHE_OK;
+}
+
+int32_t bootstrap_device(sgfhe_ctx *c, const uint64_t *a1, const uint64_t *b1, const uint64_t *a2,
+                         const uint64_t *b2, size_t batch, uint64_t *out, uint32_t flags,
+                         uint64_t n_iters, ulonglong2 *acc_out, hipStream_t st) {
+    if (!c->have_key) return fail(c, SGFHE_ERR_NO_KEY, "no bootstrap key uploaded");
+    const uint32_t chunk = c->chunk ? c->chunk : default_chunk(c);
+    const uint32_t n = c->n, M = c->M;
+    const bool raw = flags & SGFHE_FLAG_RAW_MODQ;
+    for (size_t c0 = 0; c0 < batch; c0 += chunk) {
+        const uint32_t cb = (uint32_t)((batch - c0 < chunk) ? batch - c0 : chunk);
+        const uint32_t cpad = round_up8(cb);
+        int32_t rc = ensure_work(c, cpad);
+        if (rc) return rc;
+        c->last_chunk = cpad;
+        const uint32_t tot = cpad * M;
+        hipLaunchKernelGGL(k_init, dim3((tot + 255) / 256), dim3(256), 0, st, a1 + c0 * n, b1 + c0,
+                           a2 + c0 * n, b2 + c0, c->d_dig, c->d_ua, c->d_crt, cb, cpad, n,
+                           (uint32_t)c->logm);
+        HIPCHK(c, hipGetLastError());
+        rc = run_iterations(c, cpad, n_iters, st);
+        if (rc) return rc;
+        if (acc_out) {
+            const uint32_t t2 = cb * 2 * M;
+            hipLaunchKernelGGL(k_dump_acc, dim3((t2 + 255) / 256), dim3(256), 0, st, c->d_dig,
+                               acc_out + c0 * 2 * M, c->d_crt, t2);
+            HIPCHK(c, hipGetLastError());
+        }
+        if (out) {
+            const uint32_t t3 = cb * (n + 1);
+            hipLaunchKernelGGL(k_final, dim3((t3 + 255) / 256), dim3(256), 0, st, c->d_dig,
+                               out + c0 * 3 * (n + 1) * (raw ? 2 : 1), c->d_crt, cb, n,
+                               (uint32_t)c->logm, raw ? 1u : 0u);
+            HIPCHK(c, hipGetLastError());
+        }
+    }
+    return SGFHE_OK;
+}
+
+// ---- constants -------------------------------------------------------------------------------------
+
+int32_t build_constants(sgfhe_ctx *c) {
+    const uint32_t M = c->M;
+    const int logm = c->logm;
+    const u128 Q = c->Q, B = c->B;
+
+    // RNS primes: the NPR largest primes below 2^30 with p = 1 mod 2^15 (covers 2 m | p - 1
+    // for every supported m, and leaves room for m = 2^14).
+    {
+        int found = 0;
+        for (uint64_t kk = ((1ull << 30) - 1) >> 15; kk > 0 && found < NPR; kk--) {
+            uint32_t cand = (uint32_t)((kk << 15) + 1);
+            if (cand < (1u << 30) && is_prime32(cand)) c->primes[found++] = cand;
+        }
+        if (found < NPR) return fail(c, SGFHE_ERR_UNSUPPORTED, "could not find RNS primes");
+    }
+    // Exactness bound: |D| <= 2 m B Q must stay below M_rns / 8 (see k_crt_acc).
+    double log_need = 3.0 + logm + u128_log2(B) + u128_log2(Q) + 0.01;
+    double log_have = 0;
+    for (int i = 0; i < NPR; i++) log_have += log2((double)c->primes[i]);
+    if (log_need > log_have)
+        return fail(c, SGFHE_ERR_UNSUPPORTED,
+                    "8 m B Q exceeds the product of the RNS primes (need more primes)");
+
+    // flatten constants (utils.jl:162-169)
+    const u128 s = (B & 1) ? (B - 1) / 2 : B / 2 - 1;
+    const u128 off = (((1 + B) % Q) * (s % Q)) % Q;  // (1+B) < 2^63, s < 2^62
+    auto digits_of = [&](u128 acc) {
+        u128 x = (acc + off) % Q;
+        return make_ulonglong2((uint64_t)(x % B), (uint64_t)(x / B));
+    };
+
+    CrtConst &cc = c->h_crt;
+    memset(&cc, 0, sizeof cc);
+    cc.Q = Q;
+    cc.B = B;
+    cc.offneg = (Q - off) % Q;
+    cc.DQ = ld128(c->par.DQ_tilde) % Q;
+    cc.halfQ = Q / 2;
+    cc.roundthr = Q / 2 + (Q & 1);
+    cc.invQ = 1.0 / u128_dbl(Q);
+    cc.invB = 1.0 / u128_dbl(B);
+    cc.logr = logm + 1;
+    cc.dig0 = digits_of(0);
+    cc.digP = digits_of(cc.DQ);
+    cc.digN = digits_of((Q - cc.DQ) % Q);
+    u128 cM = 1 % Q;
+    for (int i = 0; i < NPR; i++) cM = (cM * c->primes[i]) % Q;  // < 2^94 * 2^30
+    for (int i = 0; i < NPR; i++) {
+        u128 ci = 1 % Q;
+        for (int j = 0; j < NPR; j++)
+            if (j != i) ci = (ci * c->primes[j]) % Q;
+        cc.c[i] = ci;
+        cc.invp[i] = 1.0f / (float)c->primes[i];
+    }
+    const uint32_t plast = c->primes[NPR - 1];
+    const u128 cH = (cc.c[NPR - 1] * ((plast - 1) / 2)) % Q;
+    for (int a = 0; a <= NPR; a++) cc.T[a] = (Q - (((u128)a * cM) % Q + cH) % Q) % Q;
+
+    // twiddle tables and per-prime constants
+    std::vector<uint2> tw((size_t)NPR * 2 * M);
+    std::vector<PrimeK> pk(NPR);
+    HIPCHK(c, hipMalloc(&c->d_tw, tw.size() * sizeof(uint2)));
+    for (int i = 0; i < NPR; i++) {
+        const uint32_t p = c->primes[i];
+        uint32_t psi = 0;
+        for (uint32_t x = 2; x < 2000 && !psi; x++) {
+            uint32_t g = powmod32(x, (p - 1) / (2 * M), p);
+            if (powmod32(g, M, p) == p - 1) psi = g;
+        }
+        if (!psi) return fail(c, SGFHE_ERR_UNSUPPORTED, "no primitive 2m-th root of unity");
+        const uint32_t ipsi = powmod32(psi, p - 2, p);
+        uint2 *f = tw.data() + (size_t)(2 * i) * M, *v = f + M;
+        uint32_t pw = 1, ipw = 1;
+        for (uint32_t t = 0; t < M; t++) {
+            const uint32_t br = bitrev(t, logm);
+            f[br] = make_uint2(pw, (uint32_t)(((uint64_t)pw << 32) / p));
+            v[br] = make_uint2(ipw, (uint32_t)(((uint64_t)ipw << 32) / p));
+            pw = mulmod32(pw, psi, p);
+            ipw = mulmod32(ipw, ipsi, p);
+        }
+        PrimeK &P = pk[i];
+        memset(&P, 0, sizeof P);
+        P.p = p;
+        uint32_t inv = p;  // Newton: p^-1 mod 2^32
+        for (int it = 0; it < 5; it++) inv *= 2u - p * inv;
+        P.ninv = 0u - inv;
+        const uint32_t R1 = (uint32_t)((1ull << 32) % p);
+        const uint32_t Rinv = powmod32(R1, p - 2, p);
+        P.r1 = R1;
+        P.r2 = mulmod32(R1, R1, p);
+        P.r3 = mulmod32(P.r2, R1, p);
+        P.sR = mulmod32((uint32_t)(s % p), Rinv, p);
+        P.hoff = (i == NPR - 1) ? (p - 1) / 2 : 0;
+        P.qmodp = (uint32_t)(Q % p);
+        uint32_t Mi = 1;  // (M_rns / p_i) mod p_i
+        for (int j = 0; j < NPR; j++)
+            if (j != i) Mi = mulmod32(Mi, c->primes[j] % p, p);
+        const uint32_t ei = powmod32(Mi, p - 2, p);
+        const uint32_t minv = powmod32(M % p, p - 2, p);
+        const uint32_t kappa = mulmod32(mulmod32(P.r2, minv, p), ei, p);
+        P.kappaR = mulmod32(kappa, R1, p);
+        P.minvR = mulmod32(minv, R1, p);
+        P.invp = 1.0f / (float)p;
+        P.twf = c->d_tw + (size_t)(2 * i) * M;
+        P.twi = c->d_tw + (size_t)(2 * i + 1) * M;
+    }
+    HIPCHK(c, hipMemcpy(c->d_tw, tw.data(), tw.size() * sizeof(uint2), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMalloc(&c->d_primes, NPR * sizeof(PrimeK)));
+    HIPCHK(c, hipMemcpy(c->d_primes, pk.data(), NPR * sizeof(PrimeK), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMalloc(&c->d_crt, sizeof(CrtConst)));
+    HIPCHK(c, hipMemcpy(c->d_crt, &cc, sizeof(CrtConst), hipMemcpyHostToDevice));
+    return SGFHE_OK;
+}
+
+int32_t key_alloc(sgfhe_ctx *c) {
+    if (c->d_key) return SGFHE_OK;
+    c->key_bytes = (size_t)c->n * NPR * 8 * c->M * 4;
+    HIPCHK(c, hipMalloc(&c->d_key, c->key_bytes));
+    return SGFHE_OK;
+}
+
+// canonical [npolys][m][2 words] in host memory -> NTT-domain key polys poly0.. in keyhat
+int32_t key_transform_host(sgfhe_ctx *c, const uint64_t *canon, uint32_t npolys, uint32_t *keyhat) {
+    const size_t poly_bytes = (size_t)c->M * 16;
+    uint32_t stage_polys = (uint32_t)(((size_t)64 << 20) / poly_bytes);
+    if (stage_polys < 8) stage_polys = 8;
+    if (stage_polys > npolys) stage_polys = npolys;
+    ulonglong2 *d_stage = nullptr;
+    HIPCHK(c, hipMalloc(&d_stage, (size_t)stage_polys * poly_bytes));
+    int32_t rc = SGFHE_OK;
+    for (uint32_t p0 = 0; p0 < npolys && rc == SGFHE_OK; p0 += stage_polys) {
+        const uint32_t np = (npolys - p0 < stage_polys) ? npolys - p0 : stage_polys;
+        hipError_t e = hipMemcpyAsync(d_stage, canon + (size_t)p0 * c->M * 2, (size_t)np * poly_bytes,
+                                      hipMemcpyHostToDevice, c->stream);
+        if (e != hipSuccess) { rc = fail(c, SGFHE_ERR_HIP, hipGetErrorString(e)); break; }
+        rc = launch_keytr(c, d_stage, keyhat, p0, np, c->stream);
+        if (rc) break;
+        e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) rc = fail(c, SGFHE_ERR_HIP, hipGetErrorString(e));
+    }
+    (void)hipFree(d_stage);
+    return rc;
+}
+
+}  // namespace
+
+// ==================================================================================================
+// C ABI
+// ==================================================================================================
+
+extern "C" {
+
+const char *sgfhe_version(void) { return "sgfhe_hip 0.1.0 gfx950"; }
+
+const char *sgfhe_last_error_string(const sgfhe_ctx *ctx) {
+    return ctx ? ctx->err.c_str() : "null context";
+}
+
+int32_t sgfhe_ctx_create(const sgfhe_params *p, int device, sgfhe_ctx **out) {
+    if (!p || !out) return SGFHE_ERR_INVALID_ARG;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev)
+        return SGFHE_ERR_NO_DEVICE;
+    if (hipSetDevice(device) != hipSuccess) return SGFHE_ERR_NO_DEVICE;
+    sgfhe_ctx *c = new (std::nothrow) sgfhe_ctx();
+    if (!c) return SGFHE_ERR_OOM;
+    *out = c;  // returned even on failure so that the caller can read the error string
+    c->par = *p;
+    c->device = device;
+    const uint64_t m = p->m;
+    if (p->ell != 2) return fail(c, SGFHE_ERR_UNSUPPORTED, "ell must be 2 (fhe.jl:576)");
+    if (m < 64 || m > 8192 || (m & (m - 1)))
+        return fail(c, SGFHE_ERR_UNSUPPORTED, "m must be a power of two in [2^6, 2^13]");
+    if (p->r != 2 * m) return fail(c, SGFHE_ERR_INVALID_ARG, "r must equal 2 m (fhe.jl:62)");
+    if (p->n == 0 || p->n > m / 4)
+        return fail(c, SGFHE_ERR_INVALID_ARG, "n must be in [1, m / 4] (extract, fhe.jl:585-590)");
+    c->M = (uint32_t)m;
+    c->n = (uint32_t)p->n;
+    while ((1u << c->logm) < c->M) c->logm++;
+    c->Q = ld128(p->Q);
+    c->B = ld128(p->B);
+    if (c->Q < 3 || (c->Q >> 94)) return fail(c, SGFHE_ERR_UNSUPPORTED, "Q must be in [3, 2^94)");
+    if (c->B < 2 || (c->B >> 62)) return fail(c, SGFHE_ERR_UNSUPPORTED, "B must be in [2, 2^62)");
+    {
+        // B^2 >= Q (utils.jl:145); B < 2^62 so B*B fits 128 bits
+        if (c->B * c->B < c->Q) return fail(c, SGFHE_ERR_INVALID_ARG, "B^2 must be >= Q");
+    }
+    if (ld128(p->DQ_tilde) >= c->Q) return fail(c, SGFHE_ERR_INVALID_ARG, "DQ_tilde must be < Q");
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess)
+        return fail(c, SGFHE_ERR_HIP, "hipStreamCreate failed");
+    return build_constants(c);
+}
+
+int32_t sgfhe_ctx_destroy(sgfhe_ctx *c) {
+    if (!c) return SGFHE_OK;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    timing_flush(c);
+    if (c->d_primes) (void)hipFree(c->d_primes);
+    if (c->d_crt) (void)hipFree(c->d_crt);
+    if (c->d_tw) (void)hipFree(c->d_tw);
+    if (c->d_key) (void)hipFree(c->d_key);
+    if (c->d_dig) (void)hipFree(c->d_dig);
+    if (c->d_yres) (void)hipFree(c->d_yres);
+    if (c->d_ua) (void)hipFree(c->d_ua);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return SGFHE_OK;
+}
+
+int32_t sgfhe_set_chunk(sgfhe_ctx *c, uint32_t chunk) {
+    if (!c) return SGFHE_ERR_INVALID_ARG;
+    c->chunk = chunk ? round_up8(chunk) : 0;
+    return SGFHE_OK;
+}
+
+int32_t sgfhe_bkey_upload(sgfhe_ctx *c, const uint64_t *canonical, size_t n_words) {
+    if (!c || !canonical) return SGFHE_ERR_INVALID_ARG;
+    (void)hipSetDevice(c->device);
+    const size_t expect = (size_t)c->n * 8 * c->M * 2;
+    if (n_words != expect) return fail(c, SGFHE_ERR_INVALID_ARG, "bkey_upload: n_words != n*8*m*2");
+    int32_t rc = key_alloc(c);
+    if (rc) return rc;
+    rc = key_transform_host(c, canonical, c->n * 8, c->d_key);
+    if (rc) return rc;
+    c->have_key = true;
+    return SGFHE_OK;
+}
+
+int32_t sgfhe_bkey_upload_rns2(sgfhe_ctx *c, const uint64_t *pairs, size_t n_words, uint64_t m1,
+                               uint64_t m2) {
+    if (!c || !pairs) return SGFHE_ERR_INVALID_ARG;
+    const size_t expect = (size_t)c->n * 8 * c->M * 2;
+    if (n_words != expect) return fail(c, SGFHE_ERR_INVALID_ARG, "bkey_upload_rns2: bad n_words");
+    if ((u128)m1 * m2 != c->Q) return fail(c, SGFHE_ERR_INVALID_ARG, "m1 * m2 != Q");
+    if (m1 >= (1ull << 47) || m2 >= (1ull << 47))
+        return fail(c, SGFHE_ERR_UNSUPPORTED, "RNS2 limb moduli must be < 2^47");
+    // CRT of rns.jl:32-40: x = (v1 c1 + v2 c2) mod m, c1 = m2^(m1-1) mod m, c2 = m1^(m2-1) mod m.
+    // c1 = m2 * (m2^-1 mod m1), c2 = m1 * (m1^-1 mod m2) (Fermat idempotents, m1, m2 prime).
+    auto powmod64 = [](uint64_t a, uint64_t e, uint64_t md) {
+        u128 r = 1, b = a % md;
+        while (e) { if (e & 1) r = r * b % md; b = b * b % md; e >>= 1; }
+        return (uint64_t)r;
+    };
+    const uint64_t i21 = powmod64(m2 % m1, m1 - 2, m1);  // m2^-1 mod m1
+    const uint64_t i12 = powmod64(m1 % m2, m2 - 2, m2);  // m1^-1 mod m2
+    if ((u128)(m2 % m1) * i21 % m1 != 1 || (u128)(m1 % m2) * i12 % m2 != 1)
+        return fail(c, SGFHE_ERR_INVALID_ARG, "RNS2 limb moduli must be distinct primes");
+    const size_t count = expect / 2;
+    std::vector<uint64_t> canon;
+    try { canon.resize(expect); } catch (...) { return fail(c, SGFHE_ERR_OOM, "host allocation failed"); }
+    const u128 Q = c->Q;
+    for (size_t i = 0; i < count; i++) {
+        const uint64_t v1 = pairs[2 * i], v2 = pairs[2 * i + 1];
+        // x = v1 * m2 * i21 + v2 * m1 * i12 (mod Q); reduce the word-size factors first
+        const u128 t1 = (u128)((u128)v1 * i21 % m1) * m2;
+        const u128 t2 = (u128)((u128)v2 * i12 % m2) * m1;
+        u128 x = t1 + t2;
+        if (x >= Q) x -= Q;
+        canon[2 * i] = (uint64_t)x;
+        canon[2 * i + 1] = (uint64_t)(x >> 64);
+    }
+    return sgfhe_bkey_upload(c, canon.data(), expect);
+}
+
+int32_t sgfhe_bkey_device_form_bytes(const sgfhe_ctx *c, size_t *bytes) {
+    if (!c || !bytes) return SGFHE_ERR_INVALID_ARG;
+    *bytes = (size_t)c->n * NPR * 8 * c->M * 4;
+    return SGFHE_OK;
+}
+
+int32_t sgfhe_bkey_export_device_form(sgfhe_ctx *c, void *dst) {
+    if (!c || !dst) return SGFHE_ERR_INVALID_ARG;
+    if (!c->have_key) return fail(c, SGFHE_ERR_NO_KEY, "no bootstrap key uploaded");
+    (void)hipSetDevice(c->device);
+    HIPCHK(c, hipMemcpyAsync(dst, c->d_key, c->key_bytes, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return SGFHE_OK;
+}
+
+int32_t sgfhe_bkey_import_device_form(sgfhe_ctx *c, const void *src) {
+    if (!c || !src) return SGFHE_ERR_INVALID_ARG;
+    (void)hipSetDevice(c->device);
+    int32_t rc = key_alloc(c);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->d_key, src, c->key_bytes, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->have_key = true;
+    return SGFHE_OK;
+}
+
+int32_t sgfhe_bootstrap_batch_device(sgfhe_ctx *c, const uint64_t *a1, const uint64_t *b1,
+                                     const uint64_t *a2, const uint64_t *b2, size_t batch,
+                                     uint64_t *out, uint32_t flags, void *stream) {
+    if (!c || !a1 || !b1 || !a2 || !b2 || !out) return SGFHE_ERR_INVALID_ARG;
+    if (batch == 0) return SGFHE_OK;
+    (void)hipSetDevice(c->device);
+    return bootstrap_device(c, a1, b1, a2, b2, batch, out, flags, c->n, nullptr,
+                            stream ? (hipStream_t)stream : c->stream);
+}
+
+int32_t sgfhe_sync(sgfhe_ctx *c) {
+    if (!c) return SGFHE_ERR_INVALID_ARG;
+    (void)hipSetDevice(c->device);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return SGFHE_OK;
+}
+
+static int32_t bootstrap_host(sgfhe_ctx *c, const uint64_t *a1, const uint64_t *b1,
+                              const uint64_t *a2, const uint64_t *b2, size_t batch, uint64_t *out,
+                              uint32_t flags, uint64_t n_iters, uint64_t *acc) {
+    (void)hipSetDevice(c->device);
+    const size_t n = c->n;
+    const size_t out_words = batch * 3 * (n + 1) * ((flags & SGFHE_FLAG_RAW_MODQ) ? 2 : 1);
+    const size_t acc_words = batch * 2 * (size_t)c->M * 2;
+    uint64_t *d_in = nullptr, *d_out = nullptr;
+    ulonglong2 *d_acc = nullptr;
+    const size_t in_words = 2 * batch * (n + 1);
+    HIPCHK(c, hipMalloc(&d_in, in_words * 8));
+    int32_t rc = SGFHE_OK;
+    hipError_t e = hipSuccess;
+    uint64_t *d_a1 = d_in, *d_a2 = d_in + batch * n, *d_b1 = d_in + 2 * batch * n,
+             *d_b2 = d_b1 + batch;
+    do {
+        if (out && (e = hipMalloc(&d_out, out_words * 8)) != hipSuccess) break;
+        if (acc && (e = hipMalloc(&d_acc, acc_words * 8)) != hipSuccess) break;
+        if ((e = hipMemcpyAsync(d_a1, a1, batch * n * 8, hipMemcpyHostToDevice, c->stream))) break;
+        if ((e = hipMemcpyAsync(d_a2, a2, batch * n * 8, hipMemcpyHostToDevice, c->stream))) break;
+        if ((e = hipMemcpyAsync(d_b1, b1, batch * 8, hipMemcpyHostToDevice, c->stream))) break;
+        if ((e = hipMemcpyAsync(d_b2, b2, batch * 8, hipMemcpyHostToDevice, c->stream))) break;
+        rc = bootstrap_device(c, d_a1, d_b1, d_a2, d_b2, batch, d_out, flags, n_iters, d_acc,
+                              c->stream);
+        if (rc) break;
+        if (out && (e = hipMemcpyAsync(out, d_out, out_words * 8, hipMemcpyDeviceToHost, c->stream)))
+            break;
+        if (acc && (e = hipMemcpyAsync(acc, d_acc, acc_words * 8, hipMemcpyDeviceToHost, c->stream)))
+            break;
+        e = hipStreamSynchronize(c->stream);
+    } while (0);
+    if (e != hipSuccess && rc == SGFHE_OK) rc = fail(c, SGFHE_ERR_HIP, hipGetErrorString(e));
+    (void)hipFree(d_in);
+    if (d_out) (void)hipFree(d_out);
+    if (d_acc) (void)hipFree(d_acc);
+    return rc;
+}
+
+int32_t sgfhe_bootstrap_batch(sgfhe_ctx *c, const uint64_t *a1, const uint64_t *b1,
+                              const uint64_t *a2, const uint64_t *b2, size_t batch, uint64_t *out,
+                              uint32_t flags) {
+    if (!c || !a1 || !b1 || !a2 || !b2 || !out) return SGFHE_ERR_INVALID_ARG;
+    if (batch == 0) return SGFHE_OK;
+    return bootstrap_host(c, a1, b1, a2, b2, batch, out, flags, c->n, nullptr);
+}
+
+int32_t sgfhe_debug_accumulators(sgfhe_ctx *c, const uint64_t *a1, const uint64_t *b1,
+                                 const uint64_t *a2, const uint64_t *b2, size_t batch,
+                                 uint64_t n_iters, uint64_t *acc) {
+    if (!c || !a1 || !b1 || !a2 || !b2 || !acc) return SGFHE_ERR_INVALID_ARG;
+    if (n_iters > c->n) return fail(c, SGFHE_ERR_INVALID_ARG, "n_iters > n");
+    if (batch == 0) return SGFHE_OK;
+    return bootstrap_host(c, a1, b1, a2, b2, batch, nullptr, 0, n_iters, acc);
+}
+
+int32_t sgfhe_external_product(sgfhe_ctx *c, const uint64_t *a, const uint64_t *b,
+                               const uint64_t *A, uint64_t *a_res, uint64_t *b_res) {
+    if (!c || !a || !b || !A || !a_res || !b_res) return SGFHE_ERR_INVALID_ARG;
+    (void)hipSetDevice(c->device);
+    const uint32_t M = c->M;
+    const uint32_t cpad = 8;
+    int32_t rc = ensure_work(c, cpad);
+    if (rc) return rc;
+    uint32_t *d_A = nullptr;
+    ulonglong2 *d_ab = nullptr;
+    HIPCHK(c, hipMalloc(&d_A, (size_t)NPR * 8 * M * 4));
+    hipError_t e = hipMalloc(&d_ab, (size_t)2 * M * 16);
+    if (e != hipSuccess) { (void)hipFree(d_A); return fail(c, SGFHE_ERR_HIP, hipGetErrorString(e)); }
+    do {
+        // A[4][2][m] is exactly one key slice (k = 0)
+        rc = key_transform_host(c, A, 8, d_A);
+        if (rc) break;
+        if ((e = hipMemsetAsync(c->d_dig, 0, (size_t)cpad * 2 * M * 16, c->stream))) break;
+        if ((e = hipMemcpyAsync(d_ab, a, (size_t)M * 16, hipMemcpyHostToDevice, c->stream))) break;
+        if ((e = hipMemcpyAsync(d_ab + M, b, (size_t)M * 16, hipMemcpyHostToDevice, c->stream))) break;
+        hipLaunchKernelGGL(k_flatten_canon, dim3((2 * M + 255) / 256), dim3(256), 0, c->stream, d_ab,
+                           c->d_dig, c->d_crt, 2 * M);
+        rc = launch_extprod(c, d_A, cpad, 0, MODE_PLAIN, c->stream);
+        if (rc) break;
+        rc = launch_crt(c, cpad, MODE_NOACC | MODE_CANON, c->stream);
+        if (rc) break;
+        if ((e = hipMemcpyAsync(a_res, c->d_dig, (size_t)M * 16, hipMemcpyDeviceToHost, c->stream))) break;
+        if ((e = hipMemcpyAsync(b_res, c->d_dig + M, (size_t)M * 16, hipMemcpyDeviceToHost, c->stream))) break;
+        e = hipStreamSynchronize(c->stream);
+    } while (0);
+    if (e != hipSuccess && rc == SGFHE_OK) rc = fail(c, SGFHE_ERR_HIP, hipGetErrorString(e));
+    (void)hipFree(d_A);
+    (void)hipFree(d_ab);
+    return rc;
+}
+
+int32_t sgfhe_debug_ntt(sgfhe_ctx *c, uint32_t prime_index, int inverse, const uint32_t *in,
+                        uint32_t *out) {
+    if (!c || !in || !out || prime_index >= NPR) return SGFHE_ERR_INVALID_ARG;
+    (void)hipSetDevice(c->device);
+    uint32_t *d = nullptr;
+    HIPCHK(c, hipMalloc(&d, (size_t)2 * c->M * 4));
+    int32_t rc = SGFHE_OK;
+    hipError_t e;
+    do {
+        if ((e = hipMemcpyAsync(d, in, (size_t)c->M * 4, hipMemcpyHostToDevice, c->stream))) break;
+        rc = launch_dbgntt(c, d, d + c->M, prime_index, inverse, c->stream);
+        if (rc) break;
+        if ((e = hipMemcpyAsync(out, d + c->M, (size_t)c->M * 4, hipMemcpyDeviceToHost, c->stream))) break;
+        e = hipStreamSynchronize(c->stream);
+    } while (0);
+    if (e != hipSuccess && rc == SGFHE_OK) rc = fail(c, SGFHE_ERR_HIP, hipGetErrorString(e));
+    (void)hipFree(d);
+    return rc;
+}
+
+int32_t sgfhe_debug_primes(const sgfhe_ctx *c, uint32_t *count, uint32_t *primes) {
+    if (!c || !count || !primes) return SGFHE_ERR_INVALID_ARG;
+    *count = NPR;
+    for (int i = 0; i < NPR; i++) primes[i] = c->primes[i];
+    return SGFHE_OK;
+}
+
+int32_t sgfhe_timing_enable(sgfhe_ctx *c, int enable) {
+    if (!c) return SGFHE_ERR_INVALID_ARG;
+    c->timing = enable != 0;
+    return SGFHE_OK;
+}
+
+int32_t sgfhe_timing_read(sgfhe_ctx *c, double *stats, int reset) {
+    if (!c || !stats) return SGFHE_ERR_INVALID_ARG;
+    (void)hipSetDevice(c->device);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    timing_flush(c);
+    stats[0] = c->n_ext ? c->t_ext / (double)c->n_ext : 0.0;
+    stats[1] = (double)c->n_ext;
+    stats[2] = c->n_crt ? c->t_crt / (double)c->n_crt : 0.0;
+    stats[3] = (double)c->n_crt;
+    stats[4] = (double)c->last_chunk;
+    if (reset) { c->t_ext = c->t_crt = 0; c->n_ext = c->n_crt = 0; }
+    return SGFHE_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,432 @@
+// HIP kernels of the gate-bootstrap engine (gfx950).  Hot path of nucypher/SGFHE.jl:
+// _bootstrap_internal / external_product / flatten / reduce_modulus
+// (/root/reference/src/fhe.jl:519-621, src/utils.jl:78-189), restructured as in DESIGN.md:
+//
+//   acc <- acc + (x^j - 1) * sum_row u_row (*) C_k[row]          (CMux form of fhe.jl:580-581)
+//
+// State per bootstrap: the *flattened* accumulators, i.e. for every coefficient of (a, b) the
+// two base-B digits (lo, hi) of x' = (acc + off) mod Q with off = (1 + B) s (utils.jl:162-181).
+// Per iteration k two kernels run over a chunk of bootstraps in lock-step:
+//   k_extprod  one workgroup per (bootstrap, RNS prime): digits -> 4 forward NTTs -> 8 pointwise
+//              multiply-accumulates against the NTT-domain key slice -> 2 inverse NTTs ->
+//              negacyclic rotate-and-subtract (x^j - 1) -> residues y mod p_i
+//   k_crt_acc  per coefficient: CRT of the residues to the exact integer, reduce mod Q, add to
+//              the accumulator, flatten again (divide by B).
+#pragma once
+
+#include "ntt.h"
+
+namespace sgfhe {
+
+typedef unsigned __int128 u128;
+
+constexpr int NPR = 5;  // RNS primes (p_i < 2^30), product M ~ 2^150
+
+struct PrimeK {
+    uint32_t p;       // prime
+    uint32_t ninv;    // -p^-1 mod 2^32
+    uint32_t sR;      // s * R^-1 mod p      (digit offset s of utils.jl:162-166, R = 2^32)
+    uint32_t hoff;    // offset added to the output residue: (p-1)/2 for the last prime, else 0
+    uint32_t r1, r2, r3;  // R, R^2, R^3 mod p
+    uint32_t qmodp;   // Q mod p
+    uint32_t kappaR;  // key scale kappa * R mod p, kappa = R^2 m^-1 (M/p)^-1 mod p
+    uint32_t minvR;   // m^-1 * R mod p (debug inverse NTT scaling)
+    float invp;       // 1 / p
+    uint32_t pad_;
+    const uint2 *twf;  // forward twiddles (w, floor(w 2^32 / p)), bit-reversed psi powers
+    const uint2 *twi;  // inverse twiddles
+};
+
+// The NPR PrimeK records live in device memory and are indexed by the (wave-uniform) prime
+// index of the workgroup.
+typedef const PrimeK *__restrict__ PrimeSet;
+
+// CRT / flatten constants, resident in device memory.
+struct CrtConst {
+    u128 Q, B;
+    u128 c[NPR];         // (M / p_i) mod Q
+    u128 T[NPR + 1];     // (-alpha * M - H') mod Q,  H' = (M / p_last) * (p_last - 1) / 2
+    u128 offneg;         // (Q - off) mod Q, off = (1 + B) s mod Q
+    u128 DQ;             // DQ_tilde mod Q
+    u128 halfQ;          // Q / 2 (centred lift of key residues)
+    u128 roundthr;       // Q / 2 + (Q odd)        (utils.jl:84)
+    double invQ, invB;
+    float invp[NPR];
+    uint32_t logr;
+    ulonglong2 dig0, digP, digN;  // (lo, hi) digits of x' for acc = 0, DQ_tilde, Q - DQ_tilde
+};
+
+enum : uint32_t {
+    MODE_PLAIN = 1u,  // k_extprod: no (x^j - 1) factor (external_product debug hook)
+    MODE_NOACC = 2u,  // k_crt_acc: do not add the previous accumulator
+    MODE_CANON = 4u   // k_crt_acc: write canonical residues instead of digits
+};
+
+// ---- small 128-bit helpers -----------------------------------------------------------------
+
+__device__ __forceinline__ double u128_to_double(u128 x) {
+    return (double)(uint64_t)(x >> 64) * 18446744073709551616.0 + (double)(uint64_t)x;
+}
+__device__ __forceinline__ u128 mul_u64_u128(uint64_t a, u128 b) {
+    // a * b mod 2^128
+    return (u128)a * (uint64_t)b + (((u128)(a * (uint64_t)(b >> 64))) << 64);
+}
+// x mod d for x < 2^127, d < 2^94, quotient < 2^62; inv = 1.0 / d.
+__device__ __forceinline__ u128 mod_wide(u128 x, u128 d, double inv, uint64_t *quot) {
+    uint64_t q = (uint64_t)(u128_to_double(x) * inv);
+    u128 r = x - mul_u64_u128(q, d);
+#pragma unroll 1
+    while ((__int128)r < 0) { r += d; q--; }
+#pragma unroll 1
+    while (r >= d) { r -= d; q++; }
+    if (quot) *quot = q;
+    return r;
+}
+
+// ---- digit -> residue ------------------------------------------------------------------------
+// (e - s) * R^-1 mod p in [0, p) for a raw digit e in [0, B), B < 2^62.
+__device__ __forceinline__ uint32_t digit_reduce(uint64_t e, const PrimeK &P) {
+    uint32_t v = csub(redc64(e, P.p, P.ninv), P.p);
+    uint32_t t = v - P.sR;
+    return min(t, t + P.p);
+}
+
+// ---- k_extprod ----------------------------------------------------------------------------------
+// grid = chunk * NPR workgroups of T = m / 8 threads; chunk is a multiple of 8.  Workgroups are
+// dealt round-robin to the 8 XCDs (blocks g and g + 8 share an XCD, MI355X_MICROARCH.md), so
+// the NPR prime-workgroups of one bootstrap are given the same g mod 8: they re-read the same
+// digits and hit in that XCD's L2.
+//   dig    [chunk][2][m]        (lo, hi) digits of x' for acc_a (c = 0) and acc_b (c = 1)
+//   keyk   [NPR][4][2][m]       NTT-domain key slice of iteration k (slot order, scaled by kappa)
+//   yres   [chunk][2][NPR][m]   output residues y_i = (M/p_i)^-1 * D mod p_i (+ hoff)
+//   ua     [chunk][n]           j = u.a[k] of every bootstrap (fhe.jl:566,580)
+template <int LOGM>
+__global__ void __launch_bounds__(NttGeom<LOGM>::T)
+k_extprod(const ulonglong2 *__restrict__ dig, const uint32_t *__restrict__ keyk,
+          uint32_t *__restrict__ yres, const uint32_t *__restrict__ ua, PrimeSet PS, uint32_t k,
+          uint32_t n, uint32_t mode) {
+    using G = NttGeom<LOGM>;
+    constexpr int M = G::M, T = G::T;
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+
+    const int tid = threadIdx.x;
+    const uint32_t g = blockIdx.x;
+    const uint32_t slot = g >> 3;
+    const uint32_t b = (slot / NPR) * 8 + (g & 7);
+    const uint32_t pi = slot % NPR;
+    const PrimeK P = PS[pi];
+    const uint32_t p = P.p;
+
+    // 1. digits -> residues (flatten_poly, utils.jl:253-264, lifted to signed integers)
+    uint32_t x[4][8];
+    {
+        const ulonglong2 *da = dig + ((size_t)b * 2 + 0) * M;
+        const ulonglong2 *db = dig + ((size_t)b * 2 + 1) * M;
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            const ulonglong2 va = da[tid + T * e];
+            const ulonglong2 vb = db[tid + T * e];
+            x[0][e] = digit_reduce(va.x, P);
+            x[1][e] = digit_reduce(va.y, P);
+            x[2][e] = digit_reduce(vb.x, P);
+            x[3][e] = digit_reduce(vb.y, P);
+        }
+    }
+
+    // 2. four forward NTTs (u = [a_lo, a_hi, b_lo, b_hi], fhe.jl:524-526)
+    ntt_forward<LOGM, 4>(x, lds, P.twf, tid, p);
+
+    // 3. pointwise: z_c = sum_row U_row * K[row][c]   (fhe.jl:527-528 in the NTT domain)
+    uint32_t z[2][8];
+    {
+        uint64_t acc0[8], acc1[8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) { acc0[e] = 0; acc1[e] = 0; }
+        const uint32_t *kp = keyk + (size_t)pi * 8 * M + 8 * tid;
+#pragma unroll
+        for (int row = 0; row < 4; row++) {
+            const uint4 *k0 = reinterpret_cast<const uint4 *>(kp + (size_t)(row * 2 + 0) * M);
+            const uint4 *k1 = reinterpret_cast<const uint4 *>(kp + (size_t)(row * 2 + 1) * M);
+            const uint4 a0 = k0[0], a1 = k0[1], b0 = k1[0], b1 = k1[1];
+            const uint32_t kk0[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+            const uint32_t kk1[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                uint32_t u = x[row][e];
+                u = min(u, u - 2 * p);
+                u = csub(u, p);  // [0, p): 4 products < 4 p^2 < p 2^32
+                acc0[e] += (uint64_t)u * kk0[e];
+                acc1[e] += (uint64_t)u * kk1[e];
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            z[0][e] = redc64(acc0[e], p, P.ninv);  // [0, 2p)
+            z[1][e] = redc64(acc1[e], p, P.ninv);
+        }
+    }
+
+    // 4. two inverse NTTs -> P_c = (M/p)^-1 * sum_row u_row (*) C_row[c]  mod p
+    ntt_inverse<LOGM, 2>(z, lds, P.twi, tid, p);
+#pragma unroll
+    for (int c = 0; c < 2; c++)
+#pragma unroll
+        for (int e = 0; e < 8; e++) z[c][e] = csub(z[c][e], p);
+
+    // 5. y = x^j P - P  (mul_by_xj_minus_one, fhe.jl:554-556, applied to the product)
+    uint32_t *yb = yres + ((size_t)b * 2 * NPR + pi) * M;
+    if (mode & MODE_PLAIN) {
+#pragma unroll
+        for (int c = 0; c < 2; c++)
+#pragma unroll
+            for (int e = 0; e < 8; e++)
+                yb[(size_t)c * NPR * M + tid + T * e] = csub(z[c][e] + P.hoff, p);
+        return;
+    }
+    const uint32_t j = ua[(size_t)b * n + k];
+    lds_store<LOGM, 2, G::STOP>(z, lds, tid);
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            const uint32_t i = tid + T * e;
+            const uint32_t s = (i - j) & (2 * M - 1);
+            uint32_t v = lds[c * M + swz(s & (M - 1))];
+            if (s & M) v = csub(p - v, p);  // x^m = -1
+            uint32_t y = v - z[c][e];
+            y = min(y, y + p);
+            yb[(size_t)c * NPR * M + i] = csub(y + P.hoff, p);
+        }
+    }
+}
+
+// ---- k_crt_acc --------------------------------------------------------------------------------
+// One thread per (bootstrap, c, coefficient).  With y'_i = (D + H') (M/p_i)^-1 mod p_i:
+//   D + H' = sum_i y'_i (M/p_i) - alpha M,  alpha = floor(sum_i y'_i / p_i)
+// and |D| <= M / 8 (checked at ctx creation) puts the fractional part of the sum within
+// 0.5 +- 0.125, so alpha is exact in float.  Then x'_new = (x'_old + D) mod Q and the new
+// digits are (x'_new mod B, x'_new / B)  (flatten, utils.jl:155-189).
+__global__ void __launch_bounds__(256)
+k_crt_acc(const uint32_t *__restrict__ yres, ulonglong2 *__restrict__ dig,
+          const CrtConst *__restrict__ CC, uint32_t total, uint32_t logm, uint32_t mode) {
+    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= total) return;
+    const uint32_t M = 1u << logm;
+    const uint32_t i = t & (M - 1);
+    const uint32_t bc = t >> logm;
+    const uint32_t *yp = yres + (size_t)bc * NPR * M + i;
+    uint32_t y[NPR];
+    float f = 0.f;
+#pragma unroll
+    for (int q = 0; q < NPR; q++) {
+        y[q] = yp[(size_t)q * M];
+        f += (float)y[q] * CC->invp[q];
+    }
+    const int alpha = (int)f;
+    u128 S = CC->T[alpha];
+#pragma unroll
+    for (int q = 0; q < NPR; q++) S += mul_u64_u128(y[q], CC->c[q]);
+    const u128 B = CC->B;
+    if (!(mode & MODE_NOACC)) {
+        const ulonglong2 d = dig[t];
+        S += (u128)d.y * (uint64_t)B + d.x;
+    }
+    const u128 xn = mod_wide(S, CC->Q, CC->invQ, nullptr);
+    if (mode & MODE_CANON) {
+        dig[t] = make_ulonglong2((uint64_t)xn, (uint64_t)(xn >> 64));
+        return;
+    }
+    uint64_t hi;
+    const u128 lo = mod_wide(xn, B, CC->invB, &hi);
+    dig[t] = make_ulonglong2((uint64_t)lo, hi);
+}
+
+// ---- k_init -------------------------------------------------------------------------------------
+// u = lwe1 + lwe2 (fhe.jl:566); a = 0 (fhe.jl:570); b = x^(-u.b) t DQ_tilde (fhe.jl:572-573) with
+// t = initial_poly (fhe.jl:535-548): +1 on [0, Dr), 0 at Dr, -1 on (Dr, m).  Every coefficient of
+// b is 0, +DQ_tilde or -DQ_tilde, so the three possible digit pairs are precomputed.
+// One thread per (bootstrap of the padded chunk, coefficient).
+__global__ void __launch_bounds__(256)
+k_init(const uint64_t *__restrict__ a1, const uint64_t *__restrict__ b1,
+       const uint64_t *__restrict__ a2, const uint64_t *__restrict__ b2,
+       ulonglong2 *__restrict__ dig, uint32_t *__restrict__ ua, const CrtConst *__restrict__ CC,
+       uint32_t nvalid, uint32_t chunk, uint32_t n, uint32_t logm) {
+    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t M = 1u << logm;
+    if (t >= chunk * M) return;
+    const uint32_t i = t & (M - 1);
+    const uint32_t b = t >> logm;
+    const uint32_t rmask = 2 * M - 1;  // r = 2 m
+    const bool valid = b < nvalid;
+    if (i < n) ua[(size_t)b * n + i] =
+        valid ? (uint32_t)((a1[(size_t)b * n + i] + a2[(size_t)b * n + i]) & rmask) : 0u;
+    dig[((size_t)b * 2 + 0) * M + i] = CC->dig0;
+    ulonglong2 d = CC->dig0;
+    if (valid) {
+        const uint32_t ub = (uint32_t)((b1[b] + b2[b]) & rmask);
+        const uint32_t Dr = M / 2;  // r / 4
+        const uint32_t src = (i + ub) & rmask;
+        const uint32_t s = src & (M - 1);
+        int tv = s < Dr ? 1 : (s == Dr ? 0 : -1);
+        if (src & M) tv = -tv;
+        d = tv > 0 ? CC->digP : (tv < 0 ? CC->digN : CC->dig0);
+    }
+    dig[((size_t)b * 2 + 1) * M + i] = d;
+}
+
+// ---- k_final ------------------------------------------------------------------------------------
+// LWE extraction (fhe.jl:585-592, extract :237-244 in its i >= n branch) and ModRed
+// (fhe.jl:616-618,644-648; rescale utils.jl:78-92).  One thread per (bootstrap, t in [0, n]).
+__device__ __forceinline__ u128 acc_from_digits(ulonglong2 d, const CrtConst *CC) {
+    u128 x = (u128)d.y * (uint64_t)CC->B + d.x + CC->offneg;
+    if (x >= CC->Q) x -= CC->Q;
+    return x;
+}
+__device__ __forceinline__ uint64_t modred(u128 x, const CrtConst *CC) {
+    const u128 num = x << CC->logr;  // x * r
+    uint64_t q;
+    const u128 rem = mod_wide(num, CC->Q, CC->invQ, &q);
+    if (rem >= CC->roundthr) {
+        q += 1;
+        if (q == (1ull << CC->logr)) q = 0;
+    }
+    return q;
+}
+__global__ void __launch_bounds__(256)
+k_final(const ulonglong2 *__restrict__ dig, uint64_t *__restrict__ out,
+        const CrtConst *__restrict__ CC, uint32_t nvalid, uint32_t n, uint32_t logm, uint32_t raw) {
+    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= nvalid * (n + 1)) return;
+    const uint32_t M = 1u << logm;
+    const uint32_t b = t / (n + 1), e = t % (n + 1);
+    const ulonglong2 *da = dig + ((size_t)b * 2 + 0) * M;
+    const ulonglong2 *db = dig + ((size_t)b * 2 + 1) * M;
+    const u128 Q = CC->Q;
+    u128 va, vo;
+    if (e < n) {
+        va = acc_from_digits(da[3 * M / 4 - e], CC);
+        const u128 w = acc_from_digits(da[M / 4 - e], CC);
+        vo = w ? Q - w : 0;
+    } else {
+        va = CC->DQ + acc_from_digits(db[3 * M / 4], CC);
+        if (va >= Q) va -= Q;
+        const u128 w = acc_from_digits(db[M / 4], CC);
+        vo = CC->DQ >= w ? CC->DQ - w : CC->DQ + Q - w;
+    }
+    const u128 vx = vo >= va ? vo - va : vo + Q - va;
+    const size_t stride = n + 1;
+    if (raw) {
+        ulonglong2 *o = reinterpret_cast<ulonglong2 *>(out) + (size_t)b * 3 * stride + e;
+        o[0] = make_ulonglong2((uint64_t)va, (uint64_t)(va >> 64));
+        o[stride] = make_ulonglong2((uint64_t)vo, (uint64_t)(vo >> 64));
+        o[2 * stride] = make_ulonglong2((uint64_t)vx, (uint64_t)(vx >> 64));
+    } else {
+        uint64_t *o = out + (size_t)b * 3 * stride + e;
+        o[0] = modred(va, CC);
+        o[stride] = modred(vo, CC);
+        o[2 * stride] = modred(vx, CC);
+    }
+}
+
+// digits -> canonical accumulators (debug hook)
+__global__ void __launch_bounds__(256)
+k_dump_acc(const ulonglong2 *__restrict__ dig, ulonglong2 *__restrict__ out,
+           const CrtConst *__restrict__ CC, uint32_t total) {
+    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= total) return;
+    const u128 x = acc_from_digits(dig[t], CC);
+    out[t] = make_ulonglong2((uint64_t)x, (uint64_t)(x >> 64));
+}
+
+// canonical residues -> digits of x' = (v + off) mod Q  (flatten, utils.jl:155-189)
+__global__ void __launch_bounds__(256)
+k_flatten_canon(const ulonglong2 *__restrict__ in, ulonglong2 *__restrict__ dig,
+                const CrtConst *__restrict__ CC, uint32_t total) {
+    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= total) return;
+    const ulonglong2 v = in[t];
+    u128 x = (((u128)v.y << 64) | v.x) + (CC->Q - CC->offneg);
+    if (x >= CC->Q) x -= CC->Q;
+    if (x >= CC->Q) x -= CC->Q;
+    uint64_t hi;
+    const u128 lo = mod_wide(x, CC->B, CC->invB, &hi);
+    dig[t] = make_ulonglong2((uint64_t)lo, hi);
+}
+
+// ---- k_key_transform ------------------------------------------------------------------------------
+// BootstrapKey.key (fhe.jl:176-201) canonical residues -> device form: centred lift to
+// (-Q/2, Q/2], residue mod p_i, scaled by kappa_i, forward NTT, slot order.
+//   canon  [npolys][m] 16-byte residues (polys in [k][row][col] order)
+//   keyhat [k][NPR][row*2+col][m]
+template <int LOGM>
+__global__ void __launch_bounds__(NttGeom<LOGM>::T)
+k_key_transform(const ulonglong2 *__restrict__ canon, uint32_t *__restrict__ keyhat, PrimeSet PS,
+                const CrtConst *__restrict__ CC, uint32_t poly0) {
+    using G = NttGeom<LOGM>;
+    constexpr int M = G::M, T = G::T;
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const int tid = threadIdx.x;
+    const uint32_t pl = blockIdx.x / NPR;  // polynomial within this staging batch
+    const uint32_t pi = blockIdx.x % NPR;
+    const PrimeK P = PS[pi];
+    const uint32_t p = P.p;
+    const u128 halfQ = CC->halfQ;
+    uint32_t x[1][8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+        const ulonglong2 v = canon[(size_t)pl * M + tid + T * e];
+        const uint32_t c0 = (uint32_t)v.x, c1 = (uint32_t)(v.x >> 32), c2 = (uint32_t)v.y;
+        uint32_t r = csub(mont_mul(c0, P.r1, p, P.ninv) + mont_mul(c1, P.r2, p, P.ninv), p);
+        r = csub(r + mont_mul(c2, P.r3, p, P.ninv), p);
+        const u128 C = ((u128)v.y << 64) | v.x;
+        if (C > halfQ) { r = r - P.qmodp; r = min(r, r + p); }
+        x[0][e] = mont_mul(r, P.kappaR, p, P.ninv);
+    }
+    ntt_forward<LOGM, 1>(x, lds, P.twf, tid, p);
+    const uint32_t pg = poly0 + pl;  // global polynomial index = k * 8 + row * 2 + col
+    uint32_t *dst = keyhat + (((size_t)(pg >> 3) * NPR + pi) * 8 + (pg & 7)) * M + 8 * tid;
+    uint32_t o[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+        uint32_t u = x[0][e];
+        u = min(u, u - 2 * p);
+        o[e] = csub(u, p);
+    }
+    reinterpret_cast<uint4 *>(dst)[0] = make_uint4(o[0], o[1], o[2], o[3]);
+    reinterpret_cast<uint4 *>(dst)[1] = make_uint4(o[4], o[5], o[6], o[7]);
+}
+
+// ---- k_debug_ntt ----------------------------------------------------------------------------------
+template <int LOGM>
+__global__ void __launch_bounds__(NttGeom<LOGM>::T)
+k_debug_ntt(const uint32_t *__restrict__ in, uint32_t *__restrict__ out, PrimeSet PS, uint32_t pi,
+            uint32_t inverse) {
+    using G = NttGeom<LOGM>;
+    constexpr int T = G::T;
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const int tid = threadIdx.x;
+    const PrimeK P = PS[pi];
+    const uint32_t p = P.p;
+    uint32_t x[1][8];
+    if (!inverse) {
+#pragma unroll
+        for (int e = 0; e < 8; e++) x[0][e] = in[tid + T * e];
+        ntt_forward<LOGM, 1>(x, lds, P.twf, tid, p);
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            uint32_t u = x[0][e];
+            u = min(u, u - 2 * p);
+            out[8 * tid + e] = csub(u, p);
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; e++) x[0][e] = in[8 * tid + e];
+        ntt_inverse<LOGM, 1>(x, lds, P.twi, tid, p);
+#pragma unroll
+        for (int e = 0; e < 8; e++)
+            out[tid + T * e] = mont_mul(csub(x[0][e], p), P.minvR, p, P.ninv);
+    }
+}
+
+}  // namespace sgfhe

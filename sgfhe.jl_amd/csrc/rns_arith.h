@@ -1,0 +1,58 @@
+// Word-size modular arithmetic for the RNS primes (p < 2^30) on gfx950.
+//
+// The native integer multiplier of a CDNA4 lane is 32 x 32 (v_mul_lo_u32 / v_mul_hi_u32 /
+// v_mad_u64_u32), so the wide ring Z_Q (Q up to 94 bits; DarkIntegers MgModUInt{UInt128, Q} in
+// the reference, src/fhe.jl:83-85,104) is replaced on the device by exact integer arithmetic in
+// a residue number system of 30-bit NTT primes.  Everything here is exact; laziness ranges are
+// stated per function.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace sgfhe {
+
+// x in [0, 2p) -> [0, p).  (x - p wraps above x when x < p, so min picks x.)
+__device__ __forceinline__ uint32_t csub(uint32_t x, uint32_t p) { return min(x, x - p); }
+
+// Shoup multiplication by a constant w with companion wp = floor(w * 2^32 / p):
+// returns w * y mod p in [0, 2p) for any y < 2^32.
+__device__ __forceinline__ uint32_t shoup_mul(uint32_t y, uint32_t w, uint32_t wp, uint32_t p) {
+    uint32_t q = __umulhi(wp, y);
+    return w * y - q * p;
+}
+
+// Montgomery reduction, R = 2^32: T < p * 2^32 -> T * R^-1 mod p in [0, 2p).
+// ninv = -p^-1 mod 2^32.
+__device__ __forceinline__ uint32_t redc64(uint64_t T, uint32_t p, uint32_t ninv) {
+    uint32_t tlo = (uint32_t)T, thi = (uint32_t)(T >> 32);
+    uint32_t mq = tlo * ninv;
+    uint32_t h = __umulhi(mq, p);
+    // tlo + lo(mq * p) == 0 mod 2^32, carry out iff tlo != 0
+    return thi + h + (tlo != 0u);
+}
+
+// a * b * R^-1 mod p in [0, p); a * b < p * 2^32 required (e.g. a < 2^32, b < p).
+__device__ __forceinline__ uint32_t mont_mul(uint32_t a, uint32_t b, uint32_t p, uint32_t ninv) {
+    return csub(redc64((uint64_t)a * b, p, ninv), p);
+}
+
+// Forward (Cooley-Tukey) Harvey butterfly: X, Y in [0, 4p) -> X + wY, X - wY in [0, 4p).
+__device__ __forceinline__ void bfly_fwd(uint32_t &X, uint32_t &Y, uint32_t w, uint32_t wp,
+                                         uint32_t p, uint32_t p2) {
+    uint32_t x = min(X, X - p2);  // [0, 2p)
+    uint32_t t = shoup_mul(Y, w, wp, p);
+    X = x + t;
+    Y = x + p2 - t;
+}
+
+// Inverse (Gentleman-Sande) Harvey butterfly: X, Y in [0, 2p) -> X + Y, w (X - Y) in [0, 2p).
+__device__ __forceinline__ void bfly_inv(uint32_t &X, uint32_t &Y, uint32_t w, uint32_t wp,
+                                         uint32_t p, uint32_t p2) {
+    uint32_t s = X + Y;
+    uint32_t t = X + p2 - Y;
+    X = min(s, s - p2);
+    Y = shoup_mul(t, w, wp, p);
+}
+
+}  // namespace sgfhe

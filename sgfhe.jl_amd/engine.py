@@ -1,0 +1,178 @@
+"""Thin Python handle on one `sgfhe_ctx` of libsgfhe_hip.so (include/sgfhe_hip.h).
+
+Host arrays are numpy; 128-bit residues are uint64 arrays with a trailing axis of 2 ({lo, hi}).
+Device-resident entry points take raw device pointers (e.g. `torch.Tensor.data_ptr()`); PyTorch
+is only plumbing for device memory and torch.distributed (RCCL), never the compute path.
+"""
+
+import ctypes
+
+import numpy as np
+
+from . import _lib
+
+FLAG_RAW_MODQ = 1
+
+
+class SgfheError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("sgfhe_hip error %d: %s" % (code, msg))
+        self.code = code
+
+
+def _words(x):
+    return (ctypes.c_uint64 * 2)(x & 0xFFFFFFFFFFFFFFFF, (x >> 64) & 0xFFFFFFFFFFFFFFFF)
+
+
+def _c(arr, dtype=np.uint64):
+    a = np.ascontiguousarray(arr, dtype=dtype)
+    return a, a.ctypes.data_as(ctypes.c_void_p)
+
+
+class Engine:
+    """One bootstrap engine (ctx) for one parameter set on one HIP device."""
+
+    def __init__(self, params, device=0):
+        self.params = params
+        self.device = device
+        self._L = _lib.lib()
+        sp = _lib.SgfheParams(params.n, params.r, params.m, params.ell, _words(params.Q),
+                              _words(params.B), _words(params.DQ_tilde))
+        h = ctypes.c_void_p()
+        rc = self._L.sgfhe_ctx_create(ctypes.byref(sp), device, ctypes.byref(h))
+        self._h = h
+        if rc != 0:
+            msg = self._L.sgfhe_last_error_string(h).decode() if h else "ctx_create failed"
+            if h:
+                self._L.sgfhe_ctx_destroy(h)
+                self._h = None
+            raise SgfheError(rc, msg)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.sgfhe_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise SgfheError(rc, self._L.sgfhe_last_error_string(self._h).decode())
+
+    # ---- key ------------------------------------------------------------------------------
+    def upload_key(self, canonical):
+        """canonical: [n][4][2][m][2] uint64, value.(coeffs) of BootstrapKey.key (fhe.jl:176-201)."""
+        p = self.params
+        a, ptr = _c(canonical)
+        if a.size != p.n * 8 * p.m * 2:
+            raise ValueError("bootstrap key must hold n*4*2*m residues of 2 words")
+        self._chk(self._L.sgfhe_bkey_upload(self._h, ptr, a.size))
+
+    def upload_key_rns2(self, pairs, m1, m2):
+        """pairs: [n][4][2][m][2] uint64 (v1, v2) RNS2Number limbs (src/rns.jl:8-24)."""
+        a, ptr = _c(pairs)
+        self._chk(self._L.sgfhe_bkey_upload_rns2(self._h, ptr, a.size, m1, m2))
+
+    def key_device_form_bytes(self):
+        n = ctypes.c_size_t()
+        self._chk(self._L.sgfhe_bkey_device_form_bytes(self._h, ctypes.byref(n)))
+        return n.value
+
+    def export_key_device_form(self, dst_device_ptr):
+        self._chk(self._L.sgfhe_bkey_export_device_form(self._h, ctypes.c_void_p(dst_device_ptr)))
+
+    def import_key_device_form(self, src_device_ptr):
+        self._chk(self._L.sgfhe_bkey_import_device_form(self._h, ctypes.c_void_p(src_device_ptr)))
+
+    # ---- bootstrap ----------------------------------------------------------------------------
+    def set_chunk(self, chunk):
+        self._chk(self._L.sgfhe_set_chunk(self._h, chunk))
+
+    def _lwe_args(self, a1, b1, a2, b2):
+        n = self.params.n
+        a1, p1 = _c(a1)
+        a2, p2 = _c(a2)
+        b1, q1 = _c(b1)
+        b2, q2 = _c(b2)
+        a1 = a1.reshape(-1, n)
+        a2 = a2.reshape(-1, n)
+        batch = a1.shape[0]
+        if a2.shape[0] != batch or b1.size != batch or b2.size != batch:
+            raise ValueError("ragged LWE batch")
+        keep = (a1, a2, b1, b2)
+        return batch, (p1, q1, p2, q2), keep
+
+    def bootstrap_batch(self, a1, b1, a2, b2, raw=False):
+        """bootstrap(bkey, nothing, ., .) (fhe.jl:608-621) over a batch of LWE pairs.
+        Returns [batch][3][n+1] uint64 (AND, OR, XOR; a then b), or [batch][3][n+1][2] residues
+        mod Q with raw=True (_bootstrap_internal, fhe.jl:559-595)."""
+        batch, (p1, q1, p2, q2), _keep = self._lwe_args(a1, b1, a2, b2)
+        n = self.params.n
+        out = np.zeros((batch, 3, n + 1, 2) if raw else (batch, 3, n + 1), dtype=np.uint64)
+        if batch:
+            self._chk(self._L.sgfhe_bootstrap_batch(
+                self._h, p1, q1, p2, q2, batch, out.ctypes.data_as(ctypes.c_void_p),
+                FLAG_RAW_MODQ if raw else 0))
+        return out
+
+    def bootstrap_batch_device(self, a1_ptr, b1_ptr, a2_ptr, b2_ptr, batch, out_ptr, raw=False,
+                               stream=None):
+        """Asynchronous, all buffers device-resident (raw pointers)."""
+        self._chk(self._L.sgfhe_bootstrap_batch_device(
+            self._h, ctypes.c_void_p(a1_ptr), ctypes.c_void_p(b1_ptr), ctypes.c_void_p(a2_ptr),
+            ctypes.c_void_p(b2_ptr), batch, ctypes.c_void_p(out_ptr),
+            FLAG_RAW_MODQ if raw else 0, ctypes.c_void_p(stream or 0)))
+
+    def sync(self):
+        self._chk(self._L.sgfhe_sync(self._h))
+
+    # ---- parity / debug hooks ---------------------------------------------------------------
+    def external_product(self, a, b, A):
+        """external_product(nothing, a, b, A, Val(B), Val(2)) (fhe.jl:519-530)."""
+        m = self.params.m
+        a, pa = _c(a)
+        b, pb = _c(b)
+        A, pA = _c(A)
+        if a.size != 2 * m or b.size != 2 * m or A.size != 16 * m:
+            raise ValueError("external_product: a, b are [m][2]; A is [4][2][m][2]")
+        ra = np.zeros((m, 2), dtype=np.uint64)
+        rb = np.zeros((m, 2), dtype=np.uint64)
+        self._chk(self._L.sgfhe_external_product(self._h, pa, pb, pA,
+                                                 ra.ctypes.data_as(ctypes.c_void_p),
+                                                 rb.ctypes.data_as(ctypes.c_void_p)))
+        return ra, rb
+
+    def debug_accumulators(self, a1, b1, a2, b2, n_iters):
+        batch, (p1, q1, p2, q2), _keep = self._lwe_args(a1, b1, a2, b2)
+        acc = np.zeros((batch, 2, self.params.m, 2), dtype=np.uint64)
+        if batch:
+            self._chk(self._L.sgfhe_debug_accumulators(self._h, p1, q1, p2, q2, batch, n_iters,
+                                                       acc.ctypes.data_as(ctypes.c_void_p)))
+        return acc
+
+    def debug_ntt(self, prime_index, poly, inverse=False):
+        x, px = _c(poly, np.uint32)
+        out = np.zeros(self.params.m, dtype=np.uint32)
+        self._chk(self._L.sgfhe_debug_ntt(self._h, prime_index, int(inverse), px,
+                                          out.ctypes.data_as(ctypes.c_void_p)))
+        return out
+
+    def primes(self):
+        cnt = ctypes.c_uint32()
+        arr = (ctypes.c_uint32 * 8)()
+        self._chk(self._L.sgfhe_debug_primes(self._h, ctypes.byref(cnt), arr))
+        return [int(arr[i]) for i in range(cnt.value)]
+
+    # ---- measurement ----------------------------------------------------------------------------
+    def timing_enable(self, on=True):
+        self._chk(self._L.sgfhe_timing_enable(self._h, int(on)))
+
+    def timing_read(self, reset=True):
+        st = (ctypes.c_double * 5)()
+        self._chk(self._L.sgfhe_timing_read(self._h, st, int(reset)))
+        return dict(extprod_ms=st[0], extprod_samples=int(st[1]), crt_ms=st[2],
+                    crt_samples=int(st[3]), chunk=int(st[4]))

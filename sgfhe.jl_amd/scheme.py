@@ -1,0 +1,235 @@
+"""Host-side mirror of the SGFHE.jl API around the hot path (paths relative to /root/reference):
+`PrivateKey`, `BootstrapKey`, `encrypt` / `split_ciphertext` / `decrypt`, `bootstrap`.
+
+Same names, argument order and error behaviour as src/fhe.jl; the work of `bootstrap()`
+(src/fhe.jl:608-621) is done by the HIP engine behind the C ABI.  Random numbers come from a
+numpy Generator (the reference's MersenneTwister streams are not reproducible outside Julia,
+SURVEY.md F6).  Only the deterministic bootstrap (`rng = nothing` -> `rng=None`) is implemented.
+"""
+
+import numpy as np
+
+from .engine import Engine
+from .params import Params
+
+_M64 = 0xFFFFFFFFFFFFFFFF
+
+
+# ---- small host helpers ---------------------------------------------------------------------
+
+def _negacyclic_mul_small(a, s, r):
+    """a * s mod (x^n + 1, r) for length-n integer vectors with r a power of two <= 2^32
+    (the `Polynomial * Polynomial` of src/fhe.jl:322,479 over Z_r)."""
+    n = len(a)
+    a = np.asarray(a, dtype=np.uint64)
+    s = np.asarray(s, dtype=np.uint64)
+    full = np.zeros(2 * n, dtype=np.uint64)
+    for i in np.nonzero(s)[0]:
+        full[i:i + n] += a * s[i]            # wraps mod 2^64; r | 2^64
+    return (full[:n] - full[n:]) & np.uint64(r - 1)
+
+
+def _negacyclic_mul_big(a, b, Q):
+    """Exact product mod (x^N + 1, Q) of Python-int coefficient lists (Kronecker substitution)."""
+    N = len(a)
+    slot = (2 * (Q - 1).bit_length() + N.bit_length() + 15) // 8
+    pa = int.from_bytes(b"".join(int(c).to_bytes(slot, "little") for c in a), "little")
+    pb = int.from_bytes(b"".join(int(c).to_bytes(slot, "little") for c in b), "little")
+    prod = (pa * pb).to_bytes(2 * N * slot, "little")
+    out = [0] * N
+    for i in range(N):
+        lo = int.from_bytes(prod[i * slot:(i + 1) * slot], "little")
+        hi = int.from_bytes(prod[(i + N) * slot:(i + N + 1) * slot], "little")
+        out[i] = (lo - hi) % Q
+    return out
+
+
+def _uniform_below(rng, bound, count):
+    """`count` Python ints uniform in [0, bound) by rejection on bound.bit_length() bits."""
+    bits = bound.bit_length()
+    mask = (1 << bits) - 1
+    out = []
+    while len(out) < count:
+        raw = rng.integers(0, 1 << 63, size=(2 * (count - len(out)), 2), dtype=np.uint64)
+        for hi, lo in raw.tolist():
+            v = ((hi << 63) | lo) & mask
+            if v < bound:
+                out.append(v)
+    return out[:count]
+
+
+# ---- keys ---------------------------------------------------------------------------------------
+
+class PrivateKey:
+    """PrivateKey(params, rng) (src/fhe.jl:130-138): n random bits."""
+
+    def __init__(self, params, rng):
+        self.params = params
+        self.key = rng.integers(0, 2, size=params.n, dtype=np.uint64)
+
+
+class BootstrapKey:
+    """BootstrapKey(rng, sk) (src/fhe.jl:176-201), resident on the GPU in the engine's form.
+
+    `BootstrapKey(rng, sk)` generates the key on the host (one-time) and uploads it;
+    `BootstrapKey.from_canonical(params, residues)` uploads an existing key given as
+    value.(coeffs) in [k][row][col][coef] order (what the Julia shim passes)."""
+
+    def __init__(self, rng, sk, device=0, engine=None):
+        params = sk.params
+        self.params = params
+        self.engine = engine or Engine(params, device)
+        self.engine.upload_key(self._generate(rng, sk))
+
+    @classmethod
+    def from_canonical(cls, params, residues, device=0, engine=None):
+        self = object.__new__(cls)
+        self.params = params
+        self.engine = engine or Engine(params, device)
+        self.engine.upload_key(residues)
+        return self
+
+    @classmethod
+    def from_rns2(cls, params, pairs, m1, m2, device=0, engine=None):
+        """Key held as RNS2Number (v1, v2) limb pairs (src/rns.jl:8-24), Q = m1 * m2."""
+        self = object.__new__(cls)
+        self.params = params
+        self.engine = engine or Engine(params, device)
+        self.engine.upload_key_rns2(pairs, m1, m2)
+        return self
+
+    @staticmethod
+    def _generate(rng, sk):
+        p = sk.params
+        Q, m, n = p.Q, p.m, p.n
+        ext_key = [int(x) for x in sk.key] + [0] * (m - n)                # fhe.jl:185
+        G = ((1, 0), (p.B, 0), (0, 1), (0, p.B))                          # fhe.jl:119-122
+        out = np.zeros((n, 4, 2, m, 2), dtype=np.uint64)
+        for k in range(n):
+            for row in range(4):
+                aj = _uniform_below(rng, Q, m)                            # fhe.jl:193
+                ej = rng.integers(-n, n + 1, size=m)                      # fhe.jl:194
+                bj = _negacyclic_mul_big(aj, ext_key, Q)                  # fhe.jl:195
+                bj = [(x + int(e)) % Q for x, e in zip(bj, ej)]
+                aj[0] = (aj[0] + ext_key[k] * G[row][0]) % Q              # fhe.jl:196
+                bj[0] = (bj[0] + ext_key[k] * G[row][1]) % Q
+                for col, poly in enumerate((aj, bj)):
+                    out[k, row, col, :, 0] = [v & _M64 for v in poly]
+                    out[k, row, col, :, 1] = [v >> 64 for v in poly]
+        return out
+
+
+# ---- ciphertexts --------------------------------------------------------------------------------
+
+class LWE:
+    """LWE{T} (src/fhe.jl:206-223): a batch-capable (a, b) pair over Z_r as uint64 arrays."""
+
+    def __init__(self, a, b):
+        self.a = np.ascontiguousarray(a, dtype=np.uint64)
+        self.b = np.uint64(b)
+
+    def __eq__(self, other):
+        return np.array_equal(self.a, other.a) and self.b == other.b
+
+
+class EncryptedBit:
+    """EncryptedBit (src/fhe.jl:272-278)."""
+
+    def __init__(self, lwe):
+        self.lwe = lwe
+
+    def __eq__(self, other):
+        return self.lwe == other.lwe
+
+
+class RLWE:
+    def __init__(self, a, b):
+        self.a, self.b = a, b
+
+
+class PackedCiphertext:
+    """PackedCiphertext (src/fhe.jl:252-255)."""
+
+    def __init__(self, params, rlwe):
+        self.params, self.rlwe = params, rlwe
+
+
+def encrypt(key, rng, message):
+    """encrypt(key::PrivateKey, rng, message) (src/fhe.jl:369-372, _encrypt_private :310-328).
+    `a` is drawn from `rng` directly instead of the reference's seed expansion
+    (prng_expand, src/utils.jl:63-68)."""
+    p = key.params
+    message = np.asarray(message, dtype=np.uint64)
+    if len(message) != p.n:
+        raise AssertionError("message must have length n (src/fhe.jl:313)")
+    a = rng.integers(0, p.r, size=p.n, dtype=np.uint64)
+    w_range = p.Dr // 8                                                   # fhe.jl:318
+    w = rng.integers(-w_range, w_range + 1, size=p.n).astype(np.int64).astype(np.uint64)
+    b = (_negacyclic_mul_small(a, key.key, p.r) + w + message * np.uint64(p.Dr)) & np.uint64(p.r - 1)
+    sh = np.uint64(p.t - 4)
+    b = (b >> sh) << sh                                                   # fhe.jl:325
+    return PackedCiphertext(p, RLWE(a, b))
+
+
+def extract(a, i, n):
+    """extract(a, i, n) (src/fhe.jl:237-244) with the reference's 1-based i; a over Z_r."""
+    a = np.asarray(a, dtype=np.uint64)
+    N = len(a)
+    if i > N:
+        raise AssertionError("i <= N required (src/fhe.jl:238)")
+    if i < n:
+        head = a[np.arange(i - 1, -1, -1)]
+        tail = np.uint64(0) - a[np.arange(N - 1, N - 1 - (n - i), -1)]
+        return np.concatenate([head, tail])
+    return a[np.arange(i - 1, i - 1 - n, -1)]
+
+
+def split_ciphertext(ct):
+    """split_ciphertext (src/fhe.jl:287-290)."""
+    p = ct.params
+    mask = np.uint64(p.r - 1)
+    return [EncryptedBit(LWE(extract(ct.rlwe.a, i, p.n) & mask, ct.rlwe.b[i - 1]))
+            for i in range(1, p.n + 1)]
+
+
+def decrypt(key, ct):
+    """decrypt(key, ::EncryptedBit) (src/fhe.jl:504-507) and decrypt(key, ::PackedCiphertext)
+    (src/fhe.jl:471-494)."""
+    p = key.params
+    mask = np.uint64(p.r - 1)
+    if isinstance(ct, EncryptedBit):
+        b1 = (int(ct.lwe.b) - int(np.sum(ct.lwe.a * key.key, dtype=np.uint64))) % p.r
+        return bool(((b1 + p.Dr // 2) % p.r) // p.Dr)
+    b1 = (ct.rlwe.b - _negacyclic_mul_small(ct.rlwe.a, key.key, p.r)) & mask
+    return (((b1 + np.uint64(p.Dr // 2)) & mask) // np.uint64(p.Dr)).astype(bool)
+
+
+# ---- bootstrap -----------------------------------------------------------------------------------
+
+def bootstrap(bkey, rng, enc_bit1, enc_bit2):
+    """bootstrap(bkey, rng, enc_bit1, enc_bit2) (src/fhe.jl:608-621): returns EncryptedBits of
+    AND, OR, XOR.  A batch of 1 through the HIP engine."""
+    if rng is not None:
+        raise NotImplementedError("only the deterministic bootstrap (rng = nothing) is implemented")
+    out = bkey.engine.bootstrap_batch(enc_bit1.lwe.a[None, :], [enc_bit1.lwe.b],
+                                      enc_bit2.lwe.a[None, :], [enc_bit2.lwe.b])
+    n = bkey.params.n
+    return tuple(EncryptedBit(LWE(out[0, g, :n], out[0, g, n])) for g in range(3))
+
+
+def bootstrap_batch(bkey, rng, enc_bits1, enc_bits2):
+    """Batched form: two equally long lists of EncryptedBit -> list of (AND, OR, XOR) triples."""
+    if rng is not None:
+        raise NotImplementedError("only the deterministic bootstrap (rng = nothing) is implemented")
+    if len(enc_bits1) != len(enc_bits2):
+        raise ValueError("ragged batch")
+    n = bkey.params.n
+    if not enc_bits1:
+        return []
+    a1 = np.stack([e.lwe.a for e in enc_bits1])
+    a2 = np.stack([e.lwe.a for e in enc_bits2])
+    b1 = np.array([e.lwe.b for e in enc_bits1], dtype=np.uint64)
+    b2 = np.array([e.lwe.b for e in enc_bits2], dtype=np.uint64)
+    out = bkey.engine.bootstrap_batch(a1, b1, a2, b2)
+    return [tuple(EncryptedBit(LWE(out[t, g, :n], out[t, g, n])) for g in range(3))
+            for t in range(out.shape[0])]

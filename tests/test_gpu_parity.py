@@ -1,0 +1,123 @@
+"""GPU parity tests: the HIP engine (through the C ABI) against the oracle, bit for bit.
+Run on the GPU box with `pytest -m gpu`."""
+
+import numpy as np
+import pytest
+
+import bigint_oracle as BO
+import rns_model as RM
+
+pytestmark = pytest.mark.gpu
+
+
+def _synthetic(n, qbits=50, bbits=None, seed=0):
+    m = 8 * n
+    Q = BO.find_modulus(2 * m, 1 << qbits)
+    B = 1 << ((Q.bit_length() + 1) // 2 if bbits is None else bbits)
+    return Q, B
+
+
+def _inputs(oc_obj, sk, batch, seed):
+    rng = np.random.default_rng(seed)
+    bits = rng.integers(0, 2, size=2 * batch).astype(np.uint8)
+    a, b = oc_obj.lwe_encrypt_bits(sk, bits, seed)
+    return bits, a[0::2], b[0::2], a[1::2], b[1::2]
+
+
+@pytest.mark.parametrize("logm", [6, 7, 8, 9, 10, 11, 12, 13])
+def test_ntt_matches_model(S, logm):
+    """sgfhe_debug_ntt: forward = evaluations in slot order, inverse(forward(x)) = x."""
+    m = 1 << logm
+    n = m // 8
+    Q, B = _synthetic(n)
+    eng = S.Engine(S.Params.custom(n, Q, B))
+    primes = eng.primes()
+    assert primes == RM.rns_primes()
+    rng = np.random.default_rng(logm)
+    C = RM.Consts(n, m, Q, B, Q // 8)
+    N = RM.NttModel(logm)
+    for pi in (0, len(primes) - 1):
+        p = primes[pi]
+        poly = rng.integers(0, p, size=m, dtype=np.uint64)
+        fwd = eng.debug_ntt(pi, poly.astype(np.uint32))
+        model = N.forward(N.to_regs(poly), C.pk[pi]["twf"], p).reshape(-1) % p
+        assert np.array_equal(fwd.astype(np.uint64), model)
+        if logm <= 8:
+            ref = RM.ntt_reference([int(v) for v in poly], C.pk[pi]["psi"], p)
+            assert [int(v) for v in fwd] == ref
+        back = eng.debug_ntt(pi, fwd, inverse=True)
+        assert np.array_equal(back.astype(np.uint64), poly)
+    eng.close()
+
+
+@pytest.mark.parametrize("use_gadget", [True, False])
+def test_external_product(S, oc, use_gadget):
+    """test/internals.test.jl:144-166: q = 2^60 - 1 (composite), B = 2^30, length 64; with the
+    pure gadget matrix the external product is the identity; with a random matrix it must equal
+    the oracle."""
+    m, n = 64, 8
+    B = 1 << 30
+    Q = B * B - 1
+    params = S.Params.custom(n, Q, B)
+    eng = S.Engine(params)
+    o = oc.Oracle.from_params(params)
+    rng = np.random.default_rng(11)
+    def rnd(shape):
+        v = np.zeros(shape + (2,), dtype=np.uint64)
+        v[..., 0] = rng.integers(0, Q, size=shape, dtype=np.uint64)
+        return v
+    a, b = rnd((m,)), rnd((m,))
+    A = np.zeros((4, 2, m, 2), dtype=np.uint64) if use_gadget else rnd((4, 2, m))
+    for row, col, g in ((0, 0, 1), (1, 0, B), (2, 1, 1), (3, 1, B)):
+        A[row, col, 0, 0] = (int(A[row, col, 0, 0]) + g) % Q
+    ra, rb = eng.external_product(a, b, A)
+    if use_gadget:
+        assert np.array_equal(ra, a) and np.array_equal(rb, b)
+    ea, eb = o.external_product(a, b, A)
+    assert np.array_equal(ra, ea) and np.array_equal(rb, eb)
+    eng.close()
+
+
+@pytest.mark.parametrize("n", [8, 16, 32])
+def test_small_synthetic_bootstrap(S, oc, n):
+    """Synthetic tiny rings (m = 64, 128, 256: all three pass structures) vs the oracle:
+    accumulators after every iteration count, raw LWEs mod Q, and ModRed words."""
+    Q, B = _synthetic(n)
+    params = S.Params.custom(n, Q, B)
+    o = oc.Oracle.from_params(params)
+    sk = o.private_key(100 + n)
+    bkey = o.bootstrap_key(sk, 200 + n, noise=2)
+    eng = S.Engine(params)
+    eng.upload_key(bkey)
+    batch = 5
+    bits, a1, b1, a2, b2 = _inputs(o, sk, batch, 300 + n)
+    for it in (1, 2, n):
+        _, acc_ref = o.bootstrap_batch(bkey, a1, b1, a2, b2, n_iters=it, want_acc=True)
+        acc = eng.debug_accumulators(a1, b1, a2, b2, it)
+        assert np.array_equal(acc, acc_ref), "accumulators differ after %d iterations" % it
+    assert np.array_equal(eng.bootstrap_batch(a1, b1, a2, b2, raw=True),
+                          o.bootstrap_batch(bkey, a1, b1, a2, b2, raw=True))
+    assert np.array_equal(eng.bootstrap_batch(a1, b1, a2, b2),
+                          o.bootstrap_batch(bkey, a1, b1, a2, b2))
+    eng.close()
+
+
+def test_params64_bootstrap_truth_table(S, oc):
+    """test/api.test.jl:45-83 (deterministic branch) at Params(64), through the GPU: outputs equal
+    the oracle bit for bit and decrypt to AND / OR / XOR."""
+    params = S.Params(64)
+    o = oc.Oracle.from_params(params)
+    sk = o.private_key(1)
+    bkey = o.bootstrap_key(sk, 2)
+    eng = S.Engine(params)
+    eng.upload_key(bkey)
+    batch = 32
+    bits, a1, b1, a2, b2 = _inputs(o, sk, batch, 3)
+    out = eng.bootstrap_batch(a1, b1, a2, b2)
+    ref = o.bootstrap_batch(bkey, a1, b1, a2, b2)
+    assert np.array_equal(out, ref)
+    y1, y2 = bits[0::2], bits[1::2]
+    for g, fn in enumerate((np.bitwise_and, np.bitwise_or, np.bitwise_xor)):
+        dec = o.lwe_decrypt_bits(sk, out[:, g, :params.n], out[:, g, params.n])
+        assert np.array_equal(dec, fn(y1, y2))
+    eng.close()
