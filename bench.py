@@ -1,0 +1,223 @@
+#!/usr/bin/env python3
+"""bench.py -- bootstraps/sec of the MI355X gate-bootstrap engine (BASELINE.json metric).
+
+One "step" = one pass of the hot path (`bootstrap()` of nucypher/SGFHE.jl,
+/root/reference/src/fhe.jl:608-621) over one batch of independent gate bootstraps resident in
+HBM.  Default workload: the reference's own Params(1024) (Q = 92180593745615474572738561,
+86.25-bit prime; SURVEY.md config 4'), batch 4096 per GPU, synthetic uniformly random bootstrap
+key and LWE inputs (the arithmetic does not depend on the key being a valid encryption).
+
+Multi-GPU (launched by torch.distributed.run, one rank per GPU): the batch shards across ranks,
+rank 0 builds the device-form key and broadcasts it once over RCCL; there is no collective in
+the timed region ("scaling": "weak").
+
+Prints ONE JSON line on rank 0.
+"""
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_HBM_GBS = 8000.0     # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+W_BYTES = {"params1024": 16, "params512": 16, "params64": 8, "synth64": 8}
+
+
+def make_params(S, name):
+    if name == "params1024":
+        return S.Params(1024)
+    if name == "params512":
+        return S.Params(512)
+    if name == "params64":
+        return S.Params(64)
+    if name == "synth64":   # BASELINE.json config 3: n = 1024 with a single-limb 64-bit prime
+        m = 8192
+        Q = S.find_modulus(2 * m, (1 << 63) - (1 << 40))
+        return S.Params.custom(1024, Q, 1 << 32)
+    raise SystemExit("unknown --config " + name)
+
+
+def random_key(p, seed):
+    """Synthetic bootstrap key: canonical residues in [0, Q), [n][4][2][m][2] uint64."""
+    rng = np.random.default_rng(seed)
+    shape = (p.n, 4, 2, p.m)
+    key = np.empty(shape + (2,), dtype=np.uint64)
+    qhi = p.Q >> 64
+    if qhi:
+        key[..., 0] = rng.integers(0, 1 << 64, size=shape, dtype=np.uint64)
+        key[..., 1] = rng.integers(0, qhi, size=shape, dtype=np.uint64)   # hi < Q_hi => value < Q
+    else:
+        key[..., 0] = rng.integers(0, p.Q, size=shape, dtype=np.uint64)
+        key[..., 1] = 0
+    return key
+
+
+def algorithmic_bytes_per_bootstrap(p, W, batch):
+    """n m W (4 + 8 / batch) + 40 (n + 1)."""
+    return p.n * p.m * W * (4 + 8.0 / batch) + 40 * (p.n + 1)
+
+
+def cpu_baseline(p, key, seconds_target=15.0):
+    """Oracle 'port' (oracle/sgfhe_oracle.c: reference-shaped, 128-bit Montgomery, 24 NTTs per
+    iteration) timed on one host core over a truncated k-loop of ONE bootstrap, scaled to a full
+    bootstrap.  Test infrastructure used as a reported baseline only."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_c
+    o = oracle_c.Oracle.from_params(p)
+    rng = np.random.default_rng(7)
+    a = rng.integers(0, p.r, size=(2, p.n), dtype=np.uint64)
+    b = rng.integers(0, p.r, size=2, dtype=np.uint64)
+    t0 = time.perf_counter()
+    o.bootstrap_batch(key, a[:1], b[:1], a[1:], b[1:], n_iters=2, threads=1)
+    per_iter = max((time.perf_counter() - t0) / 2, 1e-6)
+    iters = int(min(p.n, max(4, seconds_target / per_iter)))
+    t0 = time.perf_counter()
+    o.bootstrap_batch(key, a[:1], b[:1], a[1:], b[1:], n_iters=iters, threads=1)
+    dt = time.perf_counter() - t0
+    full = dt * p.n / iters
+    return {"value": 1.0 / full, "unit": "bootstraps/sec", "cores": 1, "kind": "port",
+            "sample": "1 bootstrap, first %d of %d k-loop iterations (%.1f s), scaled x%.2f; "
+                      "reference-shaped C restatement, 1 thread" % (iters, p.n, dt, p.n / iters)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", default="params1024")
+    ap.add_argument("--batch", type=int, default=4096, help="bootstraps per GPU per step")
+    ap.add_argument("--chunk", type=int, default=0, help="lock-step chunk (0 = engine default)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import sgfhe_jl_amd as S
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    p = make_params(S, args.config)
+    W = W_BYTES[args.config]
+    eng = S.Engine(p, device=local_rank)
+    if args.chunk:
+        eng.set_chunk(args.chunk)
+
+    # ---- bootstrap key: rank 0 transforms, peers receive the device form over RCCL -------------
+    key = None
+    kbytes = eng.key_device_form_bytes()
+    if rank == 0:
+        key = random_key(p, 1)
+        eng.upload_key(key)
+    if world > 1:
+        blob = torch.empty(kbytes, dtype=torch.uint8, device="cuda")
+        if rank == 0:
+            eng.export_key_device_form(blob.data_ptr())
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        dist.broadcast(blob, src=0)
+        torch.cuda.synchronize()
+        bcast_s = time.perf_counter() - t0
+        if rank != 0:
+            eng.import_key_device_form(blob.data_ptr())
+        del blob
+    else:
+        bcast_s = 0.0
+
+    # ---- synthetic LWE inputs, resident in HBM ---------------------------------------------------
+    g = torch.Generator(device="cuda")
+    g.manual_seed(1234 + rank)
+    B = args.batch
+    a1 = torch.randint(0, p.r, (B, p.n), dtype=torch.int64, device="cuda", generator=g)
+    a2 = torch.randint(0, p.r, (B, p.n), dtype=torch.int64, device="cuda", generator=g)
+    b1 = torch.randint(0, p.r, (B,), dtype=torch.int64, device="cuda", generator=g)
+    b2 = torch.randint(0, p.r, (B,), dtype=torch.int64, device="cuda", generator=g)
+    out = torch.zeros((B, 3, p.n + 1), dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+
+    def step():
+        eng.bootstrap_batch_device(a1.data_ptr(), b1.data_ptr(), a2.data_ptr(), b2.data_ptr(), B,
+                                   out.data_ptr())
+
+    for _ in range(args.warmup):
+        step()
+    eng.sync()
+    eng.timing_enable(True)
+    eng.timing_read(reset=True)
+
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    eng.sync()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if dist:
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    tm = eng.timing_read(reset=True)
+    eng.timing_enable(False)
+
+    if rank == 0:
+        total = world * args.steps * B
+        value = total / dt
+        per_boot = algorithmic_bytes_per_bootstrap(p, W, B)
+        chunk = tm["chunk"] or B
+        # one k_extprod launch = `chunk` bootstraps x one k-loop iteration = chunk / n bootstraps
+        launch_bytes = per_boot * chunk / p.n
+        ext_s = tm["extprod_ms"] * 1e-3
+        crt_s = tm["crt_ms"] * 1e-3
+        achieved = launch_bytes / ext_s / 1e9 if ext_s > 0 else 0.0
+        pair = launch_bytes / (ext_s + crt_s) / 1e9 if ext_s + crt_s > 0 else 0.0
+        res = {
+            "metric": "bootstraps/sec", "value": value, "unit": "bootstraps/sec",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+            "config": {"workload": "%s gate bootstraps (AND/OR/XOR), batch %d per GPU, "
+                                   "deterministic flatten" % (args.config, B),
+                       "n": p.n, "m": p.m, "log2_Q": round(float(np.log2(float(p.Q))), 2),
+                       "batch_per_gpu": B, "chunk": chunk, "rns_primes": 5,
+                       "key": "uniform random residues mod Q (synthetic)",
+                       "key_broadcast_s": round(bcast_s, 4)},
+            "roofline": {"bound": "hbm", "kernel": "k_extprod", "achieved": achieved,
+                         "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": achieved / PEAK_HBM_GBS,
+                         "traffic": None,
+                         "launch_ms": tm["extprod_ms"], "launch_samples": tm["extprod_samples"],
+                         "algorithmic_bytes_per_launch": launch_bytes,
+                         "pair_kernel": "k_crt_acc", "pair_launch_ms": tm["crt_ms"],
+                         "pair_achieved": pair, "pair_frac": pair / PEAK_HBM_GBS,
+                         "whole_job_frac": per_boot * value / world / (PEAK_HBM_GBS * 1e9)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(p, key)
+        print(json.dumps(res))
+    if dist:
+        dist.destroy_process_group()
+    eng.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -48,24 +48,23 @@ __device__ __forceinline__ void fwd_bit2(uint32_t (&x)[NP][8], uint2 w, uint32_t
         for (int e = 0; e < 4; e++) bfly_fwd(x[q][e], x[q][e + 4], w.x, w.y, p, p2);
 }
 template <int NP>
-__device__ __forceinline__ void fwd_bit1(uint32_t (&x)[NP][8], uint4 w, uint32_t p, uint32_t p2) {
-#pragma unroll
-    for (int q = 0; q < NP; q++) {
-        bfly_fwd(x[q][0], x[q][2], w.x, w.y, p, p2);
-        bfly_fwd(x[q][1], x[q][3], w.x, w.y, p, p2);
-        bfly_fwd(x[q][4], x[q][6], w.z, w.w, p, p2);
-        bfly_fwd(x[q][5], x[q][7], w.z, w.w, p, p2);
-    }
-}
-template <int NP>
-__device__ __forceinline__ void fwd_bit0(uint32_t (&x)[NP][8], uint4 wa, uint4 wb, uint32_t p,
+__device__ __forceinline__ void fwd_bit1(uint32_t (&x)[NP][8], uint2 wa, uint2 wb, uint32_t p,
                                          uint32_t p2) {
 #pragma unroll
     for (int q = 0; q < NP; q++) {
-        bfly_fwd(x[q][0], x[q][1], wa.x, wa.y, p, p2);
-        bfly_fwd(x[q][2], x[q][3], wa.z, wa.w, p, p2);
-        bfly_fwd(x[q][4], x[q][5], wb.x, wb.y, p, p2);
-        bfly_fwd(x[q][6], x[q][7], wb.z, wb.w, p, p2);
+        bfly_fwd(x[q][0], x[q][2], wa.x, wa.y, p, p2);
+        bfly_fwd(x[q][1], x[q][3], wa.x, wa.y, p, p2);
+        bfly_fwd(x[q][4], x[q][6], wb.x, wb.y, p, p2);
+        bfly_fwd(x[q][5], x[q][7], wb.x, wb.y, p, p2);
+    }
+}
+template <int NP>
+__device__ __forceinline__ void fwd_bit0(uint32_t (&x)[NP][8], const uint2 (&w)[4], uint32_t p,
+                                         uint32_t p2) {
+#pragma unroll
+    for (int q = 0; q < NP; q++) {
+#pragma unroll
+        for (int h = 0; h < 4; h++) bfly_fwd(x[q][2 * h], x[q][2 * h + 1], w[h].x, w[h].y, p, p2);
     }
 }
 template <int NP>
@@ -76,24 +75,23 @@ __device__ __forceinline__ void inv_bit2(uint32_t (&x)[NP][8], uint2 w, uint32_t
         for (int e = 0; e < 4; e++) bfly_inv(x[q][e], x[q][e + 4], w.x, w.y, p, p2);
 }
 template <int NP>
-__device__ __forceinline__ void inv_bit1(uint32_t (&x)[NP][8], uint4 w, uint32_t p, uint32_t p2) {
-#pragma unroll
-    for (int q = 0; q < NP; q++) {
-        bfly_inv(x[q][0], x[q][2], w.x, w.y, p, p2);
-        bfly_inv(x[q][1], x[q][3], w.x, w.y, p, p2);
-        bfly_inv(x[q][4], x[q][6], w.z, w.w, p, p2);
-        bfly_inv(x[q][5], x[q][7], w.z, w.w, p, p2);
-    }
-}
-template <int NP>
-__device__ __forceinline__ void inv_bit0(uint32_t (&x)[NP][8], uint4 wa, uint4 wb, uint32_t p,
+__device__ __forceinline__ void inv_bit1(uint32_t (&x)[NP][8], uint2 wa, uint2 wb, uint32_t p,
                                          uint32_t p2) {
 #pragma unroll
     for (int q = 0; q < NP; q++) {
-        bfly_inv(x[q][0], x[q][1], wa.x, wa.y, p, p2);
-        bfly_inv(x[q][2], x[q][3], wa.z, wa.w, p, p2);
-        bfly_inv(x[q][4], x[q][5], wb.x, wb.y, p, p2);
-        bfly_inv(x[q][6], x[q][7], wb.z, wb.w, p, p2);
+        bfly_inv(x[q][0], x[q][2], wa.x, wa.y, p, p2);
+        bfly_inv(x[q][1], x[q][3], wa.x, wa.y, p, p2);
+        bfly_inv(x[q][4], x[q][6], wb.x, wb.y, p, p2);
+        bfly_inv(x[q][5], x[q][7], wb.x, wb.y, p, p2);
+    }
+}
+template <int NP>
+__device__ __forceinline__ void inv_bit0(uint32_t (&x)[NP][8], const uint2 (&w)[4], uint32_t p,
+                                         uint32_t p2) {
+#pragma unroll
+    for (int q = 0; q < NP; q++) {
+#pragma unroll
+        for (int h = 0; h < 4; h++) bfly_inv(x[q][2 * h], x[q][2 * h + 1], w[h].x, w[h].y, p, p2);
     }
 }
 
@@ -133,32 +131,34 @@ __device__ __forceinline__ void lds_load(uint32_t (&x)[NP][8], const uint32_t *l
 // tw[i] = (w, floor(w 2^32 / p)) with w = psi^bitrev(i) (forward) or psi^-bitrev(i) (inverse),
 // i in [1, m): the tables of the merged-twist CT / GS transforms.  A pass over bits [S, S+3)
 // of thread-group `hi` needs entries  2^(LOGM-3-S) + hi,  2^(LOGM-2-S) + 2 hi + {0,1},
-// 2^(LOGM-1-S) + 4 hi + {0..3}: one uint2, one uint4 and two uint4 loads.
+// 2^(LOGM-1-S) + 4 hi + {0..3}: 1 + 2 + 4 consecutive entries.  (All loads keep the uint2 element
+// type: a uint4-typed view of the same table made hipcc -O3's load/store vectorizer emit a
+// partial load of one entry for LOGM = 11.)
 
 template <int LOGM, int NP, int S>
 __device__ __forceinline__ void fwd_pass_full(uint32_t (&x)[NP][8], const uint2 *tw, int tid,
                                               uint32_t p, uint32_t p2) {
     const uint32_t hi = (uint32_t)tid >> S;
-    const uint4 *tw4 = reinterpret_cast<const uint4 *>(tw);
+    const uint2 *t1 = tw + (1u << (LOGM - 2 - S)) + 2 * hi;
+    const uint2 *t0 = tw + (1u << (LOGM - 1 - S)) + 4 * hi;
     const uint2 w2 = tw[(1u << (LOGM - 3 - S)) + hi];
-    const uint4 w1 = tw4[(1u << (LOGM - 3 - S)) + hi];
-    const uint4 w0a = tw4[(1u << (LOGM - 2 - S)) + 2 * hi];
-    const uint4 w0b = tw4[(1u << (LOGM - 2 - S)) + 2 * hi + 1];
+    const uint2 w1a = t1[0], w1b = t1[1];
+    const uint2 w0[4] = {t0[0], t0[1], t0[2], t0[3]};
     fwd_bit2<NP>(x, w2, p, p2);
-    fwd_bit1<NP>(x, w1, p, p2);
-    fwd_bit0<NP>(x, w0a, w0b, p, p2);
+    fwd_bit1<NP>(x, w1a, w1b, p, p2);
+    fwd_bit0<NP>(x, w0, p, p2);
 }
 template <int LOGM, int NP, int S>
 __device__ __forceinline__ void inv_pass_full(uint32_t (&x)[NP][8], const uint2 *tw, int tid,
                                               uint32_t p, uint32_t p2) {
     const uint32_t hi = (uint32_t)tid >> S;
-    const uint4 *tw4 = reinterpret_cast<const uint4 *>(tw);
-    const uint4 w0a = tw4[(1u << (LOGM - 2 - S)) + 2 * hi];
-    const uint4 w0b = tw4[(1u << (LOGM - 2 - S)) + 2 * hi + 1];
-    const uint4 w1 = tw4[(1u << (LOGM - 3 - S)) + hi];
+    const uint2 *t1 = tw + (1u << (LOGM - 2 - S)) + 2 * hi;
+    const uint2 *t0 = tw + (1u << (LOGM - 1 - S)) + 4 * hi;
+    const uint2 w0[4] = {t0[0], t0[1], t0[2], t0[3]};
+    const uint2 w1a = t1[0], w1b = t1[1];
     const uint2 w2 = tw[(1u << (LOGM - 3 - S)) + hi];
-    inv_bit0<NP>(x, w0a, w0b, p, p2);
-    inv_bit1<NP>(x, w1, p, p2);
+    inv_bit0<NP>(x, w0, p, p2);
+    inv_bit1<NP>(x, w1a, w1b, p, p2);
     inv_bit2<NP>(x, w2, p, p2);
 }
 
@@ -201,7 +201,7 @@ __device__ __forceinline__ void ntt_forward(uint32_t (&x)[NP][8], uint32_t *lds,
         fwd_pass_full<LOGM, NP, G::STOP>(x, tw, tid, p, p2);
     } else {
         fwd_bit2<NP>(x, tw[1], p, p2);
-        if constexpr (G::RHO == 2) fwd_bit1<NP>(x, reinterpret_cast<const uint4 *>(tw)[1], p, p2);
+        if constexpr (G::RHO == 2) fwd_bit1<NP>(x, tw[2], tw[3], p, p2);
     }
     if constexpr (G::SFIRST >= 0)
         FwdPasses<LOGM, NP, G::STOP, G::SFIRST>::run(x, lds, tw, tid, p, p2);
@@ -222,7 +222,7 @@ __device__ __forceinline__ void ntt_inverse(uint32_t (&x)[NP][8], uint32_t *lds,
         lds_store<LOGM, NP, SLAST>(x, lds, tid);
         __syncthreads();
         lds_load<LOGM, NP, G::STOP>(x, lds, tid);
-        if constexpr (G::RHO == 2) inv_bit1<NP>(x, reinterpret_cast<const uint4 *>(tw)[1], p, p2);
+        if constexpr (G::RHO == 2) inv_bit1<NP>(x, tw[2], tw[3], p, p2);
         inv_bit2<NP>(x, tw[1], p, p2);
     }
 }
