@@ -200,7 +200,7 @@ size_t per_bootstrap_bytes(const sgfhe_ctx *c) {
 // Default chunk: keep the per-iteration working set (digits + residues) of a chunk inside the
 // 256 MiB Infinity Cache, and give every CU several workgroups.
 uint32_t default_chunk(const sgfhe_ctx *c) {
-    size_t budget = (size_t)144 << 20;
+    size_t budget = (size_t)160 << 20;
     size_t k = budget / per_bootstrap_bytes(c);
     if (k >= 256) k = (k / 256) * 256;
     else k = (k / 8) * 8;
@@ -238,10 +238,11 @@ void timing_flush(sgfhe_ctx *c) {
 
 // ---- the k-loop over one chunk (fhe.jl:579-582) ---------------------------------------------------
 
-int32_t run_iterations(sgfhe_ctx *c, uint32_t cpad, uint64_t n_iters, hipStream_t st) {
+int32_t run_iterations(sgfhe_ctx *c, uint32_t cpad, uint64_t n_iters, hipStream_t st,
+                       bool full_chunk) {
     const size_t slice = (size_t)NPR * 8 * c->M;
     for (uint64_t k = 0; k < n_iters; k++) {
-        const bool sample = c->timing && (k % 64 == 1) && c->ev.size() < 2048;
+        const bool sample = c->timing && full_chunk && (k % 64 == 1) && c->ev.size() < 2048;
         hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
         if (sample) {
             HIPCHK(c, hipEventCreate(&e0));
@@ -274,13 +275,14 @@ int32_t bootstrap_device(sgfhe_ctx *c, const uint64_t *a1, const uint64_t *b1, c
         const uint32_t cpad = round_up8(cb);
         int32_t rc = ensure_work(c, cpad);
         if (rc) return rc;
-        c->last_chunk = cpad;
+        const bool full_chunk = (c0 == 0);  // later chunks are the same size or a smaller tail
+        if (full_chunk) c->last_chunk = cpad;
         const uint32_t tot = cpad * M;
         hipLaunchKernelGGL(k_init, dim3((tot + 255) / 256), dim3(256), 0, st, a1 + c0 * n, b1 + c0,
                            a2 + c0 * n, b2 + c0, c->d_dig, c->d_ua, c->d_crt, cb, cpad, n,
                            (uint32_t)c->logm);
         HIPCHK(c, hipGetLastError());
-        rc = run_iterations(c, cpad, n_iters, st);
+        rc = run_iterations(c, cpad, n_iters, st, full_chunk || cpad == c->last_chunk);
         if (rc) return rc;
         if (acc_out) {
             const uint32_t t2 = cb * 2 * M;
