@@ -121,3 +121,52 @@ def test_params64_bootstrap_truth_table(S, oc):
         dec = o.lwe_decrypt_bits(sk, out[:, g, :params.n], out[:, g, params.n])
         assert np.array_equal(dec, fn(y1, y2))
     eng.close()
+
+
+# ---- BASELINE.json configurations at full ring size --------------------------------------------
+
+def _big_case(S, oc, params, batch, key_seed, in_seed, valid_key, iters_checked):
+    o = oc.Oracle.from_params(params)
+    sk = o.private_key(key_seed)
+    if valid_key:
+        bkey = o.bootstrap_key(sk, key_seed + 1)
+    else:
+        import bench
+        bkey = bench.random_key(params, key_seed)
+    eng = S.Engine(params)
+    eng.upload_key(bkey)
+    bits, a1, b1, a2, b2 = _inputs(o, sk, batch, in_seed)
+    for it in iters_checked:
+        _, acc_ref = o.bootstrap_batch(bkey, a1[:1], b1[:1], a2[:1], b2[:1], n_iters=it, want_acc=True)
+        acc = eng.debug_accumulators(a1[:1], b1[:1], a2[:1], b2[:1], it)
+        assert np.array_equal(acc, acc_ref), "accumulators differ after %d iterations" % it
+    out = eng.bootstrap_batch(a1, b1, a2, b2)
+    ref = o.bootstrap_batch(bkey, a1, b1, a2, b2)
+    assert np.array_equal(out, ref)
+    if valid_key:
+        y1, y2 = bits[0::2], bits[1::2]
+        for g, fn in enumerate((np.bitwise_and, np.bitwise_or, np.bitwise_xor)):
+            dec = o.lwe_decrypt_bits(sk, out[:, g, :params.n], out[:, g, params.n])
+            assert np.array_equal(dec, fn(y1, y2))
+    eng.close()
+    return out
+
+
+def test_params512_vs_oracle(S, oc):
+    """BASELINE.json config 2 ring (Params(512), Q 80.25 bits): bit-exact vs the oracle, decrypts."""
+    _big_case(S, oc, S.Params(512), batch=8, key_seed=11, in_seed=12, valid_key=True,
+              iters_checked=(1, 2))
+
+
+def test_params1024_vs_oracle(S, oc):
+    """BASELINE.json config 4' (the reference's own Params(1024), Q 86.25 bits)."""
+    _big_case(S, oc, S.Params(1024), batch=4, key_seed=21, in_seed=22, valid_key=True,
+              iters_checked=(1, 2))
+
+
+def test_synthetic_single_limb_1024(S, oc):
+    """BASELINE.json config 3: n = 1024, single-limb 64-bit prime Q', B' = 2^32 (synthetic: the
+    parity target is the oracle at the same parameters, not decryption)."""
+    import bench
+    params = bench.make_params(S, "synth64")
+    _big_case(S, oc, params, batch=2, key_seed=31, in_seed=32, valid_key=False, iters_checked=(1, 3))
