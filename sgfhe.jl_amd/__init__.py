@@ -9,10 +9,11 @@ libsgfhe_hip.so (hand-written HIP for gfx950; include/sgfhe_hip.h).  Import as
 from ._lib import build, lib, LIB_PATH, EXPORTED_SYMBOLS
 from .engine import Engine, SgfheError, FLAG_RAW_MODQ
 from .params import Params, find_modulus, isprime
+from . import distributed
 from .scheme import (PrivateKey, BootstrapKey, LWE, RLWE, EncryptedBit, PackedCiphertext, encrypt,
                      extract, split_ciphertext, decrypt, bootstrap, bootstrap_batch)
 
-__all__ = ["build", "lib", "LIB_PATH", "EXPORTED_SYMBOLS", "Engine", "SgfheError",
+__all__ = ["distributed", "build", "lib", "LIB_PATH", "EXPORTED_SYMBOLS", "Engine", "SgfheError",
            "FLAG_RAW_MODQ", "Params", "find_modulus", "isprime", "PrivateKey", "BootstrapKey",
            "LWE", "RLWE", "EncryptedBit", "PackedCiphertext", "encrypt", "extract",
            "split_ciphertext", "decrypt", "bootstrap", "bootstrap_batch"]

@@ -49,6 +49,13 @@ def lib():
         return _lib
     if not os.path.exists(LIB_PATH):
         build()
+    try:
+        # PyTorch-ROCm ships its own copy of the HIP runtime.  Loading it first makes this
+        # library bind to the same libamdhip64 instead of bringing a second runtime into the
+        # process (with two runtimes, whichever initialises second sees no GPU).
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = ctypes.CDLL(LIB_PATH)
     vp, i32, u32, u64, sz = ctypes.c_void_p, ctypes.c_int32, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_size_t
     sig = {

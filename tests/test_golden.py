@@ -1,0 +1,96 @@
+"""Oracle (both restatements) against the committed golden vectors of tests/golden/ (generated
+by tests/golden/make_golden.py with the big-integer oracle).  No GPU."""
+
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+import bigint_oracle as BO
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load(name):
+    path = os.path.join(G, name + ".json")
+    if not os.path.exists(path):
+        pytest.skip("golden/%s.json not generated" % name)
+    with open(path) as f:
+        return json.load(f)
+
+
+def h_ints(vals, nbytes=16):
+    h = hashlib.sha256()
+    for v in vals:
+        h.update(int(v).to_bytes(nbytes, "little"))
+    return h.hexdigest()
+
+
+def test_tables_rescale_flatten(oc):
+    d = load("tables")
+    for t in d["rescale"]:
+        for x, v in enumerate(t["values"]):
+            assert BO.rescale(t["new_max"], x, t["old_max"], t["round"]) == v
+            assert oc.rescale(t["new_max"], x, t["old_max"], t["round"]) == v
+    for t in d["flatten"]:
+        for a, v in enumerate(t["values"]):
+            assert BO.flatten(a, t["B"], t["ell"], t["q"]) == v
+
+
+def test_external_product_vector(oc):
+    d = load("extprod")
+    Q, B, m = int(d["Q"]), int(d["B"]), d["m"]
+    o = oc.Oracle(n=d["n"], r=16 * d["n"], m=m, Q=Q, B=B, DQ_tilde=Q // 8)
+    A = np.stack([np.stack([oc.ints_to_u128(d["A"][r][c]) for c in range(2)]) for r in range(4)])
+    ra, rb = o.external_product(oc.ints_to_u128(d["a"]), oc.ints_to_u128(d["b"]), A)
+    assert oc.u128_to_ints(ra) == d["a_res"] and oc.u128_to_ints(rb) == d["b_res"]
+    pa, pb = BO.external_product(d["a"], d["b"], d["A"], B, 2, Q)
+    assert pa == d["a_res"] and pb == d["b_res"]
+
+
+def _check_bootstrap_golden(oc, name, full):
+    d = load(name)
+    n = d["params"]["n"]
+    o = oc.Oracle.make(n)
+    assert str(o.Q) == d["params"]["Q"] and str(o.B) == d["params"]["B"]
+    sk = o.private_key(d["sk_seed"])
+    assert [int(x) for x in sk] == d["sk"]
+    bkey = o.bootstrap_key(sk, d["key_seed"])
+    assert hashlib.sha256(np.ascontiguousarray(bkey).tobytes()).hexdigest() == d["key_sha256"]
+    for case in d["cases"]:
+        a1, b1 = np.array([case["lwe1"]["a"]], dtype=np.uint64), [case["lwe1"]["b"]]
+        a2, b2 = np.array([case["lwe2"]["a"]], dtype=np.uint64), [case["lwe2"]["b"]]
+        for k, (ha, hb) in case["acc_sha256_after"].items():
+            if not full and int(k) > 2:
+                continue
+            _, acc = o.bootstrap_batch(bkey, a1, b1, a2, b2, n_iters=int(k), want_acc=True)
+            assert h_ints(oc.u128_to_ints(acc[0, 0])) == ha, "acc_a after %s" % k
+            assert h_ints(oc.u128_to_ints(acc[0, 1])) == hb, "acc_b after %s" % k
+        if full:
+            raw = o.bootstrap_batch(bkey, a1, b1, a2, b2, raw=True)
+            out = o.bootstrap_batch(bkey, a1, b1, a2, b2)
+            for g in range(3):
+                assert h_ints(oc.u128_to_ints(raw[0, g])) == case["raw_sha256"][g]
+                if "out" in case:
+                    assert [int(v) for v in out[0, g]] == case["out"][g]
+                else:
+                    assert h_ints([int(v) for v in out[0, g]], 8) == case["out_sha256"][g]
+            y1, y2 = case["bits"]
+            dec = o.lwe_decrypt_bits(sk, out[0, :, :n], out[0, :, n])
+            assert list(dec) == [y1 & y2, y1 | y2, y1 ^ y2]
+
+
+def test_params64_golden(oc):
+    _check_bootstrap_golden(oc, "p64", full=True)
+
+
+def test_params512_golden(oc):
+    _check_bootstrap_golden(oc, "p512", full=True)
+
+
+def test_params1024_golden(oc):
+    """Accumulator hashes after the first two iterations here; the full-bootstrap golden output is
+    compared with the HIP engine in tests/test_gpu_golden.py."""
+    _check_bootstrap_golden(oc, "p1024", full=False)

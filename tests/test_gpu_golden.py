@@ -1,0 +1,218 @@
+"""HIP engine against the committed golden vectors (tests/golden/, big-integer oracle) and the
+edge cases of the boundary.  Run on the GPU box with `pytest -m gpu`."""
+
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def h_ints(vals, nbytes=16):
+    h = hashlib.sha256()
+    for v in vals:
+        h.update(int(v).to_bytes(nbytes, "little"))
+    return h.hexdigest()
+
+
+def _u128_ints(arr):
+    flat = np.ascontiguousarray(arr).reshape(-1, 2)
+    return [int(lo) | (int(hi) << 64) for lo, hi in flat]
+
+
+@pytest.mark.parametrize("name", ["p64", "p512", "p1024"])
+def test_engine_matches_golden(S, oc, name):
+    path = os.path.join(G, name + ".json")
+    if not os.path.exists(path):
+        pytest.skip("golden/%s.json not generated" % name)
+    d = json.load(open(path))
+    n = d["params"]["n"]
+    params = S.Params(n)
+    assert str(params.Q) == d["params"]["Q"]
+    o = oc.Oracle.from_params(params)                 # key regenerated from its seed
+    sk = o.private_key(d["sk_seed"])
+    bkey = o.bootstrap_key(sk, d["key_seed"])
+    assert hashlib.sha256(np.ascontiguousarray(bkey).tobytes()).hexdigest() == d["key_sha256"]
+    eng = S.Engine(params)
+    eng.upload_key(bkey)
+    for case in d["cases"]:
+        a1, b1 = np.array([case["lwe1"]["a"]], dtype=np.uint64), [case["lwe1"]["b"]]
+        a2, b2 = np.array([case["lwe2"]["a"]], dtype=np.uint64), [case["lwe2"]["b"]]
+        for k, (ha, hb) in case["acc_sha256_after"].items():
+            acc = eng.debug_accumulators(a1, b1, a2, b2, int(k))
+            assert h_ints(_u128_ints(acc[0, 0])) == ha, "acc_a after %s iterations" % k
+            assert h_ints(_u128_ints(acc[0, 1])) == hb, "acc_b after %s iterations" % k
+        raw = eng.bootstrap_batch(a1, b1, a2, b2, raw=True)
+        out = eng.bootstrap_batch(a1, b1, a2, b2)
+        for g in range(3):
+            assert h_ints(_u128_ints(raw[0, g])) == case["raw_sha256"][g]
+            if "out" in case:
+                assert [int(v) for v in out[0, g]] == case["out"][g]
+            else:
+                assert h_ints([int(v) for v in out[0, g]], 8) == case["out_sha256"][g]
+    eng.close()
+
+
+def test_external_product_golden(S):
+    d = json.load(open(os.path.join(G, "extprod.json")))
+    Q, B, m = int(d["Q"]), int(d["B"]), d["m"]
+    eng = S.Engine(S.Params.custom(d["n"], Q, B))
+
+    def u(vals):
+        a = np.zeros((len(vals), 2), dtype=np.uint64)
+        a[:, 0] = [v & 0xFFFFFFFFFFFFFFFF for v in vals]
+        a[:, 1] = [v >> 64 for v in vals]
+        return a
+    A = np.stack([np.stack([u(d["A"][r][c]) for c in range(2)]) for r in range(4)])
+    ra, rb = eng.external_product(u(d["a"]), u(d["b"]), A)
+    assert _u128_ints(ra) == d["a_res"] and _u128_ints(rb) == d["b_res"]
+    eng.close()
+
+
+# ---- edge cases of the boundary ---------------------------------------------------------------------
+
+@pytest.fixture(scope="module")
+def p64(S, oc):
+    params = S.Params(64)
+    o = oc.Oracle.from_params(params)
+    sk = o.private_key(1)
+    bkey = o.bootstrap_key(sk, 2)
+    eng = S.Engine(params)
+    eng.upload_key(bkey)
+    yield params, o, sk, bkey, eng
+    eng.close()
+
+
+def test_empty_single_and_ragged_batches(S, p64):
+    params, o, sk, bkey, eng = p64
+    n = params.n
+    empty = eng.bootstrap_batch(np.zeros((0, n), dtype=np.uint64), [], np.zeros((0, n), dtype=np.uint64), [])
+    assert empty.shape == (0, 3, n + 1)
+    bits = np.random.default_rng(1).integers(0, 2, size=2 * 21).astype(np.uint8)
+    a, b = o.lwe_encrypt_bits(sk, bits, 77)
+    a1, b1, a2, b2 = a[0::2], b[0::2], a[1::2], b[1::2]
+    ref = o.bootstrap_batch(bkey, a1, b1, a2, b2)
+    for batch in (1, 7, 8, 9, 21):                       # chunk padding is a multiple of 8
+        out = eng.bootstrap_batch(a1[:batch], b1[:batch], a2[:batch], b2[:batch])
+        assert np.array_equal(out, ref[:batch])
+    with pytest.raises(ValueError):
+        eng.bootstrap_batch(a1[:3], b1[:2], a2[:3], b2[:3])
+
+
+def test_chunk_size_independence_and_determinism(S, p64):
+    params, o, sk, bkey, eng = p64
+    bits = np.random.default_rng(2).integers(0, 2, size=2 * 40).astype(np.uint8)
+    a, b = o.lwe_encrypt_bits(sk, bits, 78)
+    a1, b1, a2, b2 = a[0::2], b[0::2], a[1::2], b[1::2]
+    base = eng.bootstrap_batch(a1, b1, a2, b2)
+    assert np.array_equal(base, eng.bootstrap_batch(a1, b1, a2, b2))      # manual.md:155-172
+    for chunk in (8, 16, 24):
+        eng.set_chunk(chunk)
+        assert np.array_equal(eng.bootstrap_batch(a1, b1, a2, b2), base)
+    eng.set_chunk(0)
+    assert np.array_equal(base, o.bootstrap_batch(bkey, a1, b1, a2, b2))
+
+
+def test_extreme_lwe_values(S, p64):
+    """Trivial LWEs (all-zero a: every x^j - 1 factor vanishes), maximal words r - 1, and the
+    trivial encryption of 1 used by pack_encrypted_bits (src/fhe.jl:669-673)."""
+    params, o, sk, bkey, eng = p64
+    n, r = params.n, params.r
+    a1 = np.zeros((4, n), dtype=np.uint64)
+    a2 = np.zeros((4, n), dtype=np.uint64)
+    b1 = np.array([0, params.Dr, r - 1, params.Dr], dtype=np.uint64)
+    b2 = np.array([0, 0, r - 1, params.Dr], dtype=np.uint64)
+    a1[2] = r - 1
+    a2[2] = r - 1
+    a2[3] = np.random.default_rng(3).integers(0, r, size=n, dtype=np.uint64)
+    assert np.array_equal(eng.bootstrap_batch(a1, b1, a2, b2), o.bootstrap_batch(bkey, a1, b1, a2, b2))
+    assert np.array_equal(eng.bootstrap_batch(a1, b1, a2, b2, raw=True),
+                          o.bootstrap_batch(bkey, a1, b1, a2, b2, raw=True))
+
+
+def test_no_key_and_bad_parameters_fail_loudly(S):
+    eng = S.Engine(S.Params(64))
+    z = np.zeros((1, 64), dtype=np.uint64)
+    with pytest.raises(S.SgfheError) as ei:
+        eng.bootstrap_batch(z, [0], z, [0])
+    assert ei.value.code == -5
+    with pytest.raises(ValueError):
+        eng.upload_key(np.zeros(10, dtype=np.uint64))
+    eng.close()
+    with pytest.raises(S.SgfheError):
+        S.Engine(S.Params.custom(8, 1 << 100, 1 << 61))       # Q >= 2^94
+
+
+def test_device_form_export_import(S, p64):
+    import torch
+    params, o, sk, bkey, eng = p64
+    nbytes = eng.key_device_form_bytes()
+    assert nbytes == params.n * 5 * 8 * params.m * 4
+    blob = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    eng.export_key_device_form(blob.data_ptr())
+    eng2 = S.Engine(params)
+    eng2.import_key_device_form(blob.data_ptr())
+    bits = np.array([1, 0, 1, 1], dtype=np.uint8)
+    a, b = o.lwe_encrypt_bits(sk, bits, 5)
+    assert np.array_equal(eng2.bootstrap_batch(a[0::2], b[0::2], a[1::2], b[1::2]),
+                          eng.bootstrap_batch(a[0::2], b[0::2], a[1::2], b[1::2]))
+    eng2.close()
+
+
+def test_rns2_key_upload_matches_canonical(S, oc):
+    """BASELINE.json config 4 boundary (src/rns.jl:16-18,32-40): a key held as RNS2Number limb
+    pairs over Q = B * Bp gives the same bootstrap as the same key in canonical form; the result
+    equals the oracle over the composite modulus."""
+    import bigint_oracle as BO
+    n, m = 16, 128
+    Bp = BO.find_modulus(2 * m, 1 << 24)
+    B = BO.find_modulus(2 * m, Bp + 1)                         # rule of src/fhe2.jl:57-58
+    Q = B * Bp
+    params = S.Params.custom(n, Q, B)
+    o = oc.Oracle.from_params(params)
+    assert not o.uses_ntt
+    sk = o.private_key(9)
+    bkey = o.bootstrap_key(sk, 10, noise=2)
+    vals = oc.u128_to_ints(bkey)
+    pairs = np.array([BO.rns2_from_int(v, B, Bp) for v in vals], dtype=np.uint64).reshape(bkey.shape)
+    e1 = S.Engine(params)
+    e1.upload_key(bkey)
+    e2 = S.Engine(params)
+    e2.upload_key_rns2(pairs, B, Bp)
+    bits = np.array([0, 1, 1, 1, 0, 0], dtype=np.uint8)
+    a, b = o.lwe_encrypt_bits(sk, bits, 11)
+    out1 = e1.bootstrap_batch(a[0::2], b[0::2], a[1::2], b[1::2])
+    out2 = e2.bootstrap_batch(a[0::2], b[0::2], a[1::2], b[1::2])
+    assert np.array_equal(out1, out2)
+    assert np.array_equal(out1, o.bootstrap_batch(bkey, a[0::2], b[0::2], a[1::2], b[1::2]))
+    e1.close()
+    e2.close()
+
+
+def test_batch_position_independence_params1024(S):
+    """Full-size ring, 600 bootstraps (more than one 256-chunk): identical inputs at different
+    batch positions / chunks give identical outputs, different inputs give different ones."""
+    import bench
+    params = S.Params(1024)
+    eng = S.Engine(params)
+    eng.upload_key(bench.random_key(params, 3))
+    rng = np.random.default_rng(4)
+    batch = 600
+    a1 = rng.integers(0, params.r, size=(batch, params.n), dtype=np.uint64)
+    a2 = rng.integers(0, params.r, size=(batch, params.n), dtype=np.uint64)
+    b1 = rng.integers(0, params.r, size=batch, dtype=np.uint64)
+    b2 = rng.integers(0, params.r, size=batch, dtype=np.uint64)
+    for dup in (255, 256, 511, 599):
+        a1[dup], a2[dup], b1[dup], b2[dup] = a1[0], a2[0], b1[0], b2[0]
+    out = eng.bootstrap_batch(a1, b1, a2, b2)
+    for dup in (255, 256, 511, 599):
+        assert np.array_equal(out[dup], out[0])
+    assert not np.array_equal(out[1], out[0])
+    single = eng.bootstrap_batch(a1[:1], b1[:1], a2[:1], b2[:1])
+    assert np.array_equal(single[0], out[0])
+    eng.close()

@@ -1,0 +1,110 @@
+"""Host-side mirror of the SGFHE.jl API (sgfhe.jl_amd/): parameters, ciphertext plumbing, and
+the C-ABI library's exported symbols.  No GPU compute."""
+
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import bigint_oracle as BO
+
+TABLE_P = {  # SURVEY.md section 8, Table P (derived from src/fhe.jl:43-97)
+    64: dict(r=1024, m=512, t=9, q=65537, Q=5494391545392009217, B=2348810240, Dr=256,
+             DQ_tilde=686798943174001152),
+    512: dict(r=8192, m=4096, t=12, q=4205569, Q=1440321777275241790332929, B=1202590842880,
+              Dr=2048, DQ_tilde=180040222159405223791616),
+    1024: dict(r=16384, m=8192, t=13, q=16801793, Q=92180593745615474572738561, B=9620726743040,
+               Dr=4096, DQ_tilde=11522574218201934321592320),
+}
+
+
+@pytest.mark.parametrize("n", [64, 512, 1024])
+def test_params_table(S, oc, n):
+    p = S.Params(n)
+    for k, v in TABLE_P[n].items():
+        assert getattr(p, k) == v, k
+    assert p.ell == 2 and p.Dq == p.q // 4
+    o = BO.Params.make(n)
+    assert (o.Q, o.q, o.B, o.DQ_tilde) == (p.Q, p.q, p.B, p.DQ_tilde)
+    d = oc.params_make(n)
+    assert (d["Q"], d["B"], d["DQ_tilde"], d["m"], d["r"]) == (p.Q, p.B, p.DQ_tilde, p.m, p.r)
+    assert S.isprime(p.Q) and (p.Q - 1) % (2 * p.m) == 0 and p.B * p.B >= p.Q
+
+
+def test_params_rejects_bad_n(S):
+    for n in (32, 96, 0):
+        with pytest.raises(AssertionError):
+            S.Params(n)
+    with pytest.raises(AssertionError):
+        S.Params.custom(8, 1 << 40, 1 << 10)      # B^2 < Q
+
+
+def test_find_modulus(S):
+    assert S.find_modulus(128, 1024 * 64) == 65537
+    with pytest.raises(ValueError):
+        S.find_modulus(1 << 20, 10, 20)
+
+
+def test_encrypt_split_decrypt_roundtrip(S):
+    """test/api.test.jl:33-42 (split_ciphertext + per-bit decrypt) and :8-17 style round trip."""
+    p = S.Params(64)
+    rng = np.random.default_rng(0)
+    sk = S.PrivateKey(p, rng)
+    msg = rng.integers(0, 2, size=p.n).astype(bool)
+    ct = S.encrypt(sk, rng, msg)
+    assert np.array_equal(S.decrypt(sk, ct), msg)
+    bits = S.split_ciphertext(ct)
+    assert len(bits) == p.n
+    assert [S.decrypt(sk, b) for b in bits] == list(msg)
+    with pytest.raises(AssertionError):
+        S.encrypt(sk, rng, msg[:-1])
+
+
+def test_extract_matches_reference_semantics(S):
+    """src/fhe.jl:237-244 against the oracle's literal restatement."""
+    Q = 1 << 10
+    a = list(range(1, 17))
+    for n in (4, 16):
+        for i in range(1, 17):
+            got = [int(v) % Q for v in S.extract(np.array(a, dtype=np.uint64), i, n)]
+            assert got == BO.extract(a, i, n, Q)
+
+
+def test_bootstrap_rejects_rng(S):
+    class Dummy:
+        params = S.Params(64)
+    eb = S.EncryptedBit(S.LWE(np.zeros(64, dtype=np.uint64), 0))
+    with pytest.raises(NotImplementedError):
+        S.bootstrap(Dummy(), np.random.default_rng(0), eb, eb)
+
+
+def test_library_exports_every_declared_symbol(S):
+    """The C-ABI library loads and exports exactly what include/sgfhe_hip.h declares."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = open(os.path.join(root, "include", "sgfhe_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(sgfhe_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(S.EXPORTED_SYMBOLS)
+    L = ctypes.CDLL(S.build())
+    for name in declared:
+        assert hasattr(L, name), name
+    assert b"gfx950" in S.lib().sgfhe_version()
+
+
+def test_ctx_create_argument_errors(S):
+    """Status codes without touching a device: NULL arguments."""
+    L = S.lib()
+    assert L.sgfhe_ctx_create(None, 0, None) == -1
+    assert L.sgfhe_bootstrap_batch(None, None, None, None, None, 0, None, 0) == -1
+    assert L.sgfhe_ctx_destroy(None) == 0
+
+
+def test_no_gpu_fails_loudly(S):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(S.SgfheError) as ei:
+        S.Engine(S.Params(64))
+    assert ei.value.code == -3
