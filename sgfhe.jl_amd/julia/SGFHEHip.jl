@@ -1,0 +1,113 @@
+# SGFHEHip.jl -- Julia-side binding of libsgfhe_hip.so (include/sgfhe_hip.h).
+#
+# Drop-in for the bootstrap path of nucypher/SGFHE.jl: `HipBootstrapKey(bkey)` uploads an
+# existing `SGFHE.BootstrapKey` to the GPU once; `SGFHE.bootstrap(hkey, nothing, bit1, bit2)`
+# then runs on the MI355X and returns the same three `EncryptedBit`s, bit for bit, as
+# `SGFHE.bootstrap(bkey, nothing, bit1, bit2)` (src/fhe.jl:608-621).  A vector method batches
+# independent gates into one call.
+#
+# NOT EXECUTED in the build container (no julia binary, no DarkIntegers.jl there); the Python
+# ctypes binding in ../engine.py exercises the identical C entry points in the tests.
+
+module SGFHEHip
+
+using SGFHE
+using SGFHE: Params, BootstrapKey, EncryptedBit, LWE
+using DarkIntegers
+using DarkIntegers: ModUInt, value, _verbatim
+
+const libsgfhe_hip = get(ENV, "SGFHE_HIP_LIB", "libsgfhe_hip.so")
+
+# struct sgfhe_params (include/sgfhe_hip.h)
+struct CParams
+    n::UInt64
+    r::UInt64
+    m::UInt64
+    ell::UInt64
+    Q::NTuple{2,UInt64}
+    B::NTuple{2,UInt64}
+    DQ_tilde::NTuple{2,UInt64}
+end
+
+words(x) = (UInt64(UInt128(x) & typemax(UInt64)), UInt64(UInt128(x) >> 64))
+
+function check(ctx::Ptr{Cvoid}, rc::Int32)
+    rc == 0 && return
+    msg = unsafe_string(ccall((:sgfhe_last_error_string, libsgfhe_hip), Cstring, (Ptr{Cvoid},), ctx))
+    error("sgfhe_hip error $rc: $msg")
+end
+
+mutable struct HipBootstrapKey
+    params::Params
+    ctx::Ptr{Cvoid}
+
+    function HipBootstrapKey(bkey::BootstrapKey; device::Integer=0)
+        p = bkey.params
+        cp = Ref(CParams(p.n, p.r, p.m, 2, words(p.Q), words(p.B), words(p.DQ_tilde)))
+        ctx = Ref{Ptr{Cvoid}}(C_NULL)
+        rc = ccall((:sgfhe_ctx_create, libsgfhe_hip), Int32,
+                   (Ref{CParams}, Cint, Ref{Ptr{Cvoid}}), cp, device, ctx)
+        check(ctx[], rc)
+        # value.(p.coeffs) of every polynomial, order [k][row][col][coef], 2 x UInt64 each
+        # (BootstrapKey.key is a Vector of 4x2 Matrix{Polynomial}, src/fhe.jl:176-201).
+        canon = Vector{UInt64}(undef, p.n * 8 * p.m * 2)
+        pos = 1
+        for k in 1:p.n, row in 1:4, col in 1:2
+            for c in bkey.key[k][row, col].coeffs
+                lo, hi = words(value(c))
+                canon[pos] = lo; canon[pos+1] = hi
+                pos += 2
+            end
+        end
+        rc = ccall((:sgfhe_bkey_upload, libsgfhe_hip), Int32,
+                   (Ptr{Cvoid}, Ptr{UInt64}, Csize_t), ctx[], canon, length(canon))
+        check(ctx[], rc)
+        key = new(p, ctx[])
+        finalizer(k -> ccall((:sgfhe_ctx_destroy, libsgfhe_hip), Int32, (Ptr{Cvoid},), k.ctx), key)
+        key
+    end
+end
+
+# Vector{ModUInt{UInt64, r}} is an isbits array: reinterpret is a zero-copy n x UInt64 view
+# (src/fhe.jl:206-209,272-274).
+lwe_words(bits::AbstractVector{EncryptedBit}, n) =
+    (reduce(vcat, [reinterpret(UInt64, b.lwe.a) for b in bits]),
+     UInt64[reinterpret(UInt64, [b.lwe.b])[1] for b in bits])
+
+"""
+    bootstrap(hkey, nothing, enc_bits1, enc_bits2)
+
+Batched deterministic gate bootstrap on the GPU; returns a vector of (AND, OR, XOR) triples.
+"""
+function SGFHE.bootstrap(hkey::HipBootstrapKey, rng::Nothing,
+                         bits1::AbstractVector{EncryptedBit}, bits2::AbstractVector{EncryptedBit})
+    p = hkey.params
+    n = p.n
+    batch = length(bits1)
+    @assert length(bits2) == batch
+    a1, b1 = lwe_words(bits1, n)
+    a2, b2 = lwe_words(bits2, n)
+    out = Vector{UInt64}(undef, batch * 3 * (n + 1))
+    rc = ccall((:sgfhe_bootstrap_batch, libsgfhe_hip), Int32,
+               (Ptr{Cvoid}, Ptr{UInt64}, Ptr{UInt64}, Ptr{UInt64}, Ptr{UInt64}, Csize_t,
+                Ptr{UInt64}, UInt32),
+               hkey.ctx, a1, b1, a2, b2, batch, out, 0)
+    check(hkey.ctx, rc)
+    tp = ModUInt{UInt64, UInt64(p.r)}
+    mk(x) = tp(x, _verbatim)                       # as at src/utils.jl:116
+    res = Vector{NTuple{3,EncryptedBit}}(undef, batch)
+    for t in 1:batch
+        base = (t - 1) * 3 * (n + 1)
+        res[t] = ntuple(3) do g
+            o = base + (g - 1) * (n + 1)
+            EncryptedBit(LWE(mk.(out[o+1:o+n]), mk(out[o+n+1])))
+        end
+    end
+    res
+end
+
+# The drop-in: same signature as src/fhe.jl:608-610, batch of one.
+SGFHE.bootstrap(hkey::HipBootstrapKey, rng::Nothing, bit1::EncryptedBit, bit2::EncryptedBit) =
+    SGFHE.bootstrap(hkey, nothing, [bit1], [bit2])[1]
+
+end # module
