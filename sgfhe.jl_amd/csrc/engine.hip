@@ -75,7 +75,7 @@ struct sgfhe_ctx {
     // device constants
     PrimeK *d_primes = nullptr;
     CrtConst *d_crt = nullptr;
-    uint2 *d_tw = nullptr;  // NPR * 2 * M entries
+    uint32_t *d_tw = nullptr;  // NPR * 2 * M entries
     CrtConst h_crt;
     // key
     uint32_t *d_key = nullptr;
@@ -83,7 +83,7 @@ struct sgfhe_ctx {
     bool have_key = false;
     // work buffers (sized for `cap` bootstraps)
     uint32_t chunk = 0, cap = 0;
-    ulonglong2 *d_dig = nullptr;
+    uint64_t *d_dig = nullptr;
     uint32_t *d_yres = nullptr;
     uint32_t *d_ua = nullptr;
     // timing
@@ -115,6 +115,7 @@ int32_t fail(sgfhe_ctx *ctx, int32_t code, const std::string &msg) {
 }
 
 size_t lds_bytes(int logm, int npoly) { return (size_t)npoly * ((size_t)4 << logm); }
+template <int LOGM> constexpr int threads_of() { return NttGeom<LOGM, LOGE>::T; }
 
 // ---- per-LOGM dispatch ------------------------------------------------------------------------
 
@@ -123,14 +124,14 @@ size_t lds_bytes(int logm, int npoly) { return (size_t)npoly * ((size_t)4 << log
 template <int LOGM>
 int32_t launch_extprod_t(sgfhe_ctx *c, const uint32_t *keyk, uint32_t cpad, uint32_t k,
                          uint32_t mode, hipStream_t st) {
-    const size_t lds = lds_bytes(LOGM, 4);
+    const size_t lds = lds_bytes(LOGM, 2);  // exchange buffer + z1 accumulator
     static bool attr_done[16] = {};
     if (!attr_done[c->device & 15]) {
         HIPCHK(c, hipFuncSetAttribute((const void *)k_extprod<LOGM>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_done[c->device & 15] = true;
     }
-    hipLaunchKernelGGL(k_extprod<LOGM>, dim3(cpad * NPR), dim3(NttGeom<LOGM>::T), lds, st, c->d_dig,
+    hipLaunchKernelGGL(k_extprod<LOGM>, dim3(cpad * NPR), dim3(threads_of<LOGM>()), lds, st, c->d_dig,
                        keyk, c->d_yres, c->d_ua, c->d_primes, k, c->n, mode);
     HIPCHK(c, hipGetLastError());
     return SGFHE_OK;
@@ -148,7 +149,7 @@ int32_t launch_extprod(sgfhe_ctx *c, const uint32_t *keyk, uint32_t cpad, uint32
 template <int LOGM>
 int32_t launch_keytr_t(sgfhe_ctx *c, const ulonglong2 *canon, uint32_t *keyhat, uint32_t poly0,
                        uint32_t npolys, hipStream_t st) {
-    hipLaunchKernelGGL(k_key_transform<LOGM>, dim3(npolys * NPR), dim3(NttGeom<LOGM>::T),
+    hipLaunchKernelGGL(k_key_transform<LOGM>, dim3(npolys * NPR), dim3(threads_of<LOGM>()),
                        lds_bytes(LOGM, 1), st, canon, keyhat, c->d_primes, c->d_crt, poly0);
     HIPCHK(c, hipGetLastError());
     return SGFHE_OK;
@@ -166,7 +167,7 @@ int32_t launch_keytr(sgfhe_ctx *c, const ulonglong2 *canon, uint32_t *keyhat, ui
 template <int LOGM>
 int32_t launch_dbgntt_t(sgfhe_ctx *c, const uint32_t *in, uint32_t *out, uint32_t pi, int inverse,
                         hipStream_t st) {
-    hipLaunchKernelGGL(k_debug_ntt<LOGM>, dim3(1), dim3(NttGeom<LOGM>::T), lds_bytes(LOGM, 1), st,
+    hipLaunchKernelGGL(k_debug_ntt<LOGM>, dim3(1), dim3(threads_of<LOGM>()), lds_bytes(LOGM, 1), st,
                        in, out, c->d_primes, pi, (uint32_t)inverse);
     HIPCHK(c, hipGetLastError());
     return SGFHE_OK;
@@ -215,7 +216,7 @@ int32_t ensure_work(sgfhe_ctx *c, uint32_t cpad) {
     if (c->d_yres) { (void)hipFree(c->d_yres); c->d_yres = nullptr; }
     if (c->d_ua) { (void)hipFree(c->d_ua); c->d_ua = nullptr; }
     c->cap = 0;
-    HIPCHK(c, hipMalloc(&c->d_dig, (size_t)cpad * 2 * c->M * sizeof(ulonglong2)));
+    HIPCHK(c, hipMalloc(&c->d_dig, (size_t)cpad * 4 * c->M * sizeof(uint64_t)));
     HIPCHK(c, hipMalloc(&c->d_yres, (size_t)cpad * 2 * NPR * c->M * 4));
     HIPCHK(c, hipMalloc(&c->d_ua, (size_t)cpad * c->n * 4));
     c->cap = cpad;
@@ -287,7 +288,7 @@ int32_t bootstrap_device(sgfhe_ctx *c, const uint64_t *a1, const uint64_t *b1, c
         if (acc_out) {
             const uint32_t t2 = cb * 2 * M;
             hipLaunchKernelGGL(k_dump_acc, dim3((t2 + 255) / 256), dim3(256), 0, st, c->d_dig,
-                               acc_out + c0 * 2 * M, c->d_crt, t2);
+                               acc_out + c0 * 2 * M, c->d_crt, t2, (uint32_t)c->logm);
             HIPCHK(c, hipGetLastError());
         }
         if (out) {
@@ -362,9 +363,9 @@ int32_t build_constants(sgfhe_ctx *c) {
     for (int a = 0; a <= NPR; a++) cc.T[a] = (Q - (((u128)a * cM) % Q + cH) % Q) % Q;
 
     // twiddle tables and per-prime constants
-    std::vector<uint2> tw((size_t)NPR * 2 * M);
+    std::vector<uint32_t> tw((size_t)NPR * 2 * M);
     std::vector<PrimeK> pk(NPR);
-    HIPCHK(c, hipMalloc(&c->d_tw, tw.size() * sizeof(uint2)));
+    HIPCHK(c, hipMalloc(&c->d_tw, tw.size() * sizeof(uint32_t)));
     for (int i = 0; i < NPR; i++) {
         const uint32_t p = c->primes[i];
         uint32_t psi = 0;
@@ -374,12 +375,13 @@ int32_t build_constants(sgfhe_ctx *c) {
         }
         if (!psi) return fail(c, SGFHE_ERR_UNSUPPORTED, "no primitive 2m-th root of unity");
         const uint32_t ipsi = powmod32(psi, p - 2, p);
-        uint2 *f = tw.data() + (size_t)(2 * i) * M, *v = f + M;
+        uint32_t *f = tw.data() + (size_t)(2 * i) * M, *v = f + M;
+        const uint32_t R1m = (uint32_t)((1ull << 32) % p);
         uint32_t pw = 1, ipw = 1;
         for (uint32_t t = 0; t < M; t++) {
             const uint32_t br = bitrev(t, logm);
-            f[br] = make_uint2(pw, (uint32_t)(((uint64_t)pw << 32) / p));
-            v[br] = make_uint2(ipw, (uint32_t)(((uint64_t)ipw << 32) / p));
+            f[br] = mulmod32(pw, R1m, p);   // Montgomery form
+            v[br] = mulmod32(ipw, R1m, p);
             pw = mulmod32(pw, psi, p);
             ipw = mulmod32(ipw, ipsi, p);
         }
@@ -409,7 +411,7 @@ int32_t build_constants(sgfhe_ctx *c) {
         P.twf = c->d_tw + (size_t)(2 * i) * M;
         P.twi = c->d_tw + (size_t)(2 * i + 1) * M;
     }
-    HIPCHK(c, hipMemcpy(c->d_tw, tw.data(), tw.size() * sizeof(uint2), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->d_tw, tw.data(), tw.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     HIPCHK(c, hipMalloc(&c->d_primes, NPR * sizeof(PrimeK)));
     HIPCHK(c, hipMemcpy(c->d_primes, pk.data(), NPR * sizeof(PrimeK), hipMemcpyHostToDevice));
     HIPCHK(c, hipMalloc(&c->d_crt, sizeof(CrtConst)));
@@ -688,13 +690,13 @@ int32_t sgfhe_external_product(sgfhe_ctx *c, const uint64_t *a, const uint64_t *
         if ((e = hipMemcpyAsync(d_ab, a, (size_t)M * 16, hipMemcpyHostToDevice, c->stream))) break;
         if ((e = hipMemcpyAsync(d_ab + M, b, (size_t)M * 16, hipMemcpyHostToDevice, c->stream))) break;
         hipLaunchKernelGGL(k_flatten_canon, dim3((2 * M + 255) / 256), dim3(256), 0, c->stream, d_ab,
-                           c->d_dig, c->d_crt, 2 * M);
+                           c->d_dig, c->d_crt, 2 * M, (uint32_t)c->logm);
         rc = launch_extprod(c, d_A, cpad, 0, MODE_PLAIN, c->stream);
         if (rc) break;
         rc = launch_crt(c, cpad, MODE_NOACC | MODE_CANON, c->stream);
         if (rc) break;
         if ((e = hipMemcpyAsync(a_res, c->d_dig, (size_t)M * 16, hipMemcpyDeviceToHost, c->stream))) break;
-        if ((e = hipMemcpyAsync(b_res, c->d_dig + M, (size_t)M * 16, hipMemcpyDeviceToHost, c->stream))) break;
+        if ((e = hipMemcpyAsync(b_res, c->d_dig + 2 * (size_t)M, (size_t)M * 16, hipMemcpyDeviceToHost, c->stream))) break;
         e = hipStreamSynchronize(c->stream);
     } while (0);
     if (e != hipSuccess && rc == SGFHE_OK) rc = fail(c, SGFHE_ERR_HIP, hipGetErrorString(e));

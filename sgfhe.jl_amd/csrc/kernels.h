@@ -20,7 +20,11 @@ namespace sgfhe {
 
 typedef unsigned __int128 u128;
 
-constexpr int NPR = 5;  // RNS primes (p_i < 2^30), product M ~ 2^150
+constexpr int NPR = 5;   // RNS primes (p_i < 2^30), product M ~ 2^150
+#ifndef SGFHE_LOGE
+#define SGFHE_LOGE 4
+#endif
+constexpr int LOGE = SGFHE_LOGE;  // points per thread (2^LOGE) in every NTT of the engine
 
 struct PrimeK {
     uint32_t p;       // prime
@@ -33,8 +37,8 @@ struct PrimeK {
     uint32_t minvR;   // m^-1 * R mod p (debug inverse NTT scaling)
     float invp;       // 1 / p
     uint32_t pad_;
-    const uint2 *twf;  // forward twiddles (w, floor(w 2^32 / p)), bit-reversed psi powers
-    const uint2 *twi;  // inverse twiddles
+    const uint32_t *twf;  // forward twiddles psi^bitrev(i) * R mod p (Montgomery form)
+    const uint32_t *twi;  // inverse twiddles psi^-bitrev(i) * R mod p
 };
 
 // The NPR PrimeK records live in device memory and are indexed by the (wave-uniform) prime
@@ -91,23 +95,44 @@ __device__ __forceinline__ uint32_t digit_reduce(uint64_t e, const PrimeK &P) {
     return min(t, t + P.p);
 }
 
+// ---- digit planes ---------------------------------------------------------------------------------
+// dig[bootstrap][c][digit][coef] (uint64): digit 0 = lo, digit 1 = hi of x' for acc_a (c = 0) and
+// acc_b (c = 1).  Plane p = 2 c + digit is the p-th row of u = [a_lo, a_hi, b_lo, b_hi]
+// (fhe.jl:524-526) and multiplies key row p.
+__device__ __forceinline__ ulonglong2 load_digits(const uint64_t *__restrict__ dig, size_t bc,
+                                                  uint32_t i, uint32_t M) {
+    return make_ulonglong2(dig[(bc * 2 + 0) * M + i], dig[(bc * 2 + 1) * M + i]);
+}
+__device__ __forceinline__ void store_digits(uint64_t *__restrict__ dig, size_t bc, uint32_t i,
+                                             uint32_t M, uint64_t lo, uint64_t hi) {
+    dig[(bc * 2 + 0) * M + i] = lo;
+    dig[(bc * 2 + 1) * M + i] = hi;
+}
+
 // ---- k_extprod ----------------------------------------------------------------------------------
-// grid = chunk * NPR workgroups of T = m / 8 threads; chunk is a multiple of 8.  Workgroups are
+// grid = chunk * NPR workgroups of T = m / 16 threads; chunk is a multiple of 8.  Workgroups are
 // dealt round-robin to the 8 XCDs (blocks g and g + 8 share an XCD, MI355X_MICROARCH.md), so
 // the NPR prime-workgroups of one bootstrap are given the same g mod 8: they re-read the same
-// digits and hit in that XCD's L2.
-//   dig    [chunk][2][m]        (lo, hi) digits of x' for acc_a (c = 0) and acc_b (c = 1)
+// digits and hit in that XCD's L2.  At m = 8192 a workgroup is 512 threads, at most 128 VGPRs and
+// 64 KiB of LDS (32 KiB NTT exchange buffer + 32 KiB thread-private accumulator of the second
+// product polynomial): two workgroups share a CU, so one computes butterflies while the other
+// sits in an LDS exchange, a barrier or a load.
+//   dig    [chunk][2][2][m]     digit planes (see above)
 //   keyk   [NPR][4][2][m]       NTT-domain key slice of iteration k (slot order, scaled by kappa)
 //   yres   [chunk][2][NPR][m]   output residues y_i = (M/p_i)^-1 * D mod p_i (+ hoff)
 //   ua     [chunk][n]           j = u.a[k] of every bootstrap (fhe.jl:566,580)
+// The four digit polynomials u = [a_lo, a_hi, b_lo, b_hi] (fhe.jl:524-526) go through the forward
+// NTT one at a time (phase = key row); the two product polynomials through the inverse NTT one at
+// a time.  The running NTT-domain sum z_0 lives in registers, z_1 in LDS.
 template <int LOGM>
-__global__ void __launch_bounds__(NttGeom<LOGM>::T)
-k_extprod(const ulonglong2 *__restrict__ dig, const uint32_t *__restrict__ keyk,
+__global__ void __launch_bounds__((NttGeom<LOGM, LOGE>::T), (NttGeom<LOGM, LOGE>::T >= 256 ? 4 : 1))
+k_extprod(const uint64_t *__restrict__ dig, const uint32_t *__restrict__ keyk,
           uint32_t *__restrict__ yres, const uint32_t *__restrict__ ua, PrimeSet PS, uint32_t k,
           uint32_t n, uint32_t mode) {
-    using G = NttGeom<LOGM>;
-    constexpr int M = G::M, T = G::T;
+    using G = NttGeom<LOGM, LOGE>;
+    constexpr int M = G::M, T = G::T, E = G::E;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    uint32_t *const z1 = lds + M + threadIdx.x;  // z1[e * T]: private to the thread, conflict-free
 
     const int tid = threadIdx.x;
     const uint32_t g = blockIdx.x;
@@ -116,85 +141,90 @@ k_extprod(const ulonglong2 *__restrict__ dig, const uint32_t *__restrict__ keyk,
     const uint32_t pi = slot % NPR;
     const PrimeK P = PS[pi];
     const uint32_t p = P.p;
+    const Mod md = {P.p, P.ninv, 2 * P.p};
 
-    // 1. digits -> residues (flatten_poly, utils.jl:253-264, lifted to signed integers)
-    uint32_t x[4][8];
-    {
-        const ulonglong2 *da = dig + ((size_t)b * 2 + 0) * M;
-        const ulonglong2 *db = dig + ((size_t)b * 2 + 1) * M;
+    uint32_t z0[1][E];
 #pragma unroll
-        for (int e = 0; e < 8; e++) {
-            const ulonglong2 va = da[tid + T * e];
-            const ulonglong2 vb = db[tid + T * e];
-            x[0][e] = digit_reduce(va.x, P);
-            x[1][e] = digit_reduce(va.y, P);
-            x[2][e] = digit_reduce(vb.x, P);
-            x[3][e] = digit_reduce(vb.y, P);
-        }
-    }
+    for (int e = 0; e < E; e++) { z0[0][e] = 0; z1[e * T] = 0; }
+    // A real loop (not unrolled): one copy of the forward NTT in the instruction stream, and the
+    // loads of a later phase cannot be hoisted over the registers of an earlier one.
+#pragma unroll 1
+    for (int ph = 0; ph < 4; ph++) {
+        // The thread index is made opaque per iteration: otherwise the ~60 loop-invariant LDS /
+        // twiddle addresses derived from it are hoisted out of the loop and spilled.
+        const int tid = (int)threadIdx.x + (int)opaque_zero();
+        // 1. digits -> residues (flatten_poly, utils.jl:253-264, lifted to signed integers)
+        uint32_t x[1][E];
+        const uint64_t *d = dig + ((size_t)b * 4 + ph) * M;
+#pragma unroll
+        for (int e = 0; e < E; e++)
+#ifdef SGFHE_ABL_NO_DIG
+            x[0][e] = digit_reduce((uint64_t)(tid + e) * 0x9E3779B97F4Aull, P);  // timing-only build
+#else
+            x[0][e] = digit_reduce(d[tid + T * e], P);
+#endif
+        // the exchange buffer is reused: every wave must have finished the previous phase's loads
+        SGFHE_SYNC();
 
-    // 2. four forward NTTs (u = [a_lo, a_hi, b_lo, b_hi], fhe.jl:524-526)
-    ntt_forward<LOGM, 4>(x, lds, P.twf, tid, p);
+        // 2. forward NTT of u[ph]
+        ntt_forward<LOGM, 1, LOGE>(x, lds, P.twf, tid, md);
 
-    // 3. pointwise: z_c = sum_row U_row * K[row][c]   (fhe.jl:527-528 in the NTT domain)
-    uint32_t z[2][8];
-    {
-        uint64_t acc0[8], acc1[8];
+        // 3. pointwise: z_c += U * K[ph][c]   (fhe.jl:527-528 in the NTT domain)
+        //    U in [0, 4p), K < p: the product is < p 2^32
+        const uint32_t *kp = keyk + ((size_t)pi * 8 + ph * 2) * M + E * tid;
 #pragma unroll
-        for (int e = 0; e < 8; e++) { acc0[e] = 0; acc1[e] = 0; }
-        const uint32_t *kp = keyk + (size_t)pi * 8 * M + 8 * tid;
+        for (int h = 0; h < E / 4; h++) {
+#ifdef SGFHE_ABL_NO_KEY
+            const uint4 a = make_uint4(tid, h, ph, 7u), bq = make_uint4(h, tid, 5u, ph);  // timing-only
+#else
+            const uint4 a = reinterpret_cast<const uint4 *>(kp)[h];
+            const uint4 bq = reinterpret_cast<const uint4 *>(kp + M)[h];
+#endif
+            const uint32_t ka[4] = {a.x, a.y, a.z, a.w};
+            const uint32_t kb[4] = {bq.x, bq.y, bq.z, bq.w};
 #pragma unroll
-        for (int row = 0; row < 4; row++) {
-            const uint4 *k0 = reinterpret_cast<const uint4 *>(kp + (size_t)(row * 2 + 0) * M);
-            const uint4 *k1 = reinterpret_cast<const uint4 *>(kp + (size_t)(row * 2 + 1) * M);
-            const uint4 a0 = k0[0], a1 = k0[1], b0 = k1[0], b1 = k1[1];
-            const uint32_t kk0[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-            const uint32_t kk1[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
-#pragma unroll
-            for (int e = 0; e < 8; e++) {
-                uint32_t u = x[row][e];
-                u = min(u, u - 2 * p);
-                u = csub(u, p);  // [0, p): 4 products < 4 p^2 < p 2^32
-                acc0[e] += (uint64_t)u * kk0[e];
-                acc1[e] += (uint64_t)u * kk1[e];
+            for (int t = 0; t < 4; t++) {
+                const int e = 4 * h + t;
+                const uint32_t s0 = z0[0][e] + redc64((uint64_t)x[0][e] * ka[t], p, P.ninv);
+                z0[0][e] = min(s0, s0 - md.p2);  // [0, 2p)
+                const uint32_t r1 = redc64((uint64_t)x[0][e] * kb[t], p, P.ninv);
+                uint32_t *zp = lds + M + e * T + tid;
+                const uint32_t s1 = *zp + r1;
+                *zp = min(s1, s1 - md.p2);
             }
         }
-#pragma unroll
-        for (int e = 0; e < 8; e++) {
-            z[0][e] = redc64(acc0[e], p, P.ninv);  // [0, 2p)
-            z[1][e] = redc64(acc1[e], p, P.ninv);
-        }
     }
 
-    // 4. two inverse NTTs -> P_c = (M/p)^-1 * sum_row u_row (*) C_row[c]  mod p
-    ntt_inverse<LOGM, 2>(z, lds, P.twi, tid, p);
-#pragma unroll
-    for (int c = 0; c < 2; c++)
-#pragma unroll
-        for (int e = 0; e < 8; e++) z[c][e] = csub(z[c][e], p);
-
-    // 5. y = x^j P - P  (mul_by_xj_minus_one, fhe.jl:554-556, applied to the product)
     uint32_t *yb = yres + ((size_t)b * 2 * NPR + pi) * M;
-    if (mode & MODE_PLAIN) {
-#pragma unroll
-        for (int c = 0; c < 2; c++)
-#pragma unroll
-            for (int e = 0; e < 8; e++)
-                yb[(size_t)c * NPR * M + tid + T * e] = csub(z[c][e] + P.hoff, p);
-        return;
-    }
-    const uint32_t j = ua[(size_t)b * n + k];
-    lds_store<LOGM, 2, G::STOP>(z, lds, tid);
-    __syncthreads();
+    const uint32_t j = (mode & MODE_PLAIN) ? 0u : ua[(size_t)b * n + k];
 #pragma unroll
     for (int c = 0; c < 2; c++) {
+        // 4. inverse NTT -> P_c = (M/p)^-1 * sum_row u_row (*) C_row[c]  mod p
+        if (c > 0) {
 #pragma unroll
-        for (int e = 0; e < 8; e++) {
+            for (int e = 0; e < E; e++) z0[0][e] = z1[e * T];
+            SGFHE_SYNC();  // rotated reads of c = 0 are done before the buffer is rewritten
+        }
+        ntt_inverse<LOGM, 1, LOGE>(z0, lds, P.twi, tid, md);
+#pragma unroll
+        for (int e = 0; e < E; e++) z0[0][e] = csub(z0[0][e], p);
+
+        // 5. y = x^j P - P  (mul_by_xj_minus_one, fhe.jl:554-556, applied to the product)
+        if (mode & MODE_PLAIN) {
+#pragma unroll
+            for (int e = 0; e < E; e++)
+                yb[(size_t)c * NPR * M + tid + T * e] = csub(z0[0][e] + P.hoff, p);
+            continue;
+        }
+        lds_store<LOGM, 1, LOGE, G::STOP>(z0, lds, tid);
+        SGFHE_SYNC();
+#pragma unroll
+        for (int e = 0; e < E; e++) {
             const uint32_t i = tid + T * e;
             const uint32_t s = (i - j) & (2 * M - 1);
-            uint32_t v = lds[c * M + swz(s & (M - 1))];
+            uint32_t v = lds[swz<LOGE>(s & (M - 1))];
             if (s & M) v = csub(p - v, p);  // x^m = -1
-            uint32_t y = v - z[c][e];
+            uint32_t y = v - z0[0][e];
             y = min(y, y + p);
             yb[(size_t)c * NPR * M + i] = csub(y + P.hoff, p);
         }
@@ -208,7 +238,7 @@ k_extprod(const ulonglong2 *__restrict__ dig, const uint32_t *__restrict__ keyk,
 // 0.5 +- 0.125, so alpha is exact in float.  Then x'_new = (x'_old + D) mod Q and the new
 // digits are (x'_new mod B, x'_new / B)  (flatten, utils.jl:155-189).
 __global__ void __launch_bounds__(256)
-k_crt_acc(const uint32_t *__restrict__ yres, ulonglong2 *__restrict__ dig,
+k_crt_acc(const uint32_t *__restrict__ yres, uint64_t *__restrict__ dig,
           const CrtConst *__restrict__ CC, uint32_t total, uint32_t logm, uint32_t mode) {
     const uint32_t t = blockIdx.x * 256 + threadIdx.x;
     if (t >= total) return;
@@ -229,17 +259,17 @@ k_crt_acc(const uint32_t *__restrict__ yres, ulonglong2 *__restrict__ dig,
     for (int q = 0; q < NPR; q++) S += mul_u64_u128(y[q], CC->c[q]);
     const u128 B = CC->B;
     if (!(mode & MODE_NOACC)) {
-        const ulonglong2 d = dig[t];
+        const ulonglong2 d = load_digits(dig, bc, i, M);
         S += (u128)d.y * (uint64_t)B + d.x;
     }
     const u128 xn = mod_wide(S, CC->Q, CC->invQ, nullptr);
-    if (mode & MODE_CANON) {
-        dig[t] = make_ulonglong2((uint64_t)xn, (uint64_t)(xn >> 64));
+    if (mode & MODE_CANON) {  // canonical residues, interleaved {lo, hi} words
+        reinterpret_cast<ulonglong2 *>(dig)[t] = make_ulonglong2((uint64_t)xn, (uint64_t)(xn >> 64));
         return;
     }
     uint64_t hi;
     const u128 lo = mod_wide(xn, B, CC->invB, &hi);
-    dig[t] = make_ulonglong2((uint64_t)lo, hi);
+    store_digits(dig, bc, i, M, (uint64_t)lo, hi);
 }
 
 // ---- k_init -------------------------------------------------------------------------------------
@@ -250,7 +280,7 @@ k_crt_acc(const uint32_t *__restrict__ yres, ulonglong2 *__restrict__ dig,
 __global__ void __launch_bounds__(256)
 k_init(const uint64_t *__restrict__ a1, const uint64_t *__restrict__ b1,
        const uint64_t *__restrict__ a2, const uint64_t *__restrict__ b2,
-       ulonglong2 *__restrict__ dig, uint32_t *__restrict__ ua, const CrtConst *__restrict__ CC,
+       uint64_t *__restrict__ dig, uint32_t *__restrict__ ua, const CrtConst *__restrict__ CC,
        uint32_t nvalid, uint32_t chunk, uint32_t n, uint32_t logm) {
     const uint32_t t = blockIdx.x * 256 + threadIdx.x;
     const uint32_t M = 1u << logm;
@@ -261,7 +291,7 @@ k_init(const uint64_t *__restrict__ a1, const uint64_t *__restrict__ b1,
     const bool valid = b < nvalid;
     if (i < n) ua[(size_t)b * n + i] =
         valid ? (uint32_t)((a1[(size_t)b * n + i] + a2[(size_t)b * n + i]) & rmask) : 0u;
-    dig[((size_t)b * 2 + 0) * M + i] = CC->dig0;
+    store_digits(dig, (size_t)b * 2 + 0, i, M, CC->dig0.x, CC->dig0.y);
     ulonglong2 d = CC->dig0;
     if (valid) {
         const uint32_t ub = (uint32_t)((b1[b] + b2[b]) & rmask);
@@ -272,7 +302,7 @@ k_init(const uint64_t *__restrict__ a1, const uint64_t *__restrict__ b1,
         if (src & M) tv = -tv;
         d = tv > 0 ? CC->digP : (tv < 0 ? CC->digN : CC->dig0);
     }
-    dig[((size_t)b * 2 + 1) * M + i] = d;
+    store_digits(dig, (size_t)b * 2 + 1, i, M, d.x, d.y);
 }
 
 // ---- k_final ------------------------------------------------------------------------------------
@@ -294,24 +324,23 @@ __device__ __forceinline__ uint64_t modred(u128 x, const CrtConst *CC) {
     return q;
 }
 __global__ void __launch_bounds__(256)
-k_final(const ulonglong2 *__restrict__ dig, uint64_t *__restrict__ out,
+k_final(const uint64_t *__restrict__ dig, uint64_t *__restrict__ out,
         const CrtConst *__restrict__ CC, uint32_t nvalid, uint32_t n, uint32_t logm, uint32_t raw) {
     const uint32_t t = blockIdx.x * 256 + threadIdx.x;
     if (t >= nvalid * (n + 1)) return;
     const uint32_t M = 1u << logm;
     const uint32_t b = t / (n + 1), e = t % (n + 1);
-    const ulonglong2 *da = dig + ((size_t)b * 2 + 0) * M;
-    const ulonglong2 *db = dig + ((size_t)b * 2 + 1) * M;
+    const size_t ba = (size_t)b * 2 + 0, bb = (size_t)b * 2 + 1;
     const u128 Q = CC->Q;
     u128 va, vo;
     if (e < n) {
-        va = acc_from_digits(da[3 * M / 4 - e], CC);
-        const u128 w = acc_from_digits(da[M / 4 - e], CC);
+        va = acc_from_digits(load_digits(dig, ba, 3 * M / 4 - e, M), CC);
+        const u128 w = acc_from_digits(load_digits(dig, ba, M / 4 - e, M), CC);
         vo = w ? Q - w : 0;
     } else {
-        va = CC->DQ + acc_from_digits(db[3 * M / 4], CC);
+        va = CC->DQ + acc_from_digits(load_digits(dig, bb, 3 * M / 4, M), CC);
         if (va >= Q) va -= Q;
-        const u128 w = acc_from_digits(db[M / 4], CC);
+        const u128 w = acc_from_digits(load_digits(dig, bb, M / 4, M), CC);
         vo = CC->DQ >= w ? CC->DQ - w : CC->DQ + Q - w;
     }
     const u128 vx = vo >= va ? vo - va : vo + Q - va;
@@ -331,27 +360,29 @@ k_final(const ulonglong2 *__restrict__ dig, uint64_t *__restrict__ out,
 
 // digits -> canonical accumulators (debug hook)
 __global__ void __launch_bounds__(256)
-k_dump_acc(const ulonglong2 *__restrict__ dig, ulonglong2 *__restrict__ out,
-           const CrtConst *__restrict__ CC, uint32_t total) {
+k_dump_acc(const uint64_t *__restrict__ dig, ulonglong2 *__restrict__ out,
+           const CrtConst *__restrict__ CC, uint32_t total, uint32_t logm) {
     const uint32_t t = blockIdx.x * 256 + threadIdx.x;
     if (t >= total) return;
-    const u128 x = acc_from_digits(dig[t], CC);
+    const uint32_t M = 1u << logm;
+    const u128 x = acc_from_digits(load_digits(dig, t >> logm, t & (M - 1), M), CC);
     out[t] = make_ulonglong2((uint64_t)x, (uint64_t)(x >> 64));
 }
 
 // canonical residues -> digits of x' = (v + off) mod Q  (flatten, utils.jl:155-189)
 __global__ void __launch_bounds__(256)
-k_flatten_canon(const ulonglong2 *__restrict__ in, ulonglong2 *__restrict__ dig,
-                const CrtConst *__restrict__ CC, uint32_t total) {
+k_flatten_canon(const ulonglong2 *__restrict__ in, uint64_t *__restrict__ dig,
+                const CrtConst *__restrict__ CC, uint32_t total, uint32_t logm) {
     const uint32_t t = blockIdx.x * 256 + threadIdx.x;
     if (t >= total) return;
+    const uint32_t M = 1u << logm;
     const ulonglong2 v = in[t];
     u128 x = (((u128)v.y << 64) | v.x) + (CC->Q - CC->offneg);
     if (x >= CC->Q) x -= CC->Q;
     if (x >= CC->Q) x -= CC->Q;
     uint64_t hi;
     const u128 lo = mod_wide(x, CC->B, CC->invB, &hi);
-    dig[t] = make_ulonglong2((uint64_t)lo, hi);
+    store_digits(dig, t >> logm, t & (M - 1), M, (uint64_t)lo, hi);
 }
 
 // ---- k_key_transform ------------------------------------------------------------------------------
@@ -360,21 +391,22 @@ k_flatten_canon(const ulonglong2 *__restrict__ in, ulonglong2 *__restrict__ dig,
 //   canon  [npolys][m] 16-byte residues (polys in [k][row][col] order)
 //   keyhat [k][NPR][row*2+col][m]
 template <int LOGM>
-__global__ void __launch_bounds__(NttGeom<LOGM>::T)
+__global__ void __launch_bounds__((NttGeom<LOGM, LOGE>::T))
 k_key_transform(const ulonglong2 *__restrict__ canon, uint32_t *__restrict__ keyhat, PrimeSet PS,
                 const CrtConst *__restrict__ CC, uint32_t poly0) {
-    using G = NttGeom<LOGM>;
-    constexpr int M = G::M, T = G::T;
+    using G = NttGeom<LOGM, LOGE>;
+    constexpr int M = G::M, T = G::T, E = G::E;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const int tid = threadIdx.x;
     const uint32_t pl = blockIdx.x / NPR;  // polynomial within this staging batch
     const uint32_t pi = blockIdx.x % NPR;
     const PrimeK P = PS[pi];
     const uint32_t p = P.p;
+    const Mod md = {P.p, P.ninv, 2 * P.p};
     const u128 halfQ = CC->halfQ;
-    uint32_t x[1][8];
+    uint32_t x[1][E];
 #pragma unroll
-    for (int e = 0; e < 8; e++) {
+    for (int e = 0; e < E; e++) {
         const ulonglong2 v = canon[(size_t)pl * M + tid + T * e];
         const uint32_t c0 = (uint32_t)v.x, c1 = (uint32_t)(v.x >> 32), c2 = (uint32_t)v.y;
         uint32_t r = csub(mont_mul(c0, P.r1, p, P.ninv) + mont_mul(c1, P.r2, p, P.ninv), p);
@@ -383,48 +415,49 @@ k_key_transform(const ulonglong2 *__restrict__ canon, uint32_t *__restrict__ key
         if (C > halfQ) { r = r - P.qmodp; r = min(r, r + p); }
         x[0][e] = mont_mul(r, P.kappaR, p, P.ninv);
     }
-    ntt_forward<LOGM, 1>(x, lds, P.twf, tid, p);
+    ntt_forward<LOGM, 1, LOGE>(x, lds, P.twf, tid, md);
     const uint32_t pg = poly0 + pl;  // global polynomial index = k * 8 + row * 2 + col
-    uint32_t *dst = keyhat + (((size_t)(pg >> 3) * NPR + pi) * 8 + (pg & 7)) * M + 8 * tid;
-    uint32_t o[8];
+    uint32_t *dst = keyhat + (((size_t)(pg >> 3) * NPR + pi) * 8 + (pg & 7)) * M + E * tid;
 #pragma unroll
-    for (int e = 0; e < 8; e++) {
-        uint32_t u = x[0][e];
-        u = min(u, u - 2 * p);
-        o[e] = csub(u, p);
+    for (int h = 0; h < E / 4; h++) {
+        uint32_t o[4];
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const uint32_t u = min(x[0][4 * h + t], x[0][4 * h + t] - md.p2);
+            o[t] = csub(u, p);
+        }
+        reinterpret_cast<uint4 *>(dst)[h] = make_uint4(o[0], o[1], o[2], o[3]);
     }
-    reinterpret_cast<uint4 *>(dst)[0] = make_uint4(o[0], o[1], o[2], o[3]);
-    reinterpret_cast<uint4 *>(dst)[1] = make_uint4(o[4], o[5], o[6], o[7]);
 }
 
 // ---- k_debug_ntt ----------------------------------------------------------------------------------
 template <int LOGM>
-__global__ void __launch_bounds__(NttGeom<LOGM>::T)
+__global__ void __launch_bounds__((NttGeom<LOGM, LOGE>::T))
 k_debug_ntt(const uint32_t *__restrict__ in, uint32_t *__restrict__ out, PrimeSet PS, uint32_t pi,
             uint32_t inverse) {
-    using G = NttGeom<LOGM>;
-    constexpr int T = G::T;
+    using G = NttGeom<LOGM, LOGE>;
+    constexpr int T = G::T, E = G::E;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const int tid = threadIdx.x;
     const PrimeK P = PS[pi];
     const uint32_t p = P.p;
-    uint32_t x[1][8];
+    const Mod md = {P.p, P.ninv, 2 * P.p};
+    uint32_t x[1][E];
     if (!inverse) {
 #pragma unroll
-        for (int e = 0; e < 8; e++) x[0][e] = in[tid + T * e];
-        ntt_forward<LOGM, 1>(x, lds, P.twf, tid, p);
+        for (int e = 0; e < E; e++) x[0][e] = in[tid + T * e];
+        ntt_forward<LOGM, 1, LOGE>(x, lds, P.twf, tid, md);
 #pragma unroll
-        for (int e = 0; e < 8; e++) {
-            uint32_t u = x[0][e];
-            u = min(u, u - 2 * p);
-            out[8 * tid + e] = csub(u, p);
+        for (int e = 0; e < E; e++) {
+            const uint32_t u = min(x[0][e], x[0][e] - md.p2);
+            out[E * tid + e] = csub(u, p);
         }
     } else {
 #pragma unroll
-        for (int e = 0; e < 8; e++) x[0][e] = in[8 * tid + e];
-        ntt_inverse<LOGM, 1>(x, lds, P.twi, tid, p);
+        for (int e = 0; e < E; e++) x[0][e] = in[E * tid + e];
+        ntt_inverse<LOGM, 1, LOGE>(x, lds, P.twi, tid, md);
 #pragma unroll
-        for (int e = 0; e < 8; e++)
+        for (int e = 0; e < E; e++)
             out[tid + T * e] = mont_mul(csub(x[0][e], p), P.minvR, p, P.ninv);
     }
 }

@@ -1,229 +1,250 @@
 // LDS-staged negacyclic NTT of length m = 2^LOGM over one 30-bit RNS prime, NP polynomials at
 // once (same twiddles, NP-fold instruction-level parallelism).
 //
-// Geometry: a workgroup of T = m / 8 threads; every thread keeps 8 points of each polynomial in
-// registers and performs radix-8 passes (three butterfly stages per pass) on them.  Between
-// passes the points are exchanged through LDS.  A pass over index bits [S, S+3) gives thread
-// (hi, lo) = (tid >> S, tid & (2^S - 1)) the points  idx(e) = hi << (S+3) | e << S | lo.
-// When LOGM is not a multiple of 3 the top LOGM % 3 bits are handled by a partial pass in the
-// (hi = 0) layout S = LOGM - 3, which is also the coalesced global-memory layout
+// Geometry: a workgroup of T = m / E threads, E = 2^LOGE (8 or 16); every thread keeps E points
+// of each polynomial in registers and performs radix-E passes (LOGE butterfly stages per pass)
+// on them.  Between passes the points are exchanged through LDS.  A pass over index bits
+// [S, S+LOGE) gives thread (hi, lo) = (tid >> S, tid & (2^S - 1)) the points
+//     idx(e) = hi << (S+LOGE) | e << S | lo.
+// When LOGM is not a multiple of LOGE the top LOGM % LOGE bits are handled by a partial pass in
+// the (hi = 0) layout S = LOGM - LOGE, which is also the coalesced global-memory layout
 // idx(e) = tid + T * e.
 //
 // Forward: Cooley-Tukey with the psi twist merged into the twiddles (natural order in, slot
-// order = bit-reversed evaluation order out); on exit thread tid holds slots 8 tid .. 8 tid + 7.
+// order = bit-reversed evaluation order out); on exit thread tid holds slots E tid .. E tid + E-1.
 // Inverse: Gentleman-Sande, slot order in (same ownership), natural order out in the
 // idx(e) = tid + T * e layout, not scaled by 1/m (the scale is folded into the key).
 //
-// LDS addressing: word address = poly * m + swz(idx), where swz XORs the five bank bits with
-// index bits 5..7 such that the b32 accesses of every pass (S = 0, 3, 6, 9 and S >= 5 in
-// general) are bank-conflict free within each 32-lane group:
-//   bank bits (b0..b4) = (a0^a6, a1^a7, a2^a5, a3^a6, a4^a7).
+// Twiddles: tw[i] = psi^(+-bitrev(i)) * 2^32 mod p (Montgomery form), i in [1, m).  Stage
+// "local bit b" of a pass over [S, S+LOGE) uses the 2^(LOGE-1-b) consecutive entries starting at
+// 2^(LOGM-1-S-b) + (hi << (LOGE-1-b)).
+//
+// LDS addressing: word address = poly * m + swz(idx); swz XORs the five bank bits with higher
+// index bits such that the b32 accesses of every pass are bank-conflict free within each
+// 32-lane group (checked exhaustively in tests/test_rns_model.py):
+//   E = 8 :  (b0..b4) ^= (a6, a7, a5, a6, a7)
+//   E = 16:  (b0..b4) ^= (a5, a6, a7, a8, a8)
 #pragma once
 
 #include "rns_arith.h"
 
+#ifdef SGFHE_ABL_NO_BARRIER
+#define SGFHE_SYNC() ((void)0)  // timing-only build
+#else
+#define SGFHE_SYNC() __syncthreads()
+#endif
+
 namespace sgfhe {
 
+template <int LOGE>
 __host__ __device__ constexpr uint32_t swz_bits(uint32_t idx) {
-    return (((idx >> 6) & 1u) * 0x09u) ^ (((idx >> 7) & 1u) * 0x12u) ^ (((idx >> 5) & 1u) * 0x04u);
+    if constexpr (LOGE == 3)
+        return (((idx >> 6) & 1u) * 0x09u) ^ (((idx >> 7) & 1u) * 0x12u) ^ (((idx >> 5) & 1u) * 0x04u);
+    else
+        return (((idx >> 5) & 1u) * 0x01u) ^ (((idx >> 6) & 1u) * 0x02u) ^
+               (((idx >> 7) & 1u) * 0x04u) ^ (((idx >> 8) & 1u) * 0x18u);
 }
-__host__ __device__ constexpr uint32_t swz(uint32_t idx) { return idx ^ swz_bits(idx); }
+template <int LOGE>
+__host__ __device__ constexpr uint32_t swz(uint32_t idx) { return idx ^ swz_bits<LOGE>(idx); }
 
-template <int LOGM>
+template <int LOGM, int LOGE>
 struct NttGeom {
     static constexpr int M = 1 << LOGM;
-    static constexpr int T = M / 8;
-    static constexpr int RHO = LOGM % 3;
-    static constexpr int STOP = LOGM - 3;                       // layout of the global order
-    static constexpr int SFIRST = RHO ? LOGM - RHO - 3 : LOGM - 6;  // first LDS pass (forward)
+    static constexpr int E = 1 << LOGE;
+    static constexpr int T = M / E;
+    static constexpr int RHO = LOGM % LOGE;
+    static constexpr int STOP = LOGM - LOGE;                           // layout of the global order
+    static constexpr int SFIRST = RHO ? LOGM - RHO - LOGE : LOGM - 2 * LOGE;  // first LDS pass
+    static constexpr int SLAST_INV = RHO ? LOGM - RHO - LOGE : STOP;   // last full inverse pass
 };
 
-// ---- butterfly stages on the 3 local index bits of e ------------------------------------
+// ---- twiddles of one pass ---------------------------------------------------------------------
+// The E - 1 twiddles of a radix-E pass sit in registers in heap order: stage "local bit B" owns
+// entries [NG - 1, 2 NG - 1), NG = 2^(LOGE-1-B).  They are loaded (from L1/L2) BEFORE the LDS
+// exchange that precedes the pass, so the load latency overlaps the exchange and its barrier.
 
-template <int NP>
-__device__ __forceinline__ void fwd_bit2(uint32_t (&x)[NP][8], uint2 w, uint32_t p, uint32_t p2) {
+template <int LOGM, int LOGE, int S, int BHI, int BLO>
+__device__ __forceinline__ void load_twiddles(uint32_t (&t)[(1 << LOGE) - 1], const uint32_t *tw,
+                                              uint32_t hi) {
+    constexpr int NG = 1 << (LOGE - 1 - BHI);
+    const uint32_t *w = tw + (1u << (LOGM - 1 - S - BHI)) + (hi << (LOGE - 1 - BHI));
+#pragma unroll
+    for (int g = 0; g < NG; g++)
+#ifdef SGFHE_ABL_NO_TW
+        t[NG - 1 + g] = hi + g + 12345u;  // timing-only build: no twiddle loads (wrong results)
+#else
+        t[NG - 1 + g] = w[g];
+#endif
+    if constexpr (BHI > BLO) load_twiddles<LOGM, LOGE, S, BHI - 1, BLO>(t, tw, hi);
+}
+
+// ---- one butterfly stage on local bit B of the register index e -----------------------------
+
+template <int NP, int LOGE, int B>
+__device__ __forceinline__ void fwd_stage(uint32_t (&x)[NP][1 << LOGE],
+                                          const uint32_t (&t)[(1 << LOGE) - 1], const Mod &md) {
+    constexpr int NG = 1 << (LOGE - 1 - B);
 #pragma unroll
     for (int q = 0; q < NP; q++)
 #pragma unroll
-        for (int e = 0; e < 4; e++) bfly_fwd(x[q][e], x[q][e + 4], w.x, w.y, p, p2);
-}
-template <int NP>
-__device__ __forceinline__ void fwd_bit1(uint32_t (&x)[NP][8], uint2 wa, uint2 wb, uint32_t p,
-                                         uint32_t p2) {
+        for (int g = 0; g < NG; g++)
 #pragma unroll
-    for (int q = 0; q < NP; q++) {
-        bfly_fwd(x[q][0], x[q][2], wa.x, wa.y, p, p2);
-        bfly_fwd(x[q][1], x[q][3], wa.x, wa.y, p, p2);
-        bfly_fwd(x[q][4], x[q][6], wb.x, wb.y, p, p2);
-        bfly_fwd(x[q][5], x[q][7], wb.x, wb.y, p, p2);
-    }
+            for (int l = 0; l < (1 << B); l++) {
+                const int e0 = (g << (B + 1)) | l;
+                bfly_fwd(x[q][e0], x[q][e0 | (1 << B)], t[NG - 1 + g], md);
+            }
 }
-template <int NP>
-__device__ __forceinline__ void fwd_bit0(uint32_t (&x)[NP][8], const uint2 (&w)[4], uint32_t p,
-                                         uint32_t p2) {
-#pragma unroll
-    for (int q = 0; q < NP; q++) {
-#pragma unroll
-        for (int h = 0; h < 4; h++) bfly_fwd(x[q][2 * h], x[q][2 * h + 1], w[h].x, w[h].y, p, p2);
-    }
-}
-template <int NP>
-__device__ __forceinline__ void inv_bit2(uint32_t (&x)[NP][8], uint2 w, uint32_t p, uint32_t p2) {
+template <int NP, int LOGE, int B>
+__device__ __forceinline__ void inv_stage(uint32_t (&x)[NP][1 << LOGE],
+                                          const uint32_t (&t)[(1 << LOGE) - 1], const Mod &md) {
+    constexpr int NG = 1 << (LOGE - 1 - B);
 #pragma unroll
     for (int q = 0; q < NP; q++)
 #pragma unroll
-        for (int e = 0; e < 4; e++) bfly_inv(x[q][e], x[q][e + 4], w.x, w.y, p, p2);
+        for (int g = 0; g < NG; g++)
+#pragma unroll
+            for (int l = 0; l < (1 << B); l++) {
+                const int e0 = (g << (B + 1)) | l;
+                bfly_inv(x[q][e0], x[q][e0 | (1 << B)], t[NG - 1 + g], md);
+            }
 }
-template <int NP>
-__device__ __forceinline__ void inv_bit1(uint32_t (&x)[NP][8], uint2 wa, uint2 wb, uint32_t p,
-                                         uint32_t p2) {
-#pragma unroll
-    for (int q = 0; q < NP; q++) {
-        bfly_inv(x[q][0], x[q][2], wa.x, wa.y, p, p2);
-        bfly_inv(x[q][1], x[q][3], wa.x, wa.y, p, p2);
-        bfly_inv(x[q][4], x[q][6], wb.x, wb.y, p, p2);
-        bfly_inv(x[q][5], x[q][7], wb.x, wb.y, p, p2);
-    }
+
+// stages B = BHI, BHI-1, ..., BLO (forward order)
+template <int NP, int LOGE, int BHI, int BLO>
+__device__ __forceinline__ void fwd_stages(uint32_t (&x)[NP][1 << LOGE],
+                                           const uint32_t (&t)[(1 << LOGE) - 1], const Mod &md) {
+    fwd_stage<NP, LOGE, BHI>(x, t, md);
+    if constexpr (BHI > BLO) fwd_stages<NP, LOGE, BHI - 1, BLO>(x, t, md);
 }
-template <int NP>
-__device__ __forceinline__ void inv_bit0(uint32_t (&x)[NP][8], const uint2 (&w)[4], uint32_t p,
-                                         uint32_t p2) {
-#pragma unroll
-    for (int q = 0; q < NP; q++) {
-#pragma unroll
-        for (int h = 0; h < 4; h++) bfly_inv(x[q][2 * h], x[q][2 * h + 1], w[h].x, w[h].y, p, p2);
-    }
+// stages B = BLO, BLO+1, ..., BHI (inverse order)
+template <int NP, int LOGE, int BLO, int BHI>
+__device__ __forceinline__ void inv_stages(uint32_t (&x)[NP][1 << LOGE],
+                                           const uint32_t (&t)[(1 << LOGE) - 1], const Mod &md) {
+    inv_stage<NP, LOGE, BLO>(x, t, md);
+    if constexpr (BLO < BHI) inv_stages<NP, LOGE, BLO + 1, BHI>(x, t, md);
 }
 
 // ---- LDS exchange ------------------------------------------------------------------------
 
-template <int LOGM, int S>
+template <int LOGE, int S>
 __device__ __forceinline__ uint32_t lds_base(int tid) {
-    uint32_t lo = (uint32_t)tid & ((1u << S) - 1u);
-    uint32_t hi = (uint32_t)tid >> S;
-    return swz((hi << (S + 3)) | lo);
+    const uint32_t lo = (uint32_t)tid & ((1u << S) - 1u);
+    const uint32_t hi = (uint32_t)tid >> S;
+    return swz<LOGE>((hi << (S + LOGE)) | lo);
 }
-
-template <int LOGM, int NP, int S>
-__device__ __forceinline__ void lds_store(const uint32_t (&x)[NP][8], uint32_t *lds, int tid) {
+template <int LOGM, int NP, int LOGE, int S>
+__device__ __forceinline__ void lds_store(const uint32_t (&x)[NP][1 << LOGE], uint32_t *lds, int tid) {
+#ifdef SGFHE_ABL_NO_LDS
+    return;  // timing-only build: no LDS exchange (wrong results)
+#endif
     constexpr int M = 1 << LOGM;
-    const uint32_t pb = lds_base<LOGM, S>(tid);
+    const uint32_t pb = lds_base<LOGE, S>(tid);
 #pragma unroll
-    for (int e = 0; e < 8; e++) {
-        const uint32_t a = pb ^ swz((uint32_t)e << S);
+    for (int e = 0; e < (1 << LOGE); e++) {
+        const uint32_t a = pb ^ swz<LOGE>((uint32_t)e << S);
 #pragma unroll
         for (int q = 0; q < NP; q++) lds[q * M + a] = x[q][e];
     }
 }
-template <int LOGM, int NP, int S>
-__device__ __forceinline__ void lds_load(uint32_t (&x)[NP][8], const uint32_t *lds, int tid) {
+template <int LOGM, int NP, int LOGE, int S>
+__device__ __forceinline__ void lds_load(uint32_t (&x)[NP][1 << LOGE], const uint32_t *lds, int tid) {
+#ifdef SGFHE_ABL_NO_LDS
+    return;
+#endif
     constexpr int M = 1 << LOGM;
-    const uint32_t pb = lds_base<LOGM, S>(tid);
+    const uint32_t pb = lds_base<LOGE, S>(tid);
 #pragma unroll
-    for (int e = 0; e < 8; e++) {
-        const uint32_t a = pb ^ swz((uint32_t)e << S);
+    for (int e = 0; e < (1 << LOGE); e++) {
+        const uint32_t a = pb ^ swz<LOGE>((uint32_t)e << S);
 #pragma unroll
         for (int q = 0; q < NP; q++) x[q][e] = lds[q * M + a];
     }
 }
 
-// ---- twiddle tables -------------------------------------------------------------------------
-// tw[i] = (w, floor(w 2^32 / p)) with w = psi^bitrev(i) (forward) or psi^-bitrev(i) (inverse),
-// i in [1, m): the tables of the merged-twist CT / GS transforms.  A pass over bits [S, S+3)
-// of thread-group `hi` needs entries  2^(LOGM-3-S) + hi,  2^(LOGM-2-S) + 2 hi + {0,1},
-// 2^(LOGM-1-S) + 4 hi + {0..3}: 1 + 2 + 4 consecutive entries.  (All loads keep the uint2 element
-// type: a uint4-typed view of the same table made hipcc -O3's load/store vectorizer emit a
-// partial load of one entry for LOGM = 11.)
+// ---- pass recursions ---------------------------------------------------------------------------
 
-template <int LOGM, int NP, int S>
-__device__ __forceinline__ void fwd_pass_full(uint32_t (&x)[NP][8], const uint2 *tw, int tid,
-                                              uint32_t p, uint32_t p2) {
-    const uint32_t hi = (uint32_t)tid >> S;
-    const uint2 *t1 = tw + (1u << (LOGM - 2 - S)) + 2 * hi;
-    const uint2 *t0 = tw + (1u << (LOGM - 1 - S)) + 4 * hi;
-    const uint2 w2 = tw[(1u << (LOGM - 3 - S)) + hi];
-    const uint2 w1a = t1[0], w1b = t1[1];
-    const uint2 w0[4] = {t0[0], t0[1], t0[2], t0[3]};
-    fwd_bit2<NP>(x, w2, p, p2);
-    fwd_bit1<NP>(x, w1a, w1b, p, p2);
-    fwd_bit0<NP>(x, w0, p, p2);
-}
-template <int LOGM, int NP, int S>
-__device__ __forceinline__ void inv_pass_full(uint32_t (&x)[NP][8], const uint2 *tw, int tid,
-                                              uint32_t p, uint32_t p2) {
-    const uint32_t hi = (uint32_t)tid >> S;
-    const uint2 *t1 = tw + (1u << (LOGM - 2 - S)) + 2 * hi;
-    const uint2 *t0 = tw + (1u << (LOGM - 1 - S)) + 4 * hi;
-    const uint2 w0[4] = {t0[0], t0[1], t0[2], t0[3]};
-    const uint2 w1a = t1[0], w1b = t1[1];
-    const uint2 w2 = tw[(1u << (LOGM - 3 - S)) + hi];
-    inv_bit0<NP>(x, w0, p, p2);
-    inv_bit1<NP>(x, w1a, w1b, p, p2);
-    inv_bit2<NP>(x, w2, p, p2);
+// A zero the compiler cannot see through.  Added to the twiddle pointer once per pass so that the
+// (read-only, hence freely hoistable) twiddle loads stay one pass ahead of their use and no
+// further: hoisting all ~46 loads of an NTT to its top costs that many registers.
+__device__ __forceinline__ uint32_t opaque_zero() {
+    uint32_t z = 0;
+    asm volatile("" : "+v"(z));
+    return z;
 }
 
-// Recursion over the LDS passes S = SCUR, SCUR - 3, ..., 0 (forward).
-template <int LOGM, int NP, int SPREV, int SCUR>
+// forward LDS passes S = SCUR, SCUR - LOGE, ..., 0; data arrives in registers in layout SPREV
+template <int LOGM, int NP, int LOGE, int SPREV, int SCUR>
 struct FwdPasses {
-    static __device__ __forceinline__ void run(uint32_t (&x)[NP][8], uint32_t *lds,
-                                               const uint2 *tw, int tid, uint32_t p, uint32_t p2) {
-        lds_store<LOGM, NP, SPREV>(x, lds, tid);
-        __syncthreads();
-        lds_load<LOGM, NP, SCUR>(x, lds, tid);
-        fwd_pass_full<LOGM, NP, SCUR>(x, tw, tid, p, p2);
-        if constexpr (SCUR >= 3) FwdPasses<LOGM, NP, SCUR, SCUR - 3>::run(x, lds, tw, tid, p, p2);
+    static __device__ __forceinline__ void run(uint32_t (&x)[NP][1 << LOGE], uint32_t *lds,
+                                               const uint32_t *tw, int tid, const Mod &md) {
+        uint32_t t[(1 << LOGE) - 1];
+        load_twiddles<LOGM, LOGE, SCUR, LOGE - 1, 0>(t, tw + opaque_zero(), (uint32_t)tid >> SCUR);
+        lds_store<LOGM, NP, LOGE, SPREV>(x, lds, tid);
+        SGFHE_SYNC();
+        lds_load<LOGM, NP, LOGE, SCUR>(x, lds, tid);
+        fwd_stages<NP, LOGE, LOGE - 1, 0>(x, t, md);
+        if constexpr (SCUR >= LOGE)
+            FwdPasses<LOGM, NP, LOGE, SCUR, SCUR - LOGE>::run(x, lds, tw, tid, md);
     }
 };
-// Inverse: passes S = SCUR, SCUR + 3, ... up to SLAST (inclusive), data arrives in registers in
-// layout SCUR.
-template <int LOGM, int NP, int SCUR, int SLAST>
+// inverse passes S = SCUR, SCUR + LOGE, ..., SLAST; data arrives in registers in layout SCUR and
+// the twiddles of pass SCUR in t
+template <int LOGM, int NP, int LOGE, int SCUR, int SLAST>
 struct InvPasses {
-    static __device__ __forceinline__ void run(uint32_t (&x)[NP][8], uint32_t *lds,
-                                               const uint2 *tw, int tid, uint32_t p, uint32_t p2) {
-        inv_pass_full<LOGM, NP, SCUR>(x, tw, tid, p, p2);
+    static __device__ __forceinline__ void run(uint32_t (&x)[NP][1 << LOGE], uint32_t *lds,
+                                               const uint32_t *tw, int tid, const Mod &md,
+                                               const uint32_t (&t)[(1 << LOGE) - 1]) {
+        inv_stages<NP, LOGE, 0, LOGE - 1>(x, t, md);
         if constexpr (SCUR < SLAST) {
-            lds_store<LOGM, NP, SCUR>(x, lds, tid);
-            __syncthreads();
-            lds_load<LOGM, NP, SCUR + 3>(x, lds, tid);
-            InvPasses<LOGM, NP, SCUR + 3, SLAST>::run(x, lds, tw, tid, p, p2);
+            uint32_t tn[(1 << LOGE) - 1];
+            load_twiddles<LOGM, LOGE, SCUR + LOGE, LOGE - 1, 0>(tn, tw + opaque_zero(),
+                                                                (uint32_t)tid >> (SCUR + LOGE));
+            lds_store<LOGM, NP, LOGE, SCUR>(x, lds, tid);
+            SGFHE_SYNC();
+            lds_load<LOGM, NP, LOGE, SCUR + LOGE>(x, lds, tid);
+            InvPasses<LOGM, NP, LOGE, SCUR + LOGE, SLAST>::run(x, lds, tw, tid, md, tn);
         }
     }
 };
 
 // Forward transform.  In: x[q][e] = coefficient tid + T e of polynomial q, in [0, 4p).
-// Out: x[q][e] = slot 8 tid + e, in [0, 4p).  `lds` must hold NP * m words.
-template <int LOGM, int NP>
-__device__ __forceinline__ void ntt_forward(uint32_t (&x)[NP][8], uint32_t *lds, const uint2 *tw,
-                                            int tid, uint32_t p) {
-    using G = NttGeom<LOGM>;
-    const uint32_t p2 = 2 * p;
-    if constexpr (G::RHO == 0) {
-        fwd_pass_full<LOGM, NP, G::STOP>(x, tw, tid, p, p2);
-    } else {
-        fwd_bit2<NP>(x, tw[1], p, p2);
-        if constexpr (G::RHO == 2) fwd_bit1<NP>(x, tw[2], tw[3], p, p2);
-    }
+// Out: x[q][e] = slot E tid + e, in [0, 4p).  `lds` must hold NP * m words.
+template <int LOGM, int NP, int LOGE>
+__device__ __forceinline__ void ntt_forward(uint32_t (&x)[NP][1 << LOGE], uint32_t *lds,
+                                            const uint32_t *tw, int tid, const Mod &md) {
+    using G = NttGeom<LOGM, LOGE>;
+    constexpr int BLO = G::RHO == 0 ? 0 : LOGE - G::RHO;
+    uint32_t t[(1 << LOGE) - 1];
+    load_twiddles<LOGM, LOGE, G::STOP, LOGE - 1, BLO>(t, tw + opaque_zero(), 0u);
+    fwd_stages<NP, LOGE, LOGE - 1, BLO>(x, t, md);
     if constexpr (G::SFIRST >= 0)
-        FwdPasses<LOGM, NP, G::STOP, G::SFIRST>::run(x, lds, tw, tid, p, p2);
+        FwdPasses<LOGM, NP, LOGE, G::STOP, G::SFIRST>::run(x, lds, tw, tid, md);
 }
 
-// Inverse transform (unscaled).  In: slots 8 tid + e in [0, 2p).  Out: coefficient tid + T e in
-// [0, 2p).  On return every thread has its output both in registers and NOT in LDS.
-template <int LOGM, int NP>
-__device__ __forceinline__ void ntt_inverse(uint32_t (&x)[NP][8], uint32_t *lds, const uint2 *tw,
-                                            int tid, uint32_t p) {
-    using G = NttGeom<LOGM>;
-    const uint32_t p2 = 2 * p;
+// Inverse transform (unscaled).  In: slots E tid + e in [0, 2p).  Out: coefficient tid + T e in
+// [0, 2p), in registers; the last LDS accesses of every thread were loads in layout STOP.
+template <int LOGM, int NP, int LOGE>
+__device__ __forceinline__ void ntt_inverse(uint32_t (&x)[NP][1 << LOGE], uint32_t *lds,
+                                            const uint32_t *tw, int tid, const Mod &md) {
+    using G = NttGeom<LOGM, LOGE>;
     if constexpr (G::RHO == 0) {
-        InvPasses<LOGM, NP, 0, G::STOP>::run(x, lds, tw, tid, p, p2);
+        uint32_t t[(1 << LOGE) - 1];
+        load_twiddles<LOGM, LOGE, 0, LOGE - 1, 0>(t, tw + opaque_zero(), (uint32_t)tid);
+        InvPasses<LOGM, NP, LOGE, 0, G::STOP>::run(x, lds, tw, tid, md, t);
     } else {
-        constexpr int SLAST = LOGM - G::RHO - 3;
-        InvPasses<LOGM, NP, 0, SLAST>::run(x, lds, tw, tid, p, p2);
-        lds_store<LOGM, NP, SLAST>(x, lds, tid);
-        __syncthreads();
-        lds_load<LOGM, NP, G::STOP>(x, lds, tid);
-        if constexpr (G::RHO == 2) inv_bit1<NP>(x, tw[2], tw[3], p, p2);
-        inv_bit2<NP>(x, tw[1], p, p2);
+        uint32_t tp[(1 << LOGE) - 1];
+        if constexpr (G::SLAST_INV >= 0) {
+            uint32_t t[(1 << LOGE) - 1];
+            load_twiddles<LOGM, LOGE, 0, LOGE - 1, 0>(t, tw + opaque_zero(), (uint32_t)tid);
+            InvPasses<LOGM, NP, LOGE, 0, G::SLAST_INV>::run(x, lds, tw, tid, md, t);
+            load_twiddles<LOGM, LOGE, G::STOP, LOGE - 1, LOGE - G::RHO>(tp, tw + opaque_zero(), 0u);
+            lds_store<LOGM, NP, LOGE, G::SLAST_INV>(x, lds, tid);
+            SGFHE_SYNC();
+            lds_load<LOGM, NP, LOGE, G::STOP>(x, lds, tid);
+        } else {
+            load_twiddles<LOGM, LOGE, G::STOP, LOGE - 1, LOGE - G::RHO>(tp, tw + opaque_zero(), 0u);
+        }
+        inv_stages<NP, LOGE, LOGE - G::RHO, LOGE - 1>(x, tp, md);
     }
 }
 

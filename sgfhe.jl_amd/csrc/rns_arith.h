@@ -15,13 +15,6 @@ namespace sgfhe {
 // x in [0, 2p) -> [0, p).  (x - p wraps above x when x < p, so min picks x.)
 __device__ __forceinline__ uint32_t csub(uint32_t x, uint32_t p) { return min(x, x - p); }
 
-// Shoup multiplication by a constant w with companion wp = floor(w * 2^32 / p):
-// returns w * y mod p in [0, 2p) for any y < 2^32.
-__device__ __forceinline__ uint32_t shoup_mul(uint32_t y, uint32_t w, uint32_t wp, uint32_t p) {
-    uint32_t q = __umulhi(wp, y);
-    return w * y - q * p;
-}
-
 // Montgomery reduction, R = 2^32: T < p * 2^32 -> T * R^-1 mod p in [0, 2p).
 // ninv = -p^-1 mod 2^32.
 __device__ __forceinline__ uint32_t redc64(uint64_t T, uint32_t p, uint32_t ninv) {
@@ -37,22 +30,36 @@ __device__ __forceinline__ uint32_t mont_mul(uint32_t a, uint32_t b, uint32_t p,
     return csub(redc64((uint64_t)a * b, p, ninv), p);
 }
 
+// Modulus record kept in registers by the NTT code.
+struct Mod {
+    uint32_t p, ninv, p2;  // prime, -p^-1 mod 2^32, 2p
+};
+
+// Lazy Montgomery multiplication by a constant held in Montgomery form (wM = w * 2^32 mod p):
+// returns w * y mod p in [0, 2p) for any y < 2^32.  Two v_mad_u64_u32 and one v_mul_lo_u32
+// (measured on gfx950: 1.73 + 1.63 + 1.73 add-equivalents, against 5.8 for the Shoup form
+// mul_hi + 2 mul_lo + sub; tools/ubench_int.hip).
+__device__ __forceinline__ uint32_t mont_lazy(uint32_t y, uint32_t wM, const Mod &md) {
+    const uint64_t T = (uint64_t)wM * y;             // < p * 2^32
+    const uint32_t mq = (uint32_t)T * md.ninv;
+    const uint64_t U = (uint64_t)mq * md.p + T;      // low word cancels; < 2p * 2^32
+    return (uint32_t)(U >> 32);
+}
+
 // Forward (Cooley-Tukey) Harvey butterfly: X, Y in [0, 4p) -> X + wY, X - wY in [0, 4p).
-__device__ __forceinline__ void bfly_fwd(uint32_t &X, uint32_t &Y, uint32_t w, uint32_t wp,
-                                         uint32_t p, uint32_t p2) {
-    uint32_t x = min(X, X - p2);  // [0, 2p)
-    uint32_t t = shoup_mul(Y, w, wp, p);
+__device__ __forceinline__ void bfly_fwd(uint32_t &X, uint32_t &Y, uint32_t wM, const Mod &md) {
+    const uint32_t x = min(X, X - md.p2);  // [0, 2p)
+    const uint32_t t = mont_lazy(Y, wM, md);
     X = x + t;
-    Y = x + p2 - t;
+    Y = x + md.p2 - t;
 }
 
 // Inverse (Gentleman-Sande) Harvey butterfly: X, Y in [0, 2p) -> X + Y, w (X - Y) in [0, 2p).
-__device__ __forceinline__ void bfly_inv(uint32_t &X, uint32_t &Y, uint32_t w, uint32_t wp,
-                                         uint32_t p, uint32_t p2) {
-    uint32_t s = X + Y;
-    uint32_t t = X + p2 - Y;
-    X = min(s, s - p2);
-    Y = shoup_mul(t, w, wp, p);
+__device__ __forceinline__ void bfly_inv(uint32_t &X, uint32_t &Y, uint32_t wM, const Mod &md) {
+    const uint32_t s = X + Y;
+    const uint32_t t = X + md.p2 - Y;
+    X = min(s, s - md.p2);
+    Y = mont_lazy(t, wM, md);
 }
 
 }  // namespace sgfhe

@@ -82,16 +82,16 @@ class Consts:
                     psi = g
                     break
             ipsi = pow(psi, p - 2, p)
-            twf = np.zeros((m, 2), dtype=np.uint64)
-            twi = np.zeros((m, 2), dtype=np.uint64)
+            R1 = (1 << 32) % p
+            twf = np.zeros(m, dtype=np.uint64)
+            twi = np.zeros(m, dtype=np.uint64)
             pw = ipw = 1
             for t in range(m):
                 br = bitrev(t, self.logm)
-                twf[br] = (pw, (pw << 32) // p)
-                twi[br] = (ipw, (ipw << 32) // p)
+                twf[br] = pw * R1 % p          # Montgomery form
+                twi[br] = ipw * R1 % p
                 pw = pw * psi % p
                 ipw = ipw * ipsi % p
-            R1 = (1 << 32) % p
             Rinv = pow(R1, p - 2, p)
             Mi = prod // p % p
             ei = pow(Mi, p - 2, p)
@@ -123,11 +123,6 @@ def mulhi(a, b):
     return (u32(a) * u32(b)) >> 32
 
 
-def shoup_mul(y, w, wp, p):
-    q = mulhi(wp, y)
-    return u32(u32(w) * u32(y) - q * p)
-
-
 def redc64(T, p, ninv):
     T = np.asarray(T, dtype=np.uint64)
     tlo, thi = T & MASK32, T >> 32
@@ -140,121 +135,122 @@ def mont_mul(a, b, p, ninv):
     return csub(redc64(u32(a) * u32(b), p, ninv), p)
 
 
-def bfly_fwd(X, Y, w, wp, p):
+def mont_lazy(y, wM, p, ninv):
+    T = u32(wM) * u32(y)
+    mq = u32((T & MASK32) * ninv)
+    U = mq * np.uint64(p) + T
+    return U >> 32
+
+
+def bfly_fwd(X, Y, wM, p, ninv):
     p2 = 2 * p
-    x = np.minimum(u32(X), u32(X - p2 + (1 << 32)))
-    t = shoup_mul(Y, w, wp, p)
-    return u32(x + t), u32(x + p2 - t + (1 << 32))
+    x = np.minimum(u32(X), u32(u32(X) + np.uint64((1 << 32) - p2)))
+    t = mont_lazy(Y, wM, p, ninv)
+    return u32(x + t), u32(x + p2 + np.uint64(1 << 32) - t)
 
 
-def bfly_inv(X, Y, w, wp, p):
+def bfly_inv(X, Y, wM, p, ninv):
     p2 = 2 * p
     s = u32(X + Y)
-    t = u32(X + p2 - Y + (1 << 32))
-    return np.minimum(s, u32(s - p2 + (1 << 32))), shoup_mul(t, w, wp, p)
+    t = u32(X + p2 + np.uint64(1 << 32) - Y)
+    return np.minimum(s, u32(s + np.uint64((1 << 32) - p2))), mont_lazy(t, wM, p, ninv)
 
 
 # ---- ntt.h -----------------------------------------------------------------------------------------
 
-def swz(idx):
+LOGE = 4
+
+
+def swz(idx, loge=LOGE):
     idx = np.asarray(idx, dtype=np.int64)
-    return idx ^ (((idx >> 6) & 1) * 0x09) ^ (((idx >> 7) & 1) * 0x12) ^ (((idx >> 5) & 1) * 0x04)
+    if loge == 3:
+        return idx ^ (((idx >> 6) & 1) * 0x09) ^ (((idx >> 7) & 1) * 0x12) ^ (((idx >> 5) & 1) * 0x04)
+    return (idx ^ (((idx >> 5) & 1) * 0x01) ^ (((idx >> 6) & 1) * 0x02) ^ (((idx >> 7) & 1) * 0x04)
+            ^ (((idx >> 8) & 1) * 0x18))
 
 
 class NttModel:
-    """x has shape [T, 8] (one polynomial); lds is a flat array of M words."""
+    """x has shape [T, E] (one polynomial); lds is a flat array of M words."""
 
-    def __init__(self, logm):
-        self.LOGM = logm
+    def __init__(self, logm, loge=LOGE):
+        self.LOGM, self.LOGE = logm, loge
         self.M = 1 << logm
-        self.T = self.M // 8
-        self.RHO = logm % 3
-        self.STOP = logm - 3
-        self.SFIRST = logm - self.RHO - 3 if self.RHO else logm - 6
+        self.E = 1 << loge
+        self.T = self.M // self.E
+        self.RHO = logm % loge
+        self.STOP = logm - loge
+        self.SFIRST = logm - self.RHO - loge if self.RHO else logm - 2 * loge
+        self.SLAST_INV = logm - self.RHO - loge if self.RHO else self.STOP
         self.tid = np.arange(self.T, dtype=np.int64)
 
     def lds_addr(self, S, e):
         lo = self.tid & ((1 << S) - 1)
         hi = self.tid >> S
-        return swz((hi << (S + 3)) | lo) ^ int(swz(e << S))
+        return swz((hi << (S + self.LOGE)) | lo, self.LOGE) ^ int(swz(e << S, self.LOGE))
 
     def store(self, x, lds, S):
-        for e in range(8):
+        for e in range(self.E):
             lds[self.lds_addr(S, e)] = x[:, e]
 
     def load(self, lds, S):
-        x = np.zeros((self.T, 8), dtype=np.uint64)
-        for e in range(8):
+        x = np.zeros((self.T, self.E), dtype=np.uint64)
+        for e in range(self.E):
             x[:, e] = lds[self.lds_addr(S, e)]
         return x
 
-    @staticmethod
-    def _pairs(bit):
-        return {2: [(e, e + 4) for e in range(4)],
-                1: [(0, 2), (1, 3), (4, 6), (5, 7)],
-                0: [(0, 1), (2, 3), (4, 5), (6, 7)]}[bit]
-
-    def _tw_index(self, bit, S, hi, e_lo):
-        L = self.LOGM
-        if bit == 2:
-            return (1 << (L - 3 - S)) + hi
-        if bit == 1:
-            return (1 << (L - 2 - S)) + 2 * hi + (e_lo >> 2)
-        return (1 << (L - 1 - S)) + 4 * hi + (e_lo >> 1)
-
-    def stage(self, x, tw, p, bit, S, fwd):
+    def stage(self, x, tw, p, ninv, B, S, fwd):
+        """butterflies on local bit B of the pass over [S, S + LOGE)."""
         hi = self.tid >> S
-        for (ea, eb) in self._pairs(bit):
-            idx = self._tw_index(bit, S, hi, ea)
-            w, wp = tw[idx, 0], tw[idx, 1]
-            f = bfly_fwd if fwd else bfly_inv
-            x[:, ea], x[:, eb] = f(x[:, ea], x[:, eb], w, wp, p)
+        base = (1 << (self.LOGM - 1 - S - B)) + (hi << (self.LOGE - 1 - B))
+        f = bfly_fwd if fwd else bfly_inv
+        for g in range(1 << (self.LOGE - 1 - B)):
+            w = tw[base + g]
+            for l in range(1 << B):
+                e0 = (g << (B + 1)) | l
+                e1 = e0 | (1 << B)
+                x[:, e0], x[:, e1] = f(x[:, e0], x[:, e1], w, p, ninv)
 
-    def forward(self, x, tw, p):
-        """x[tid, e] = coefficient tid + T e -> slot 8 tid + e."""
+    def forward(self, x, tw, p, ninv):
+        """x[tid, e] = coefficient tid + T e -> slot E tid + e."""
         x = x.copy()
         lds = np.zeros(self.M, dtype=np.uint64)
-        if self.RHO == 0:
-            for bit in (2, 1, 0):
-                self.stage(x, tw, p, bit, self.STOP, True)
-        else:
-            self.stage(x, tw, p, 2, self.STOP, True)
-            if self.RHO == 2:
-                self.stage(x, tw, p, 1, self.STOP, True)
+        blo = 0 if self.RHO == 0 else self.LOGE - self.RHO
+        for B in range(self.LOGE - 1, blo - 1, -1):
+            self.stage(x, tw, p, ninv, B, self.STOP, True)
         sprev, S = self.STOP, self.SFIRST
         while S >= 0:
             self.store(x, lds, sprev)
             x = self.load(lds, S)
-            for bit in (2, 1, 0):
-                self.stage(x, tw, p, bit, S, True)
-            sprev, S = S, S - 3
+            for B in range(self.LOGE - 1, -1, -1):
+                self.stage(x, tw, p, ninv, B, S, True)
+            sprev, S = S, S - self.LOGE
         return x
 
-    def inverse(self, x, tw, p):
-        """slots 8 tid + e -> coefficient tid + T e (unscaled)."""
+    def inverse(self, x, tw, p, ninv):
+        """slots E tid + e -> coefficient tid + T e (unscaled)."""
         x = x.copy()
         lds = np.zeros(self.M, dtype=np.uint64)
-        slast = self.STOP if self.RHO == 0 else self.LOGM - self.RHO - 3
-        S = 0
-        while True:
-            for bit in (0, 1, 2):
-                self.stage(x, tw, p, bit, S, False)
-            if S >= slast:
-                break
-            self.store(x, lds, S)
-            x = self.load(lds, S + 3)
-            S += 3
+        if self.SLAST_INV >= 0:
+            S = 0
+            while True:
+                for B in range(self.LOGE):
+                    self.stage(x, tw, p, ninv, B, S, False)
+                if S >= self.SLAST_INV:
+                    break
+                self.store(x, lds, S)
+                x = self.load(lds, S + self.LOGE)
+                S += self.LOGE
         if self.RHO:
-            self.store(x, lds, slast)
-            x = self.load(lds, self.STOP)
-            if self.RHO == 2:
-                self.stage(x, tw, p, 1, self.STOP, False)
-            self.stage(x, tw, p, 2, self.STOP, False)
+            if self.SLAST_INV >= 0:
+                self.store(x, lds, self.SLAST_INV)
+                x = self.load(lds, self.STOP)
+            for B in range(self.LOGE - self.RHO, self.LOGE):
+                self.stage(x, tw, p, ninv, B, self.STOP, False)
         return x
 
     def to_regs(self, poly):
-        """natural-order polynomial -> [T, 8] register layout (coefficient tid + T e)."""
-        return np.asarray(poly, dtype=np.uint64).reshape(8, self.T).T.copy()
+        """natural-order polynomial -> [T, E] register layout (coefficient tid + T e)."""
+        return np.asarray(poly, dtype=np.uint64).reshape(self.E, self.T).T.copy()
 
     def from_regs(self, x):
         return x.T.reshape(-1).copy()
@@ -294,10 +290,10 @@ class EngineModel:
             if v > C.Q // 2:
                 r = (r - P["qmodp"]) % p
             vals[i] = int(mont_mul(r, P["kappaR"], p, ninv))
-        x = self.ntt.forward(self.ntt.to_regs(vals), P["twf"], p)
+        x = self.ntt.forward(self.ntt.to_regs(vals), P["twf"], p, ninv)
         x = np.minimum(x, u32(x - 2 * p + (1 << 32)))
         x = csub(x, p)
-        return x.reshape(-1)          # slot 8 tid + e
+        return x.reshape(-1)          # slot E tid + e
 
     def extprod(self, dig_a, dig_b, keyslice, j, plain=False):
         """k_extprod for one bootstrap: dig_* lists of (lo, hi); keyslice[pi][row*2+col] slot
@@ -317,15 +313,17 @@ class EngineModel:
                 v = csub(redc64(d, p, ninv), p)
                 t = u32(v - P["sR"] + (1 << 32))
                 v = np.minimum(t, u32(t + p))
-                x = self.ntt.forward(self.ntt.to_regs(v), P["twf"], p)
+                x = self.ntt.forward(self.ntt.to_regs(v), P["twf"], p, ninv)
                 x = np.minimum(x, u32(x - 2 * p + (1 << 32)))
                 U.append(csub(x, p).reshape(-1))
             for c in range(2):
-                acc = np.zeros(M, dtype=np.uint64)
-                for row in range(4):
-                    acc = acc + U[row] * keyslice[pi][row * 2 + c]
-                z = redc64(acc, p, ninv).reshape(T, 8)
-                z = self.ntt.inverse(z, P["twi"], p)
+                # two phases (digits of a with key rows 0-1, digits of b with rows 2-3), each
+                # Montgomery-reduced, summed lazily mod 2p
+                r0 = redc64(U[0] * keyslice[pi][0 + c] + U[1] * keyslice[pi][2 + c], p, ninv)
+                r1 = redc64(U[2] * keyslice[pi][4 + c] + U[3] * keyslice[pi][6 + c], p, ninv)
+                zs = u32(r0 + r1)
+                z = np.minimum(zs, u32(zs + np.uint64((1 << 32) - 2 * p))).reshape(T, self.ntt.E)
+                z = self.ntt.inverse(z, P["twi"], p, ninv)
                 Pn = self.ntt.from_regs(csub(z, p))            # natural order
                 if plain:
                     ys[c][pi] = csub(Pn + P["hoff"], p)

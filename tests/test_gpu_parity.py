@@ -40,7 +40,7 @@ def test_ntt_matches_model(S, logm):
         p = primes[pi]
         poly = rng.integers(0, p, size=m, dtype=np.uint64)
         fwd = eng.debug_ntt(pi, poly.astype(np.uint32))
-        model = N.forward(N.to_regs(poly), C.pk[pi]["twf"], p).reshape(-1) % p
+        model = N.forward(N.to_regs(poly), C.pk[pi]["twf"], p, C.pk[pi]["ninv"]).reshape(-1) % p
         assert np.array_equal(fwd.astype(np.uint64), model)
         if logm <= 8:
             ref = RM.ntt_reference([int(v) for v in poly], C.pk[pi]["psi"], p)

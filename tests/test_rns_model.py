@@ -16,7 +16,7 @@ def _textbook_fwd(a, tw, p):
     while mm < m:
         t >>= 1
         for i in range(mm):
-            W = int(tw[mm + i, 0])
+            W = int(tw[mm + i])
             for j in range(2 * i * t, 2 * i * t + t):
                 U, V = a[j], a[j + t] * W % p
                 a[j], a[j + t] = (U + V) % p, (U - V) % p
@@ -24,32 +24,35 @@ def _textbook_fwd(a, tw, p):
     return a
 
 
+@pytest.mark.parametrize("loge", [3, 4])
 @pytest.mark.parametrize("logm", [6, 7, 8, 9, 11, 13])
-def test_ntt_model(logm):
+def test_ntt_model(logm, loge):
     m = 1 << logm
     C = RM.Consts(m // 8, m, (1 << 50) + 1, 1 << 26, 12345)
-    N = RM.NttModel(logm)
+    N = RM.NttModel(logm, loge)
     P = C.pk[logm % RM.NPR]
     p = P["p"]
     poly = np.random.default_rng(logm).integers(0, p, size=m, dtype=np.uint64)
-    x = N.forward(N.to_regs(poly), P["twf"], p)
+    x = N.forward(N.to_regs(poly), P["twf"], p, P["ninv"])
     assert int(x.max()) < 4 * p
     got = [int(v) % p for v in x.reshape(-1)]
-    assert got == _textbook_fwd(poly, P["twf"], p)
+    Rinv = pow(1 << 32, p - 2, p)
+    plain = np.array([int(w) * Rinv % p for w in P["twf"]], dtype=np.uint64)
+    assert got == _textbook_fwd(poly, plain, p)
     if logm <= 7:
         assert got == RM.ntt_reference([int(v) for v in poly], P["psi"], p)
-    back = N.from_regs(N.inverse(np.array(got, dtype=np.uint64).reshape(N.T, 8), P["twi"], p))
+    back = N.from_regs(N.inverse(np.array(got, dtype=np.uint64).reshape(N.T, N.E), P["twi"], p, P["ninv"]))
     minv = pow(m, p - 2, p)
     assert [int(v) * minv % p for v in back] == [int(v) for v in poly]
 
 
 def test_swizzle_is_conflict_free():
     """Every b32 LDS access of every pass hits 32 distinct banks per 32-lane group."""
-    for logm in (9, 12, 13):
-        N = RM.NttModel(logm)
-        S_list = {N.STOP} | set(range(0, N.STOP + 1, 3))
+    for logm, loge in ((9, 3), (12, 3), (13, 3), (10, 4), (12, 4), (13, 4)):
+        N = RM.NttModel(logm, loge)
+        S_list = {N.STOP} | set(range(0, N.STOP + 1, loge))
         for S in S_list:
-            for e in range(8):
+            for e in range(N.E):
                 addr = N.lds_addr(S, e)
                 assert len(set(addr.tolist())) == N.T
                 for g0 in range(0, N.T, 32):
