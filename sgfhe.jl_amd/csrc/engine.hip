@@ -396,7 +396,7 @@ int32_t build_constants(sgfhe_ctx *c) {
         P.r1 = R1;
         P.r2 = mulmod32(R1, R1, p);
         P.r3 = mulmod32(P.r2, R1, p);
-        P.sR = mulmod32((uint32_t)(s % p), Rinv, p);
+        P.sR = p - mulmod32((uint32_t)(s % p), Rinv, p);  // in [1, p]
         P.hoff = (i == NPR - 1) ? (p - 1) / 2 : 0;
         P.qmodp = (uint32_t)(Q % p);
         uint32_t Mi = 1;  // (M_rns / p_i) mod p_i

@@ -29,7 +29,7 @@ constexpr int LOGE = SGFHE_LOGE;  // points per thread (2^LOGE) in every NTT of 
 struct PrimeK {
     uint32_t p;       // prime
     uint32_t ninv;    // -p^-1 mod 2^32
-    uint32_t sR;      // s * R^-1 mod p      (digit offset s of utils.jl:162-166, R = 2^32)
+    uint32_t sR;      // p - (s * R^-1 mod p) (digit offset s of utils.jl:162-166, R = 2^32)
     uint32_t hoff;    // offset added to the output residue: (p-1)/2 for the last prime, else 0
     uint32_t r1, r2, r3;  // R, R^2, R^3 mod p
     uint32_t qmodp;   // Q mod p
@@ -88,11 +88,10 @@ __device__ __forceinline__ u128 mod_wide(u128 x, u128 d, double inv, uint64_t *q
 }
 
 // ---- digit -> residue ------------------------------------------------------------------------
-// (e - s) * R^-1 mod p in [0, p) for a raw digit e in [0, B), B < 2^62.
+// (e - s) * R^-1 mod p, lazily in [0, 4p), for a raw digit e in [0, B), B < 2^62:
+// REDC(e) < e / 2^32 + p < 2^30 + p, plus the constant p - s R^-1.
 __device__ __forceinline__ uint32_t digit_reduce(uint64_t e, const PrimeK &P) {
-    uint32_t v = csub(redc64(e, P.p, P.ninv), P.p);
-    uint32_t t = v - P.sR;
-    return min(t, t + P.p);
+    return redc_mad(e, P.p, P.ninv) + P.sR;
 }
 
 // ---- digit planes ---------------------------------------------------------------------------------
@@ -143,9 +142,9 @@ k_extprod(const uint64_t *__restrict__ dig, const uint32_t *__restrict__ keyk,
     const uint32_t p = P.p;
     const Mod md = {P.p, P.ninv, 2 * P.p};
 
-    uint32_t z0[1][E];
+    uint64_t acc0[E];  // 64-bit NTT-domain sum of column 0 over the four phases (< 8 p^2 < 2^63)
 #pragma unroll
-    for (int e = 0; e < E; e++) { z0[0][e] = 0; z1[e * T] = 0; }
+    for (int e = 0; e < E; e++) { acc0[e] = 0; z1[e * T] = 0; }
     // A real loop (not unrolled): one copy of the forward NTT in the instruction stream, and the
     // loads of a later phase cannot be hoisted over the registers of an earlier one.
 #pragma unroll 1
@@ -169,8 +168,9 @@ k_extprod(const uint64_t *__restrict__ dig, const uint32_t *__restrict__ keyk,
         // 2. forward NTT of u[ph]
         ntt_forward<LOGM, 1, LOGE>(x, lds, P.twf, tid, md);
 
-        // 3. pointwise: z_c += U * K[ph][c]   (fhe.jl:527-528 in the NTT domain)
-        //    U in [0, 4p), K < p: the product is < p 2^32
+        // 3. pointwise: z_c += U * K[ph][c]   (fhe.jl:527-528 in the NTT domain), U in [0, 2p)
+        //    column 0: 64-bit multiply-accumulate, reduced once after the loop
+        //    column 1: Montgomery-reduced and added lazily (mod 2p) to the LDS accumulator
         const uint32_t *kp = keyk + ((size_t)pi * 8 + ph * 2) * M + E * tid;
 #pragma unroll
         for (int h = 0; h < E / 4; h++) {
@@ -185,14 +185,20 @@ k_extprod(const uint64_t *__restrict__ dig, const uint32_t *__restrict__ keyk,
 #pragma unroll
             for (int t = 0; t < 4; t++) {
                 const int e = 4 * h + t;
-                const uint32_t s0 = z0[0][e] + redc64((uint64_t)x[0][e] * ka[t], p, P.ninv);
-                z0[0][e] = min(s0, s0 - md.p2);  // [0, 2p)
-                const uint32_t r1 = redc64((uint64_t)x[0][e] * kb[t], p, P.ninv);
+                const uint32_t u = min(x[0][e], x[0][e] - md.p2);
+                acc0[e] += (uint64_t)u * ka[t];
+                const uint32_t r1 = redc_mad((uint64_t)u * kb[t], p, P.ninv);  // [0, 2p)
                 uint32_t *zp = lds + M + e * T + tid;
                 const uint32_t s1 = *zp + r1;
                 *zp = min(s1, s1 - md.p2);
             }
         }
+    }
+    uint32_t z0[1][E];
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+        const uint32_t r = redc_mad(acc0[e], p, P.ninv);  // [0, 3p)
+        z0[0][e] = min(r, r - md.p2);                     // [0, 2p)
     }
 
     uint32_t *yb = yres + ((size_t)b * 2 * NPR + pi) * M;
@@ -226,7 +232,8 @@ k_extprod(const uint64_t *__restrict__ dig, const uint32_t *__restrict__ keyk,
             if (s & M) v = csub(p - v, p);  // x^m = -1
             uint32_t y = v - z0[0][e];
             y = min(y, y + p);
-            yb[(size_t)c * NPR * M + i] = csub(y + P.hoff, p);
+            if (P.hoff) y = csub(y + P.hoff, p);  // wave-uniform: only the last prime
+            yb[(size_t)c * NPR * M + i] = y;
         }
     }
 }

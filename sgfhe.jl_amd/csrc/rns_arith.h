@@ -25,6 +25,13 @@ __device__ __forceinline__ uint32_t redc64(uint64_t T, uint32_t p, uint32_t ninv
     return thi + h + (tlo != 0u);
 }
 
+// The same reduction written for v_mad_u64_u32: hi32(T + (T_lo * ninv) * p).  Valid for any
+// T < 2^64 - 2^32 p; returns T * R^-1 mod p in [0, T / 2^32 + p).
+__device__ __forceinline__ uint32_t redc_mad(uint64_t T, uint32_t p, uint32_t ninv) {
+    const uint32_t mq = (uint32_t)T * ninv;
+    return (uint32_t)(((uint64_t)mq * p + T) >> 32);
+}
+
 // a * b * R^-1 mod p in [0, p); a * b < p * 2^32 required (e.g. a < 2^32, b < p).
 __device__ __forceinline__ uint32_t mont_mul(uint32_t a, uint32_t b, uint32_t p, uint32_t ninv) {
     return csub(redc64((uint64_t)a * b, p, ninv), p);
