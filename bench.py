@@ -94,6 +94,7 @@ def main():
     ap.add_argument("--config", default="params1024")
     ap.add_argument("--batch", type=int, default=4096, help="bootstraps per GPU per step")
     ap.add_argument("--chunk", type=int, default=0, help="lock-step chunk (0 = engine default)")
+    ap.add_argument("--lanes", type=int, default=1, help="1 = chunks in sequence, 2 = two streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -118,6 +119,7 @@ def main():
     eng = S.Engine(p, device=local_rank)
     if args.chunk:
         eng.set_chunk(args.chunk)
+    eng.set_lanes(args.lanes)
 
     # ---- bootstrap key: rank 0 transforms, peers receive the device form over RCCL -------------
     key = None
@@ -199,7 +201,7 @@ def main():
             "config": {"workload": "%s gate bootstraps (AND/OR/XOR), batch %d per GPU, "
                                    "deterministic flatten" % (args.config, B),
                        "n": p.n, "m": p.m, "log2_Q": round(float(np.log2(float(p.Q))), 2),
-                       "batch_per_gpu": B, "chunk": chunk, "rns_primes": 5,
+                       "batch_per_gpu": B, "chunk": chunk, "lanes": args.lanes, "rns_primes": 5,
                        "key": "uniform random residues mod Q (synthetic)",
                        "key_broadcast_s": round(bcast_s, 4)},
             "roofline": {"bound": "hbm", "kernel": "k_extprod", "achieved": achieved,

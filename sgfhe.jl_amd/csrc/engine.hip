@@ -72,6 +72,9 @@ struct sgfhe_ctx {
     uint32_t primes[NPR];
     std::string err;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;  // second lane: chunk i+1 overlaps its memory-bound k_crt_acc
+                                    // with the VALU-bound k_extprod of chunk i
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // device constants
     PrimeK *d_primes = nullptr;
     CrtConst *d_crt = nullptr;
@@ -81,11 +84,13 @@ struct sgfhe_ctx {
     uint32_t *d_key = nullptr;
     size_t key_bytes = 0;
     bool have_key = false;
-    // work buffers (sized for `cap` bootstraps)
-    uint32_t chunk = 0, cap = 0;
-    uint64_t *d_dig = nullptr;
-    uint32_t *d_yres = nullptr;
-    uint32_t *d_ua = nullptr;
+    // work buffers: two lanes, each sized for `cap` bootstraps
+    uint32_t chunk = 0, cap = 0, lanes = 1;
+    struct Lane {
+        uint64_t *dig = nullptr;
+        uint32_t *yres = nullptr;
+        uint32_t *ua = nullptr;
+    } lane[2];
     // timing
     bool timing = false;
     struct EvTriple { hipEvent_t e0, e1, e2; };  // ext = e0 -> e1, crt = e1 -> e2
@@ -122,8 +127,8 @@ template <int LOGM> constexpr int threads_of() { return NttGeom<LOGM, LOGE>::T; 
 #define SGFHE_FOR_LOGM(X) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13)
 
 template <int LOGM>
-int32_t launch_extprod_t(sgfhe_ctx *c, const uint32_t *keyk, uint32_t cpad, uint32_t k,
-                         uint32_t mode, hipStream_t st) {
+int32_t launch_extprod_t(sgfhe_ctx *c, const sgfhe_ctx::Lane &L, const uint32_t *keyk,
+                         uint32_t cpad, uint32_t k, uint32_t mode, hipStream_t st) {
     const size_t lds = lds_bytes(LOGM, 2);  // exchange buffer + z1 accumulator
     static bool attr_done[16] = {};
     if (!attr_done[c->device & 15]) {
@@ -131,15 +136,15 @@ int32_t launch_extprod_t(sgfhe_ctx *c, const uint32_t *keyk, uint32_t cpad, uint
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_done[c->device & 15] = true;
     }
-    hipLaunchKernelGGL(k_extprod<LOGM>, dim3(cpad * NPR), dim3(threads_of<LOGM>()), lds, st, c->d_dig,
-                       keyk, c->d_yres, c->d_ua, c->d_primes, k, c->n, mode);
+    hipLaunchKernelGGL(k_extprod<LOGM>, dim3(cpad * NPR), dim3(threads_of<LOGM>()), lds, st, L.dig,
+                       keyk, L.yres, L.ua, c->d_primes, k, c->n, mode);
     HIPCHK(c, hipGetLastError());
     return SGFHE_OK;
 }
-int32_t launch_extprod(sgfhe_ctx *c, const uint32_t *keyk, uint32_t cpad, uint32_t k,
-                       uint32_t mode, hipStream_t st) {
+int32_t launch_extprod(sgfhe_ctx *c, const sgfhe_ctx::Lane &L, const uint32_t *keyk, uint32_t cpad,
+                       uint32_t k, uint32_t mode, hipStream_t st) {
     switch (c->logm) {
-#define X(L) case L: return launch_extprod_t<L>(c, keyk, cpad, k, mode, st);
+#define X(LM) case LM: return launch_extprod_t<LM>(c, L, keyk, cpad, k, mode, st);
         SGFHE_FOR_LOGM(X)
 #undef X
     }
@@ -182,9 +187,10 @@ int32_t launch_dbgntt(sgfhe_ctx *c, const uint32_t *in, uint32_t *out, uint32_t 
     return fail(c, SGFHE_ERR_UNSUPPORTED, "unsupported log2(m)");
 }
 
-int32_t launch_crt(sgfhe_ctx *c, uint32_t cpad, uint32_t mode, hipStream_t st) {
+int32_t launch_crt(sgfhe_ctx *c, const sgfhe_ctx::Lane &L, uint32_t cpad, uint32_t mode,
+                   hipStream_t st) {
     const uint32_t total = cpad * 2 * c->M;
-    hipLaunchKernelGGL(k_crt_acc, dim3((total + 255) / 256), dim3(256), 0, st, c->d_yres, c->d_dig,
+    hipLaunchKernelGGL(k_crt_acc, dim3((total + 255) / 256), dim3(256), 0, st, L.yres, L.dig,
                        c->d_crt, total, (uint32_t)c->logm, mode);
     HIPCHK(c, hipGetLastError());
     return SGFHE_OK;
@@ -210,15 +216,24 @@ uint32_t default_chunk(const sgfhe_ctx *c) {
     return (uint32_t)k;
 }
 
+void free_lanes(sgfhe_ctx *c) {
+    for (auto &L : c->lane) {
+        if (L.dig) (void)hipFree(L.dig);
+        if (L.yres) (void)hipFree(L.yres);
+        if (L.ua) (void)hipFree(L.ua);
+        L = sgfhe_ctx::Lane();
+    }
+    c->cap = 0;
+}
+
 int32_t ensure_work(sgfhe_ctx *c, uint32_t cpad) {
     if (cpad <= c->cap) return SGFHE_OK;
-    if (c->d_dig) { (void)hipFree(c->d_dig); c->d_dig = nullptr; }
-    if (c->d_yres) { (void)hipFree(c->d_yres); c->d_yres = nullptr; }
-    if (c->d_ua) { (void)hipFree(c->d_ua); c->d_ua = nullptr; }
-    c->cap = 0;
-    HIPCHK(c, hipMalloc(&c->d_dig, (size_t)cpad * 4 * c->M * sizeof(uint64_t)));
-    HIPCHK(c, hipMalloc(&c->d_yres, (size_t)cpad * 2 * NPR * c->M * 4));
-    HIPCHK(c, hipMalloc(&c->d_ua, (size_t)cpad * c->n * 4));
+    free_lanes(c);
+    for (auto &L : c->lane) {
+        HIPCHK(c, hipMalloc(&L.dig, (size_t)cpad * 4 * c->M * sizeof(uint64_t)));
+        HIPCHK(c, hipMalloc(&L.yres, (size_t)cpad * 2 * NPR * c->M * 4));
+        HIPCHK(c, hipMalloc(&L.ua, (size_t)cpad * c->n * 4));
+    }
     c->cap = cpad;
     return SGFHE_OK;
 }
@@ -239,8 +254,8 @@ void timing_flush(sgfhe_ctx *c) {
 
 // ---- the k-loop over one chunk (fhe.jl:579-582) ---------------------------------------------------
 
-int32_t run_iterations(sgfhe_ctx *c, uint32_t cpad, uint64_t n_iters, hipStream_t st,
-                       bool full_chunk) {
+int32_t run_iterations(sgfhe_ctx *c, const sgfhe_ctx::Lane &L, uint32_t cpad, uint64_t n_iters,
+                       hipStream_t st, bool full_chunk) {
     const size_t slice = (size_t)NPR * 8 * c->M;
     for (uint64_t k = 0; k < n_iters; k++) {
         const bool sample = c->timing && full_chunk && (k % 64 == 1) && c->ev.size() < 2048;
@@ -251,10 +266,10 @@ int32_t run_iterations(sgfhe_ctx *c, uint32_t cpad, uint64_t n_iters, hipStream_
             HIPCHK(c, hipEventCreate(&e2));
             HIPCHK(c, hipEventRecord(e0, st));
         }
-        int32_t rc = launch_extprod(c, c->d_key + k * slice, cpad, (uint32_t)k, 0, st);
+        int32_t rc = launch_extprod(c, L, c->d_key + k * slice, cpad, (uint32_t)k, 0, st);
         if (rc) return rc;
         if (sample) HIPCHK(c, hipEventRecord(e1, st));
-        rc = launch_crt(c, cpad, 0, st);
+        rc = launch_crt(c, L, cpad, 0, st);
         if (rc) return rc;
         if (sample) {
             HIPCHK(c, hipEventRecord(e2, st));
@@ -271,33 +286,46 @@ int32_t bootstrap_device(sgfhe_ctx *c, const uint64_t *a1, const uint64_t *b1, c
     const uint32_t chunk = c->chunk ? c->chunk : default_chunk(c);
     const uint32_t n = c->n, M = c->M;
     const bool raw = flags & SGFHE_FLAG_RAW_MODQ;
-    for (size_t c0 = 0; c0 < batch; c0 += chunk) {
+    const bool two_lanes = c->lanes == 2 && batch > chunk;
+    if (two_lanes) {  // fork: the second lane starts after everything already queued on st
+        HIPCHK(c, hipEventRecord(c->ev_fork, st));
+        HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+    }
+    uint32_t idx = 0;
+    for (size_t c0 = 0; c0 < batch; c0 += chunk, idx++) {
         const uint32_t cb = (uint32_t)((batch - c0 < chunk) ? batch - c0 : chunk);
         const uint32_t cpad = round_up8(cb);
         int32_t rc = ensure_work(c, cpad);
         if (rc) return rc;
+        const uint32_t li = two_lanes ? (idx & 1) : 0;
+        const sgfhe_ctx::Lane &L = c->lane[li];
+        hipStream_t ls = li ? c->stream2 : st;
         const bool full_chunk = (c0 == 0);  // later chunks are the same size or a smaller tail
         if (full_chunk) c->last_chunk = cpad;
         const uint32_t tot = cpad * M;
-        hipLaunchKernelGGL(k_init, dim3((tot + 255) / 256), dim3(256), 0, st, a1 + c0 * n, b1 + c0,
-                           a2 + c0 * n, b2 + c0, c->d_dig, c->d_ua, c->d_crt, cb, cpad, n,
+        hipLaunchKernelGGL(k_init, dim3((tot + 255) / 256), dim3(256), 0, ls, a1 + c0 * n, b1 + c0,
+                           a2 + c0 * n, b2 + c0, L.dig, L.ua, c->d_crt, cb, cpad, n,
                            (uint32_t)c->logm);
         HIPCHK(c, hipGetLastError());
-        rc = run_iterations(c, cpad, n_iters, st, full_chunk || cpad == c->last_chunk);
+        rc = run_iterations(c, L, cpad, n_iters, ls, li == 0 && cpad == c->last_chunk);
         if (rc) return rc;
         if (acc_out) {
             const uint32_t t2 = cb * 2 * M;
-            hipLaunchKernelGGL(k_dump_acc, dim3((t2 + 255) / 256), dim3(256), 0, st, c->d_dig,
+            hipLaunchKernelGGL(k_dump_acc, dim3((t2 + 255) / 256), dim3(256), 0, ls, L.dig,
                                acc_out + c0 * 2 * M, c->d_crt, t2, (uint32_t)c->logm);
             HIPCHK(c, hipGetLastError());
         }
         if (out) {
             const uint32_t t3 = cb * (n + 1);
-            hipLaunchKernelGGL(k_final, dim3((t3 + 255) / 256), dim3(256), 0, st, c->d_dig,
+            hipLaunchKernelGGL(k_final, dim3((t3 + 255) / 256), dim3(256), 0, ls, L.dig,
                                out + c0 * 3 * (n + 1) * (raw ? 2 : 1), c->d_crt, cb, n,
                                (uint32_t)c->logm, raw ? 1u : 0u);
             HIPCHK(c, hipGetLastError());
         }
+    }
+    if (two_lanes) {  // join
+        HIPCHK(c, hipEventRecord(c->ev_join, c->stream2));
+        HIPCHK(c, hipStreamWaitEvent(st, c->ev_join, 0));
     }
     return SGFHE_OK;
 }
@@ -494,8 +522,11 @@ int32_t sgfhe_ctx_create(const sgfhe_params *p, int device, sgfhe_ctx **out) {
         if (c->B * c->B < c->Q) return fail(c, SGFHE_ERR_INVALID_ARG, "B^2 must be >= Q");
     }
     if (ld128(p->DQ_tilde) >= c->Q) return fail(c, SGFHE_ERR_INVALID_ARG, "DQ_tilde must be < Q");
-    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess)
-        return fail(c, SGFHE_ERR_HIP, "hipStreamCreate failed");
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess)
+        return fail(c, SGFHE_ERR_HIP, "hipStreamCreate / hipEventCreate failed");
     return build_constants(c);
 }
 
@@ -503,14 +534,16 @@ int32_t sgfhe_ctx_destroy(sgfhe_ctx *c) {
     if (!c) return SGFHE_OK;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->stream2) (void)hipStreamSynchronize(c->stream2);
     timing_flush(c);
+    free_lanes(c);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->d_primes) (void)hipFree(c->d_primes);
     if (c->d_crt) (void)hipFree(c->d_crt);
     if (c->d_tw) (void)hipFree(c->d_tw);
     if (c->d_key) (void)hipFree(c->d_key);
-    if (c->d_dig) (void)hipFree(c->d_dig);
-    if (c->d_yres) (void)hipFree(c->d_yres);
-    if (c->d_ua) (void)hipFree(c->d_ua);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return SGFHE_OK;
@@ -519,6 +552,12 @@ int32_t sgfhe_ctx_destroy(sgfhe_ctx *c) {
 int32_t sgfhe_set_chunk(sgfhe_ctx *c, uint32_t chunk) {
     if (!c) return SGFHE_ERR_INVALID_ARG;
     c->chunk = chunk ? round_up8(chunk) : 0;
+    return SGFHE_OK;
+}
+
+int32_t sgfhe_set_lanes(sgfhe_ctx *c, uint32_t lanes) {
+    if (!c || lanes < 1 || lanes > 2) return SGFHE_ERR_INVALID_ARG;
+    c->lanes = lanes;
     return SGFHE_OK;
 }
 
@@ -677,6 +716,7 @@ int32_t sgfhe_external_product(sgfhe_ctx *c, const uint64_t *a, const uint64_t *
     const uint32_t cpad = 8;
     int32_t rc = ensure_work(c, cpad);
     if (rc) return rc;
+    const sgfhe_ctx::Lane &L = c->lane[0];
     uint32_t *d_A = nullptr;
     ulonglong2 *d_ab = nullptr;
     HIPCHK(c, hipMalloc(&d_A, (size_t)NPR * 8 * M * 4));
@@ -686,17 +726,17 @@ int32_t sgfhe_external_product(sgfhe_ctx *c, const uint64_t *a, const uint64_t *
         // A[4][2][m] is exactly one key slice (k = 0)
         rc = key_transform_host(c, A, 8, d_A);
         if (rc) break;
-        if ((e = hipMemsetAsync(c->d_dig, 0, (size_t)cpad * 2 * M * 16, c->stream))) break;
+        if ((e = hipMemsetAsync(L.dig, 0, (size_t)cpad * 2 * M * 16, c->stream))) break;
         if ((e = hipMemcpyAsync(d_ab, a, (size_t)M * 16, hipMemcpyHostToDevice, c->stream))) break;
         if ((e = hipMemcpyAsync(d_ab + M, b, (size_t)M * 16, hipMemcpyHostToDevice, c->stream))) break;
         hipLaunchKernelGGL(k_flatten_canon, dim3((2 * M + 255) / 256), dim3(256), 0, c->stream, d_ab,
-                           c->d_dig, c->d_crt, 2 * M, (uint32_t)c->logm);
-        rc = launch_extprod(c, d_A, cpad, 0, MODE_PLAIN, c->stream);
+                           L.dig, c->d_crt, 2 * M, (uint32_t)c->logm);
+        rc = launch_extprod(c, L, d_A, cpad, 0, MODE_PLAIN, c->stream);
         if (rc) break;
-        rc = launch_crt(c, cpad, MODE_NOACC | MODE_CANON, c->stream);
+        rc = launch_crt(c, L, cpad, MODE_NOACC | MODE_CANON, c->stream);
         if (rc) break;
-        if ((e = hipMemcpyAsync(a_res, c->d_dig, (size_t)M * 16, hipMemcpyDeviceToHost, c->stream))) break;
-        if ((e = hipMemcpyAsync(b_res, c->d_dig + 2 * (size_t)M, (size_t)M * 16, hipMemcpyDeviceToHost, c->stream))) break;
+        if ((e = hipMemcpyAsync(a_res, L.dig, (size_t)M * 16, hipMemcpyDeviceToHost, c->stream))) break;
+        if ((e = hipMemcpyAsync(b_res, L.dig + 2 * (size_t)M, (size_t)M * 16, hipMemcpyDeviceToHost, c->stream))) break;
         e = hipStreamSynchronize(c->stream);
     } while (0);
     if (e != hipSuccess && rc == SGFHE_OK) rc = fail(c, SGFHE_ERR_HIP, hipGetErrorString(e));

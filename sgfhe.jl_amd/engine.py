@@ -92,6 +92,9 @@ class Engine:
     def set_chunk(self, chunk):
         self._chk(self._L.sgfhe_set_chunk(self._h, chunk))
 
+    def set_lanes(self, lanes):
+        self._chk(self._L.sgfhe_set_lanes(self._h, lanes))
+
     def _lwe_args(self, a1, b1, a2, b2):
         n = self.params.n
         a1, p1 = _c(a1)

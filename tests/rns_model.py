@@ -98,7 +98,7 @@ class Consts:
             minv = pow(m, p - 2, p)
             kappa = R1 * R1 % p * minv % p * ei % p
             self.pk.append(dict(
-                p=p, ninv=(-pow(p, -1, 1 << 32)) & MASK32, sR=self.s % p * Rinv % p,
+                p=p, ninv=(-pow(p, -1, 1 << 32)) & MASK32, sR=p - self.s % p * Rinv % p,
                 hoff=(p - 1) // 2 if i == NPR - 1 else 0, r1=R1, r2=R1 * R1 % p,
                 r3=R1 * R1 * R1 % p, qmodp=Q % p, kappaR=kappa * R1 % p, minvR=minv * R1 % p,
                 twf=twf, twi=twi, psi=psi, kappa=kappa, ei=ei))
@@ -129,6 +129,13 @@ def redc64(T, p, ninv):
     mq = u32(tlo * ninv)
     h = mulhi(mq, p)
     return u32(thi + h + (tlo != 0))
+
+
+def redc_mad(T, p, ninv):
+    """hi32(T + (T_lo * ninv mod 2^32) * p): the v_mad_u64_u32 form of REDC."""
+    T = np.asarray(T, dtype=np.uint64)
+    mq = u32((T & MASK32) * np.uint64(ninv))
+    return (mq * np.uint64(p) + T) >> 32
 
 
 def mont_mul(a, b, p, ninv):
@@ -310,19 +317,22 @@ class EngineModel:
                     np.array([d[1] for d in dig_b], dtype=np.uint64)]
             U = []
             for d in digs:
-                v = csub(redc64(d, p, ninv), p)
-                t = u32(v - P["sR"] + (1 << 32))
-                v = np.minimum(t, u32(t + p))
+                v = u32(redc_mad(d, p, ninv) + P["sR"])          # digit_reduce: lazy, in [0, 4p)
                 x = self.ntt.forward(self.ntt.to_regs(v), P["twf"], p, ninv)
-                x = np.minimum(x, u32(x - 2 * p + (1 << 32)))
-                U.append(csub(x, p).reshape(-1))
+                U.append(np.minimum(x, u32(x + np.uint64((1 << 32) - 2 * p))).reshape(-1))   # [0, 2p)
             for c in range(2):
-                # two phases (digits of a with key rows 0-1, digits of b with rows 2-3), each
-                # Montgomery-reduced, summed lazily mod 2p
-                r0 = redc64(U[0] * keyslice[pi][0 + c] + U[1] * keyslice[pi][2 + c], p, ninv)
-                r1 = redc64(U[2] * keyslice[pi][4 + c] + U[3] * keyslice[pi][6 + c], p, ninv)
-                zs = u32(r0 + r1)
-                z = np.minimum(zs, u32(zs + np.uint64((1 << 32) - 2 * p))).reshape(T, self.ntt.E)
+                if c == 0:
+                    # column 0: 64-bit accumulation over the four phases, one reduction
+                    acc = sum(U[row] * keyslice[pi][row * 2] for row in range(4))
+                    r = redc_mad(acc, p, ninv)                                   # [0, 3p)
+                    z = np.minimum(r, u32(r + np.uint64((1 << 32) - 2 * p)))
+                else:
+                    # column 1: reduced per phase, summed lazily mod 2p (LDS accumulator)
+                    z = np.zeros(M, dtype=np.uint64)
+                    for row in range(4):
+                        zs = u32(z + redc_mad(U[row] * keyslice[pi][row * 2 + 1], p, ninv))
+                        z = np.minimum(zs, u32(zs + np.uint64((1 << 32) - 2 * p)))
+                z = z.reshape(T, self.ntt.E)
                 z = self.ntt.inverse(z, P["twi"], p, ninv)
                 Pn = self.ntt.from_regs(csub(z, p))            # natural order
                 if plain:

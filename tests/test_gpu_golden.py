@@ -114,6 +114,9 @@ def test_chunk_size_independence_and_determinism(S, p64):
     for chunk in (8, 16, 24):
         eng.set_chunk(chunk)
         assert np.array_equal(eng.bootstrap_batch(a1, b1, a2, b2), base)
+    eng.set_lanes(2)                                   # two streams, chunks alternate
+    assert np.array_equal(eng.bootstrap_batch(a1, b1, a2, b2), base)
+    eng.set_lanes(1)
     eng.set_chunk(0)
     assert np.array_equal(base, o.bootstrap_batch(bkey, a1, b1, a2, b2))
 
