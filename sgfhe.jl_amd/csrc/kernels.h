@@ -185,12 +185,12 @@ k_extprod(const uint64_t *__restrict__ dig, const uint32_t *__restrict__ keyk,
 #pragma unroll
             for (int t = 0; t < 4; t++) {
                 const int e = 4 * h + t;
-                const uint32_t u = min(x[0][e], x[0][e] - md.p2);
+                const uint32_t u = condsub(x[0][e], md.p2);
                 acc0[e] += (uint64_t)u * ka[t];
                 const uint32_t r1 = redc_mad((uint64_t)u * kb[t], p, P.ninv);  // [0, 2p)
                 uint32_t *zp = lds + M + e * T + tid;
                 const uint32_t s1 = *zp + r1;
-                *zp = min(s1, s1 - md.p2);
+                *zp = condsub(s1, md.p2);
             }
         }
     }
@@ -198,7 +198,7 @@ k_extprod(const uint64_t *__restrict__ dig, const uint32_t *__restrict__ keyk,
 #pragma unroll
     for (int e = 0; e < E; e++) {
         const uint32_t r = redc_mad(acc0[e], p, P.ninv);  // [0, 3p)
-        z0[0][e] = min(r, r - md.p2);                     // [0, 2p)
+        z0[0][e] = condsub(r, md.p2);                     // [0, 2p)
     }
 
     uint32_t *yb = yres + ((size_t)b * 2 * NPR + pi) * M;
@@ -456,7 +456,7 @@ k_debug_ntt(const uint32_t *__restrict__ in, uint32_t *__restrict__ out, PrimeSe
         ntt_forward<LOGM, 1, LOGE>(x, lds, P.twf, tid, md);
 #pragma unroll
         for (int e = 0; e < E; e++) {
-            const uint32_t u = min(x[0][e], x[0][e] - md.p2);
+            const uint32_t u = condsub(x[0][e], md.p2);
             out[E * tid + e] = csub(u, p);
         }
     } else {

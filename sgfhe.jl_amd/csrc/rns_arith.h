@@ -12,8 +12,16 @@
 
 namespace sgfhe {
 
-// x in [0, 2p) -> [0, p).  (x - p wraps above x when x < p, so min picks x.)
-__device__ __forceinline__ uint32_t csub(uint32_t x, uint32_t p) { return min(x, x - p); }
+// Conditional subtraction: x >= m ? x - m : x.  Written through the borrow so that hipcc emits
+// v_sub_co_u32 + v_cndmask_b32 (measured 1.80 add-equivalents for the pair on gfx950) instead
+// of v_sub_u32 + v_min_u32 (2.83): tools/ubench_int.hip.
+__device__ __forceinline__ uint32_t condsub(uint32_t x, uint32_t m) {
+    uint32_t d;
+    const bool borrow = __builtin_usub_overflow(x, m, &d);
+    return borrow ? x : d;
+}
+// x in [0, 2p) -> [0, p).
+__device__ __forceinline__ uint32_t csub(uint32_t x, uint32_t p) { return condsub(x, p); }
 
 // Montgomery reduction, R = 2^32: T < p * 2^32 -> T * R^-1 mod p in [0, 2p).
 // ninv = -p^-1 mod 2^32.
@@ -55,7 +63,7 @@ __device__ __forceinline__ uint32_t mont_lazy(uint32_t y, uint32_t wM, const Mod
 
 // Forward (Cooley-Tukey) Harvey butterfly: X, Y in [0, 4p) -> X + wY, X - wY in [0, 4p).
 __device__ __forceinline__ void bfly_fwd(uint32_t &X, uint32_t &Y, uint32_t wM, const Mod &md) {
-    const uint32_t x = min(X, X - md.p2);  // [0, 2p)
+    const uint32_t x = condsub(X, md.p2);  // [0, 2p)
     const uint32_t t = mont_lazy(Y, wM, md);
     X = x + t;
     Y = x + md.p2 - t;
@@ -65,7 +73,7 @@ __device__ __forceinline__ void bfly_fwd(uint32_t &X, uint32_t &Y, uint32_t wM, 
 __device__ __forceinline__ void bfly_inv(uint32_t &X, uint32_t &Y, uint32_t wM, const Mod &md) {
     const uint32_t s = X + Y;
     const uint32_t t = X + md.p2 - Y;
-    X = min(s, s - md.p2);
+    X = condsub(s, md.p2);
     Y = mont_lazy(t, wM, md);
 }
 

@@ -14,7 +14,7 @@
         for (int i = 0; i < ITER; i++) {                                            \
             asm volatile(ASM(0) ASM(1) ASM(2) ASM(3) ASM(4) ASM(5) ASM(6) ASM(7)   \
                          : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) \
-                         : "v"(b));                                                 \
+                         : "v"(b) : "vcc");                                                 \
         }                                                                           \
         out[blockIdx.x * 256 + threadIdx.x] = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7; \
     }
@@ -42,6 +42,28 @@ KERNEL(k_sub, A_SUB)
 KERNEL(k_xor, A_XOR)
 KERNEL(k_lshladd, A_LSHLADD)
 KERNEL(k_add3, A_ADD3)
+#define A_CNDMASK(i) "v_cndmask_b32 %" #i ", %" #i ", %8, vcc\n"
+#define A_SUBCO(i) "v_sub_co_u32 %" #i ", vcc, %" #i ", %8\n"
+#define A_CMP(i) "v_cmp_lt_u32 vcc, %" #i ", %8\nv_add_u32 %" #i ", %" #i ", %8\n"
+#define A_MAX(i) "v_max_u32 %" #i ", %" #i ", %8\n"
+#define A_MINI(i) "v_min_i32 %" #i ", %" #i ", %8\n"
+#define A_LSHR(i) "v_lshrrev_b32 %" #i ", 1, %" #i "\n"
+#define A_ANDOR(i) "v_and_or_b32 %" #i ", %" #i ", %8, %8\n"
+#define A_ADDCO(i) "v_add_co_u32 %" #i ", vcc, %" #i ", %8\n"
+#define A_SUBCND(i) "v_sub_co_u32 %" #i ", vcc, %" #i ", %8\nv_cndmask_b32 %" #i ", %" #i ", %8, vcc\n"
+#define A_SUBMIN(i) "v_sub_u32 %" #i ", %" #i ", %8\nv_min_u32 %" #i ", %" #i ", %8\n"
+#define A_MULLOHI(i) "v_mul_lo_u32 %" #i ", %" #i ", %8\nv_mul_hi_u32 %" #i ", %" #i ", %8\n"
+KERNEL(k_cndmask, A_CNDMASK)
+KERNEL(k_subco, A_SUBCO)
+KERNEL(k_cmp_add, A_CMP)
+KERNEL(k_max, A_MAX)
+KERNEL(k_mini, A_MINI)
+KERNEL(k_lshr, A_LSHR)
+KERNEL(k_andor, A_ANDOR)
+KERNEL(k_addco, A_ADDCO)
+KERNEL(k_subco_cnd, A_SUBCND)
+KERNEL(k_sub_min, A_SUBMIN)
+KERNEL(k_mullo_hi, A_MULLOHI)
 
 // 64-bit forms
 __global__ void __launch_bounds__(256) k_mad64(uint32_t *out, uint32_t seed) {
@@ -103,10 +125,11 @@ int main() {
     int blocks = cus * 8;  // 8 x 256 threads per CU = 8 waves per SIMD
     uint32_t *d; hipMalloc(&d, (size_t)blocks * 256 * 4);
     double lane_ops = (double)blocks * 256 * ITER * 8;
-    struct { const char *name; double ms; } res[16]; int n = 0;
+    struct { const char *name; double ms; } res[40]; int n = 0;
 #define RUN(K) res[n].name = #K; res[n].ms = run(K, d, blocks); n++;
     RUN(k_add) RUN(k_sub) RUN(k_min) RUN(k_xor) RUN(k_lshladd) RUN(k_add3) RUN(k_mullo) RUN(k_mulhi)
     RUN(k_mul24) RUN(k_mulhi24) RUN(k_mad24) RUN(k_mad64) RUN(k_fma32) RUN(k_fma64)
+    RUN(k_cndmask) RUN(k_subco) RUN(k_cmp_add) RUN(k_max) RUN(k_mini) RUN(k_lshr) RUN(k_andor) RUN(k_addco) RUN(k_subco_cnd) RUN(k_sub_min) RUN(k_mullo_hi)
     for (int i = 0; i < n; i++) {
         double rate = lane_ops / (res[i].ms * 1e-3);                 // lane-ops / s
         double per_cu_clk = rate / cus / (prop.clockRate * 1e3);    // at nominal clock
