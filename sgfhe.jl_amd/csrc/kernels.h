@@ -224,16 +224,29 @@ k_extprod(const uint64_t *__restrict__ dig, const uint32_t *__restrict__ keyk,
         }
         lds_store<LOGM, 1, LOGE, G::STOP>(z0, lds, tid);
         SGFHE_SYNC();
+        // Source index of output coefficient i = tid + T e is s_e = (i - j) mod 2m = s_0 + T e:
+        // the swizzled low part is computed once per thread.  Residues leave in [0, p]
+        // (p == 0 mod p: k_crt_acc's alpha estimate absorbs it exactly).
+        {
+            constexpr uint32_t LOWMASK = (1u << G::STOP) - 1u;
+            const uint32_t s0 = ((uint32_t)tid - j) & (2 * M - 1);
+            const uint32_t lowswz = swz<LOGE>(s0 & LOWMASK);
+            const uint32_t h0 = s0 >> G::STOP;
 #pragma unroll
-        for (int e = 0; e < E; e++) {
-            const uint32_t i = tid + T * e;
-            const uint32_t s = (i - j) & (2 * M - 1);
-            uint32_t v = lds[swz<LOGE>(s & (M - 1))];
-            if (s & M) v = csub(p - v, p);  // x^m = -1
-            uint32_t y = v - z0[0][e];
-            y = min(y, y + p);
-            if (P.hoff) y = csub(y + P.hoff, p);  // wave-uniform: only the last prime
-            yb[(size_t)c * NPR * M + i] = y;
+            for (int e = 0; e < E; e++) {
+                const uint32_t he = h0 + e;
+                const uint32_t hipart = (he & (E - 1)) << G::STOP;
+                // swz is XOR-linear; for m = 8192 the e bits lie above every bit it reads
+                const uint32_t addr =
+                    hipart ^ lowswz ^ (G::STOP >= 9 ? 0u : swz_bits<LOGE>(hipart));
+                const uint32_t v = lds[addr];
+                const uint32_t vs = (he & E) ? p - v : v;  // x^m = -1
+                uint32_t d;
+                const bool borrow = __builtin_usub_overflow(vs, z0[0][e], &d);
+                uint32_t y = borrow ? d + p : d;           // [0, p]
+                if (P.hoff) y = condsub(y + P.hoff, p);    // wave-uniform: only the last prime
+                yb[(size_t)c * NPR * M + tid + T * e] = y;
+            }
         }
     }
 }
