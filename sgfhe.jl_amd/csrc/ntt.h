@@ -172,6 +172,22 @@ __device__ __forceinline__ uint32_t opaque_zero() {
     return z;
 }
 
+// Synchronisation of the exchange between the layouts S = SLOW + LOGE and S = SLOW.  The exchange
+// between S = LOGE and S = 0 moves data only inside aligned groups of 2^LOGE consecutive threads
+// (thread (hi, lo) <-> thread (hi, e)), i.e. inside one wavefront: the LDS queue of a wave is
+// in order, so no workgroup barrier is needed, only that the compiler keeps the stores ahead of
+// the loads (they may alias, so it does).
+template <int LOGE, int SLOW>
+__device__ __forceinline__ void exchange_sync() {
+    if constexpr (SLOW == 0 && (1 << LOGE) <= 64) {
+#ifndef SGFHE_ABL_NO_BARRIER
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+#endif
+    } else {
+        SGFHE_SYNC();
+    }
+}
+
 // forward LDS passes S = SCUR, SCUR - LOGE, ..., 0; data arrives in registers in layout SPREV
 template <int LOGM, int NP, int LOGE, int SPREV, int SCUR>
 struct FwdPasses {
@@ -180,7 +196,7 @@ struct FwdPasses {
         uint32_t t[(1 << LOGE) - 1];
         load_twiddles<LOGM, LOGE, SCUR, LOGE - 1, 0>(t, tw + opaque_zero(), (uint32_t)tid >> SCUR);
         lds_store<LOGM, NP, LOGE, SPREV>(x, lds, tid);
-        SGFHE_SYNC();
+        exchange_sync<LOGE, SCUR>();
         lds_load<LOGM, NP, LOGE, SCUR>(x, lds, tid);
         fwd_stages<NP, LOGE, LOGE - 1, 0>(x, t, md);
         if constexpr (SCUR >= LOGE)
@@ -200,7 +216,7 @@ struct InvPasses {
             load_twiddles<LOGM, LOGE, SCUR + LOGE, LOGE - 1, 0>(tn, tw + opaque_zero(),
                                                                 (uint32_t)tid >> (SCUR + LOGE));
             lds_store<LOGM, NP, LOGE, SCUR>(x, lds, tid);
-            SGFHE_SYNC();
+            exchange_sync<LOGE, SCUR>();
             lds_load<LOGM, NP, LOGE, SCUR + LOGE>(x, lds, tid);
             InvPasses<LOGM, NP, LOGE, SCUR + LOGE, SLAST>::run(x, lds, tw, tid, md, tn);
         }
