@@ -55,6 +55,11 @@ struct CrtConst {
     u128 halfQ;          // Q / 2 (centred lift of key residues)
     u128 roundthr;       // Q / 2 + (Q odd)        (utils.jl:84)
     double invQ, invB;
+    // 32-bit limb / double views of the same constants for k_crt_acc's 96-bit arithmetic
+    uint32_t c32[NPR][3];
+    uint32_t Q32[3];
+    alignas(16) uint32_t T32[NPR + 1][4];
+    double cd[NPR], Td[NPR + 1], Bd;
     float invp[NPR];
     uint32_t logr;
     ulonglong2 dig0, digP, digN;  // (lo, hi) digits of x' for acc = 0, DQ_tilde, Q - DQ_tilde
@@ -87,13 +92,6 @@ __device__ __forceinline__ u128 mod_wide(u128 x, u128 d, double inv, uint64_t *q
     return r;
 }
 
-// ---- digit -> residue ------------------------------------------------------------------------
-// (e - s) * R^-1 mod p, lazily in [0, 4p), for a raw digit e in [0, B), B < 2^62:
-// REDC(e) < e / 2^32 + p < 2^30 + p, plus the constant p - s R^-1.
-__device__ __forceinline__ uint32_t digit_reduce(uint64_t e, const PrimeK &P) {
-    return redc_mad(e, P.p, P.ninv) + P.sR;
-}
-
 // ---- digit planes ---------------------------------------------------------------------------------
 // dig[bootstrap][c][digit][coef] (uint64): digit 0 = lo, digit 1 = hi of x' for acc_a (c = 0) and
 // acc_b (c = 1).  Plane p = 2 c + digit is the p-th row of u = [a_lo, a_hi, b_lo, b_hi]
@@ -106,6 +104,13 @@ __device__ __forceinline__ void store_digits(uint64_t *__restrict__ dig, size_t 
                                              uint32_t M, uint64_t lo, uint64_t hi) {
     dig[(bc * 2 + 0) * M + i] = lo;
     dig[(bc * 2 + 1) * M + i] = hi;
+}
+
+// ---- digit -> residue ------------------------------------------------------------------------
+// (e - s) * R^-1 mod p, lazily in [0, 4p), for a raw digit e in [0, B), B < 2^62:
+// REDC(e) < e / 2^32 + p < 2^30 + p, plus the constant p - s R^-1.
+__device__ __forceinline__ uint32_t digit_reduce(uint64_t e, const PrimeK &P) {
+    return redc_mad(e, P.p, P.ninv) + P.sR;
 }
 
 // ---- k_extprod ----------------------------------------------------------------------------------
@@ -255,8 +260,23 @@ k_extprod(const uint64_t *__restrict__ dig, const uint32_t *__restrict__ keyk,
 // One thread per (bootstrap, c, coefficient).  With y'_i = (D + H') (M/p_i)^-1 mod p_i:
 //   D + H' = sum_i y'_i (M/p_i) - alpha M,  alpha = floor(sum_i y'_i / p_i)
 // and |D| <= M / 8 (checked at ctx creation) puts the fractional part of the sum within
-// 0.5 +- 0.125, so alpha is exact in float.  Then x'_new = (x'_old + D) mod Q and the new
-// digits are (x'_new mod B, x'_new / B)  (flatten, utils.jl:155-189).
+// 0.5 +- 0.125, so alpha is exact in float (residues may be p_i instead of 0: the identity holds
+// for any non-negative representatives).  Then x'_new = (x'_old + D) mod Q and the new digits are
+// (x'_new mod B, x'_new / B)  (flatten, utils.jl:155-189).
+//
+// Arithmetic: S = sum_i y'_i c_i + T[alpha] + x'_old < 2^33 Q.  Its quotient by Q is estimated in
+// double precision (error < 1), the remainder is formed modulo 2^96 in three 32-bit limbs
+// (v_mad_u64_u32 chains) and corrected by at most one +-Q; same scheme for the division by B.
+struct U96 {
+    uint32_t w0, w1, w2;
+};
+__device__ __forceinline__ void mad96(U96 &a, uint32_t y, const uint32_t (&c)[3]) {
+    const uint64_t p0 = (uint64_t)y * c[0] + a.w0;
+    const uint64_t p1 = (uint64_t)y * c[1] + a.w1 + (p0 >> 32);
+    a.w0 = (uint32_t)p0;
+    a.w1 = (uint32_t)p1;
+    a.w2 = y * c[2] + a.w2 + (uint32_t)(p1 >> 32);
+}
 __global__ void __launch_bounds__(256)
 k_crt_acc(const uint32_t *__restrict__ yres, uint64_t *__restrict__ dig,
           const CrtConst *__restrict__ CC, uint32_t total, uint32_t logm, uint32_t mode) {
@@ -264,32 +284,79 @@ k_crt_acc(const uint32_t *__restrict__ yres, uint64_t *__restrict__ dig,
     if (t >= total) return;
     const uint32_t M = 1u << logm;
     const uint32_t i = t & (M - 1);
-    const uint32_t bc = t >> logm;
-    const uint32_t *yp = yres + (size_t)bc * NPR * M + i;
+    const size_t bc = t >> logm;
+    const uint32_t *yp = yres + bc * NPR * M + i;
     uint32_t y[NPR];
     float f = 0.f;
+    double Sd = 0.0;
 #pragma unroll
     for (int q = 0; q < NPR; q++) {
         y[q] = yp[(size_t)q * M];
         f += (float)y[q] * CC->invp[q];
+        Sd += (double)y[q] * CC->cd[q];
     }
     const int alpha = (int)f;
-    u128 S = CC->T[alpha];
+    const uint4 tv = *reinterpret_cast<const uint4 *>(CC->T32[alpha]);
+    U96 a = {tv.x, tv.y, tv.z};
+    Sd += CC->Td[alpha];
 #pragma unroll
-    for (int q = 0; q < NPR; q++) S += mul_u64_u128(y[q], CC->c[q]);
-    const u128 B = CC->B;
+    for (int q = 0; q < NPR; q++) mad96(a, y[q], CC->c32[q]);
+    const uint64_t B = (uint64_t)CC->B;
     if (!(mode & MODE_NOACC)) {
-        const ulonglong2 d = load_digits(dig, bc, i, M);
-        S += (u128)d.y * (uint64_t)B + d.x;
+        const ulonglong2 d = load_digits(dig, bc, i, M);  // x'_old = hi B + lo
+        const uint32_t h0 = (uint32_t)d.y, h1 = (uint32_t)(d.y >> 32);
+        const uint32_t b0 = (uint32_t)B, b1 = (uint32_t)(B >> 32);
+        const uint64_t p0 = (uint64_t)h0 * b0 + a.w0 + (uint32_t)d.x;
+        const uint64_t p1 = (uint64_t)h0 * b1 + (uint64_t)h1 * b0 + a.w1 + (uint32_t)(d.x >> 32) + (p0 >> 32);
+        a.w0 = (uint32_t)p0;
+        a.w1 = (uint32_t)p1;
+        a.w2 += h1 * b1 + (uint32_t)(p1 >> 32);
+        Sd += (double)d.y * CC->Bd + (double)d.x;
     }
-    const u128 xn = mod_wide(S, CC->Q, CC->invQ, nullptr);
+    // subtract q1 Q, q1 = floor(S / Q) +- 1
+    {
+        const uint64_t q1 = (uint64_t)(Sd * CC->invQ);
+        const uint32_t qa = (uint32_t)q1, qb = (uint32_t)(q1 >> 32);
+        const uint64_t m0 = (uint64_t)qa * CC->Q32[0];
+        const uint64_t m1 = (uint64_t)qa * CC->Q32[1] + (uint64_t)qb * CC->Q32[0] + (m0 >> 32);
+        const uint32_t m2 = qa * CC->Q32[2] + qb * CC->Q32[1] + (uint32_t)(m1 >> 32);
+        const uint64_t r0 = (uint64_t)a.w0 - (uint32_t)m0;
+        const uint64_t r1 = (uint64_t)a.w1 - (uint32_t)m1 - ((r0 >> 32) & 1u);
+        a.w2 = a.w2 - m2 - (uint32_t)((r1 >> 32) & 1u);
+        a.w0 = (uint32_t)r0;
+        a.w1 = (uint32_t)r1;
+    }
+    // the remainder is in (-Q, 2Q) modulo 2^96: one correction
+    {
+        const uint64_t Qlo = ((uint64_t)CC->Q32[1] << 32) | CC->Q32[0];
+        const uint32_t Qhi = CC->Q32[2];
+        uint64_t lo = ((uint64_t)a.w1 << 32) | a.w0;
+        uint32_t hi = a.w2;
+        if ((int32_t)hi < 0) {  // negative: add Q
+            const uint64_t nlo = lo + Qlo;
+            hi = hi + Qhi + (nlo < lo);
+            lo = nlo;
+        } else if (hi > Qhi || (hi == Qhi && lo >= Qlo)) {
+            const uint64_t nlo = lo - Qlo;
+            hi = hi - Qhi - (lo < Qlo);
+            lo = nlo;
+        }
+        a.w0 = (uint32_t)lo;
+        a.w1 = (uint32_t)(lo >> 32);
+        a.w2 = hi;
+    }
+    const uint64_t xlo = ((uint64_t)a.w1 << 32) | a.w0;
     if (mode & MODE_CANON) {  // canonical residues, interleaved {lo, hi} words
-        reinterpret_cast<ulonglong2 *>(dig)[t] = make_ulonglong2((uint64_t)xn, (uint64_t)(xn >> 64));
+        reinterpret_cast<ulonglong2 *>(dig)[t] = make_ulonglong2(xlo, (uint64_t)a.w2);
         return;
     }
-    uint64_t hi;
-    const u128 lo = mod_wide(xn, B, CC->invB, &hi);
-    store_digits(dig, bc, i, M, (uint64_t)lo, hi);
+    // digits: hi = x' / B (double estimate +- 1), lo = x' - hi B (exact modulo 2^64)
+    const double xd = (double)a.w2 * 18446744073709551616.0 + (double)xlo;
+    uint64_t hq = (uint64_t)(xd * CC->invB);
+    int64_t lo = (int64_t)(xlo - hq * B);
+    if (lo < 0) { lo += (int64_t)B; hq--; }
+    else if ((uint64_t)lo >= B) { lo -= (int64_t)B; hq++; }
+    store_digits(dig, bc, i, M, (uint64_t)lo, hq);
 }
 
 // ---- k_init -------------------------------------------------------------------------------------
