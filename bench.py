@@ -63,6 +63,17 @@ def algorithmic_bytes_per_bootstrap(p, W, batch):
     return p.n * p.m * W * (4 + 8.0 / batch) + 40 * (p.n + 1)
 
 
+def measured_traffic(config, chunk):
+    """HBM bytes per k_extprod launch from the committed rocprofv3 PMC passes (FETCH_SIZE and
+    WRITE_SIZE are collected in separate profiler runs, not inside this process): see
+    profiles/r01_v2_hbm_traffic.json.  None unless the profile matches this workload."""
+    path = os.path.join(ROOT, "profiles", "r01_v2_hbm_traffic.json")
+    if config != "params1024" or chunk != 256 or not os.path.exists(path):
+        return None
+    with open(path) as f:
+        return json.load(f)["kernels"]["k_extprod"]["traffic_bytes_per_launch"]
+
+
 def cpu_baseline(p, key, seconds_target=15.0):
     """Oracle 'port' (oracle/sgfhe_oracle.c: reference-shaped, 128-bit Montgomery, 24 NTTs per
     iteration) timed on one host core over a truncated k-loop of ONE bootstrap, scaled to a full
@@ -206,7 +217,7 @@ def main():
                        "key_broadcast_s": round(bcast_s, 4)},
             "roofline": {"bound": "hbm", "kernel": "k_extprod", "achieved": achieved,
                          "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": achieved / PEAK_HBM_GBS,
-                         "traffic": None,
+                         "traffic": measured_traffic(args.config, chunk),
                          "launch_ms": tm["extprod_ms"], "launch_samples": tm["extprod_samples"],
                          "algorithmic_bytes_per_launch": launch_bytes,
                          "pair_kernel": "k_crt_acc", "pair_launch_ms": tm["crt_ms"],
