@@ -124,6 +124,19 @@ int32_t sgfhe_sync(sgfhe_ctx *ctx);
 int32_t sgfhe_external_product(sgfhe_ctx *ctx, const uint64_t *a, const uint64_t *b,
                                const uint64_t *A, uint64_t *a_res, uint64_t *b_res);
 
+/*
+ * pack_encrypted_bits(bkey, nothing, enc_bits) (src/fhe.jl:660-696, with
+ * shortened_external_product :632-641): `count` groups of n LWEs each -> `count` RLWE
+ * ciphertexts over Z_r.
+ *   a : [count][n][n] uint64, b : [count][n] uint64   (the n EncryptedBits of every group)
+ *   out_w, out_v : [count][m] uint64 in [0, r)         (Ciphertext.rlwe.a / .b coefficients)
+ * Runs count * n gate bootstraps (trivial encryption of 1 paired with every bit, AND branch,
+ * un-reduced), then the n half-width external products against the key on the device.
+ * Host pointers; synchronous.
+ */
+int32_t sgfhe_pack_encrypted_bits(sgfhe_ctx *ctx, const uint64_t *a, const uint64_t *b,
+                                  size_t count, uint64_t *out_w, uint64_t *out_v);
+
 /* Parity / debug hook: run the first n_iters iterations of the k-loop (src/fhe.jl:579-582) and
  * return the accumulator pair (a, b) as canonical residues, acc: [batch][2][m][2]. */
 int32_t sgfhe_debug_accumulators(sgfhe_ctx *ctx, const uint64_t *a1, const uint64_t *b1,

@@ -404,3 +404,73 @@ def rns2_to_int(v1, v2, m1, m2):
     c1 = pow(m2, m1 - 1, m)
     c2 = pow(m1, m2 - 1, m)
     return (v1 * c1 + v2 * c2) % m
+
+
+# ----------------------------------------------------------------------------------------------
+# Packing LWEs into an RLWE ciphertext (second caller of the hot path)
+# ----------------------------------------------------------------------------------------------
+
+def shortened_external_product(a, A, B, ell, Q):
+    """src/fhe.jl:632-641: flatten(a) * A[l+1:2l, :]."""
+    u = flatten_poly(a, B, ell, Q)                                        # fhe.jl:637
+    N = len(a)
+    a_res = [0] * N
+    b_res = [0] * N
+    for i in range(ell):
+        a_res = poly_add(a_res, poly_mul(u[i], A[ell + i][0], Q), Q)      # fhe.jl:638
+        b_res = poly_add(b_res, poly_mul(u[i], A[ell + i][1], Q), Q)      # fhe.jl:639
+    return a_res, b_res
+
+
+def reduce_modulus_poly(new_modulus, poly, old_modulus):
+    """src/utils.jl:120-127."""
+    return [reduce_modulus(new_modulus, x, old_modulus) for x in poly]
+
+
+def pack_encrypted_bits(p, bkey, enc_bits):
+    """src/fhe.jl:660-696 (rng = nothing).  enc_bits: n LWEs (a, b) over Z_r.
+    Returns the RLWE (w, v) over Z_r, two lists of m coefficients."""
+    Q = p.Q
+    assert len(enc_bits) == p.n                                           # fhe.jl:667
+    enc_trivial = ([0] * p.n, p.Dr)                                       # fhe.jl:669-671
+    new_lwes = [bootstrap_internal(p, bkey, enc_trivial, eb)[0] for eb in enc_bits]   # fhe.jl:673
+    as_ = [resize([new_lwes[j][0][i] for j in range(p.n)], p.m) for i in range(p.n)]  # :675-677
+    b = resize([lw[1] for lw in new_lwes], p.m)                           # fhe.jl:678
+    w_tilde = [0] * p.m
+    v_tilde = [0] * p.m
+    for i in range(p.n):                                                  # fhe.jl:683-687
+        w, v = shortened_external_product(as_[i], bkey[i], p.B, p.ell, Q)
+        w_tilde = poly_add(w_tilde, w, Q)
+        v_tilde = poly_add(v_tilde, v, Q)
+    w1 = [(Q - x) % Q for x in w_tilde]                                   # fhe.jl:689
+    v1 = poly_sub(b, v_tilde, Q)                                          # fhe.jl:690
+    return reduce_modulus_poly(p.r, w1, Q), reduce_modulus_poly(p.r, v1, Q)   # fhe.jl:692-693
+
+
+def poly_mul_mod_pow2(a, b, r):
+    """Exact negacyclic product over Z_r (r a power of two), schoolbook on the sparse key."""
+    N = len(a)
+    out = [0] * N
+    for i, y in enumerate(b):
+        if y == 0:
+            continue
+        for j, x in enumerate(a):
+            k = i + j
+            if k < N:
+                out[k] = (out[k] + x * y) % r
+            else:
+                out[k - N] = (out[k - N] - x * y) % r
+    return out
+
+
+def decrypt_ciphertext(p, sk, w, v):
+    """decrypt(key, ::Ciphertext) (src/fhe.jl:471-494): first n coefficients of b - key * a."""
+    key_poly = resize(sk, p.m)                                            # fhe.jl:475
+    prod = poly_mul_mod_pow2(w, key_poly, p.r)
+    b1 = [(x - y) % p.r for x, y in zip(v, prod)][:p.n]                   # fhe.jl:479-482
+    return [((x + p.Dr // 2) % p.r) // p.Dr for x in b1]                  # fhe.jl:491-493
+
+
+def split_ciphertext(p, w, v):
+    """split_ciphertext(::Ciphertext) (src/fhe.jl:287-290): n LWEs from a length-m RLWE."""
+    return [([x % p.r for x in extract(w, i, p.n, p.r)], v[i - 1]) for i in range(1, p.n + 1)]

@@ -56,6 +56,8 @@ def lib():
         L.sgo_bootstrap_batch.argtypes = [ctypes.c_void_p, _u64p, _u64p, _u64p, _u64p, _u64p,
                                           ctypes.c_size_t, _u64p, ctypes.c_int, ctypes.c_uint64,
                                           _u64p, ctypes.c_int]
+        L.sgo_pack_encrypted_bits.argtypes = [ctypes.c_void_p, _u64p, _u64p, _u64p, _u64p, _u64p,
+                                              ctypes.c_int]
         _lib = L
     return _lib
 
@@ -205,6 +207,23 @@ class Oracle:
         if rc:
             raise RuntimeError("sgo_bootstrap_batch failed: %d" % rc)
         return (out, acc) if want_acc else out
+
+
+def _pack(self, bkey, a, b, threads=None):
+    """fhe.jl:660-696: n LWEs (a [n][n], b [n]) -> RLWE (w, v) over Z_r, [m] each."""
+    bkey = np.ascontiguousarray(bkey, dtype=np.uint64)
+    a = np.ascontiguousarray(a, dtype=np.uint64).reshape(self.n, self.n)
+    b = np.ascontiguousarray(b, dtype=np.uint64).reshape(self.n)
+    w = np.zeros(self.m, dtype=np.uint64)
+    v = np.zeros(self.m, dtype=np.uint64)
+    rc = lib().sgo_pack_encrypted_bits(self._ctx, _p(bkey), _p(a), _p(b), _p(w), _p(v),
+                                       threads or os.cpu_count() or 1)
+    if rc:
+        raise RuntimeError("sgo_pack_encrypted_bits failed: %d" % rc)
+    return w, v
+
+
+Oracle.pack_encrypted_bits = _pack
 
 
 def rescale(new_max, x, old_max, round_result):

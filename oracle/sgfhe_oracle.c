@@ -572,3 +572,84 @@ int sgo_bootstrap_batch(const sgo_ctx *c, const uint64_t *bkey, const uint64_t *
     }
     return rc;
 }
+
+/* ---------------------------------------------------------------- packing */
+
+/* fhe.jl:632-641: flatten(a) * A[l+1:2l, :]; A is the 4x2 slice [4][2][m]. */
+static void shortened_external_product(const sgo_ctx *c, const u128 *a, const u128 *A, u128 *a_res,
+                                       u128 *b_res, u128 *scratch /* 3 m */) {
+    size_t m = c->m;
+    u128 Q = c->Q;
+    u128 *u = scratch, *prod = scratch + 2 * m;
+    for (size_t i = 0; i < m; i++) flatten2(c, a[i], &u[i], &u[m + i]);          /* fhe.jl:637 */
+    memset(a_res, 0, m * sizeof(u128));
+    memset(b_res, 0, m * sizeof(u128));
+    for (int i = 0; i < 2; i++) {
+        poly_mul(c, u + i * m, A + (size_t)((2 + i) * 2 + 0) * m, prod);          /* fhe.jl:638 */
+        for (size_t k = 0; k < m; k++) a_res[k] = addmod(a_res[k], prod[k], Q);
+        poly_mul(c, u + i * m, A + (size_t)((2 + i) * 2 + 1) * m, prod);          /* fhe.jl:639 */
+        for (size_t k = 0; k < m; k++) b_res[k] = addmod(b_res[k], prod[k], Q);
+    }
+}
+
+/* fhe.jl:660-696 with rng = nothing.  a: [n][n] LWE vectors over Z_r, b: [n]; w, v: [m] words in
+ * [0, r).  Returns 0 on success. */
+int sgo_pack_encrypted_bits(const sgo_ctx *c, const uint64_t *bkey, const uint64_t *a,
+                            const uint64_t *b, uint64_t *w, uint64_t *v, int threads) {
+    size_t n = c->n, m = c->m;
+    u128 Q = c->Q;
+    int rc = 0;
+    u128 *raw = (u128 *)malloc(n * (n + 1) * sizeof(u128)); /* AND LWE of every bit: a[0..n), b */
+    uint64_t *zeros = (uint64_t *)calloc(n, sizeof(uint64_t));
+    u128 *wt = (u128 *)calloc(m, sizeof(u128)), *vt = (u128 *)calloc(m, sizeof(u128));
+    if (!raw || !zeros || !wt || !vt) return -1;
+    /* fhe.jl:669-673: bootstrap(trivial 1, bit_i), AND branch, un-reduced */
+#pragma omp parallel for num_threads(threads > 0 ? threads : 1) schedule(dynamic)
+    for (long t = 0; t < (long)n; t++) {
+        u128 *out3 = (u128 *)malloc(3 * (n + 1) * sizeof(u128));
+        int r1 = bootstrap_one(c, (const u128 *)bkey, zeros, c->Dr, a + (size_t)t * n, b[t], n, out3,
+                               NULL);
+        if (r1) {
+#pragma omp atomic write
+            rc = r1;
+        } else {
+            memcpy(raw + (size_t)t * (n + 1), out3, (n + 1) * sizeof(u128));
+        }
+        free(out3);
+    }
+    if (rc == 0) {
+        /* fhe.jl:675-687 */
+#pragma omp parallel num_threads(threads > 0 ? threads : 1)
+        {
+            u128 *as = (u128 *)calloc(m, sizeof(u128));
+            u128 *ar = (u128 *)malloc(2 * m * sizeof(u128));
+            u128 *scratch = (u128 *)malloc(3 * m * sizeof(u128));
+            u128 *wl = (u128 *)calloc(m, sizeof(u128)), *vl = (u128 *)calloc(m, sizeof(u128));
+#pragma omp for schedule(dynamic)
+            for (long i = 0; i < (long)n; i++) {
+                for (size_t j = 0; j < n; j++) as[j] = raw[j * (n + 1) + (size_t)i];   /* :676 */
+                shortened_external_product(c, as, (const u128 *)bkey + (size_t)i * 8 * m, ar, ar + m,
+                                           scratch);
+                for (size_t k = 0; k < m; k++) {
+                    wl[k] = addmod(wl[k], ar[k], Q);
+                    vl[k] = addmod(vl[k], ar[m + k], Q);
+                }
+            }
+#pragma omp critical
+            for (size_t k = 0; k < m; k++) {
+                wt[k] = addmod(wt[k], wl[k], Q);
+                vt[k] = addmod(vt[k], vl[k], Q);
+            }
+            free(as); free(ar); free(scratch); free(wl); free(vl);
+        }
+        for (size_t k = 0; k < m; k++) {
+            u128 w1 = wt[k] ? Q - wt[k] : 0;                                     /* fhe.jl:689 */
+            u128 bk = k < n ? raw[k * (n + 1) + n] : 0;                          /* fhe.jl:678 */
+            u128 v1 = submod(bk, vt[k], Q);                                      /* fhe.jl:690 */
+            w[k] = (uint64_t)rescale(c->r, w1, Q, 1);                            /* fhe.jl:692-693 */
+            v[k] = (uint64_t)rescale(c->r, v1, Q, 1);
+        }
+    }
+    free(raw); free(zeros); free(wt); free(vt);
+    return rc;
+}

@@ -75,6 +75,11 @@ int sgo_bootstrap_batch(const sgo_ctx *ctx, const uint64_t *bkey, const uint64_t
                         const uint64_t *b1, const uint64_t *a2, const uint64_t *b2, size_t batch,
                         uint64_t *out, int raw, uint64_t n_iters, uint64_t *acc_out, int threads);
 
+/* fhe.jl:660-696 pack_encrypted_bits(bkey, nothing, enc_bits): a [n][n], b [n] over Z_r ->
+ * RLWE (w, v), [m] words in [0, r) each. */
+int sgo_pack_encrypted_bits(const sgo_ctx *ctx, const uint64_t *bkey, const uint64_t *a,
+                            const uint64_t *b, uint64_t *w, uint64_t *v, int threads);
+
 #ifdef __cplusplus
 }
 #endif

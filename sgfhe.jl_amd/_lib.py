@@ -74,6 +74,7 @@ def lib():
         "sgfhe_bootstrap_batch_device": (i32, [vp, vp, vp, vp, vp, sz, vp, u32, vp]),
         "sgfhe_sync": (i32, [vp]),
         "sgfhe_external_product": (i32, [vp, vp, vp, vp, vp, vp]),
+        "sgfhe_pack_encrypted_bits": (i32, [vp, vp, vp, sz, vp, vp]),
         "sgfhe_debug_accumulators": (i32, [vp, vp, vp, vp, vp, sz, u64, vp]),
         "sgfhe_debug_ntt": (i32, [vp, u32, ctypes.c_int, vp, vp]),
         "sgfhe_debug_primes": (i32, [vp, _u32p, _u32p]),
@@ -93,5 +94,5 @@ EXPORTED_SYMBOLS = (
     "sgfhe_set_chunk", "sgfhe_set_lanes", "sgfhe_bkey_upload", "sgfhe_bkey_upload_rns2",
     "sgfhe_bkey_device_form_bytes", "sgfhe_bkey_export_device_form",
     "sgfhe_bkey_import_device_form", "sgfhe_bootstrap_batch", "sgfhe_bootstrap_batch_device",
-    "sgfhe_sync", "sgfhe_external_product", "sgfhe_debug_accumulators", "sgfhe_debug_ntt",
+    "sgfhe_sync", "sgfhe_external_product", "sgfhe_pack_encrypted_bits", "sgfhe_debug_accumulators", "sgfhe_debug_ntt",
     "sgfhe_debug_primes", "sgfhe_timing_enable", "sgfhe_timing_read")

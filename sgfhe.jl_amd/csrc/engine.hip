@@ -80,6 +80,7 @@ struct sgfhe_ctx {
     CrtConst *d_crt = nullptr;
     uint32_t *d_tw = nullptr;  // NPR * 2 * M entries
     CrtConst h_crt;
+    uint32_t pack_G = 1;  // key slices per exact-accumulation group of the packing path
     // key
     uint32_t *d_key = nullptr;
     size_t key_bytes = 0;
@@ -145,6 +146,31 @@ int32_t launch_extprod(sgfhe_ctx *c, const sgfhe_ctx::Lane &L, const uint32_t *k
                        uint32_t k, uint32_t mode, hipStream_t st) {
     switch (c->logm) {
 #define X(LM) case LM: return launch_extprod_t<LM>(c, L, keyk, cpad, k, mode, st);
+        SGFHE_FOR_LOGM(X)
+#undef X
+    }
+    return fail(c, SGFHE_ERR_UNSUPPORTED, "unsupported log2(m)");
+}
+
+template <int LOGM>
+int32_t launch_shortprod_t(sgfhe_ctx *c, const uint64_t *pdig, uint32_t *yg, uint32_t count,
+                           uint32_t G, uint32_t groups, hipStream_t st) {
+    const size_t lds = lds_bytes(LOGM, 2);
+    static bool attr_done[16] = {};
+    if (!attr_done[c->device & 15]) {
+        HIPCHK(c, hipFuncSetAttribute((const void *)k_shortprod<LOGM>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done[c->device & 15] = true;
+    }
+    hipLaunchKernelGGL(k_shortprod<LOGM>, dim3(count * groups * NPR), dim3(threads_of<LOGM>()), lds,
+                       st, pdig, c->d_key, yg, c->d_primes, c->d_crt, c->n, G, groups);
+    HIPCHK(c, hipGetLastError());
+    return SGFHE_OK;
+}
+int32_t launch_shortprod(sgfhe_ctx *c, const uint64_t *pdig, uint32_t *yg, uint32_t count,
+                         uint32_t G, uint32_t groups, hipStream_t st) {
+    switch (c->logm) {
+#define X(LM) case LM: return launch_shortprod_t<LM>(c, pdig, yg, count, G, groups, st);
         SGFHE_FOR_LOGM(X)
 #undef X
     }
@@ -354,6 +380,15 @@ int32_t build_constants(sgfhe_ctx *c) {
     if (log_need > log_have)
         return fail(c, SGFHE_ERR_UNSUPPORTED,
                     "8 m B Q exceeds the product of the RNS primes (need more primes)");
+
+    // Packing (fhe.jl:683-687): G slices of two digit polynomials each are summed exactly before a
+    // CRT: |sum| <= G m B Q / 2 must stay below M_rns / 8.
+    {
+        const double lg = log_have - (2.0 + logm + u128_log2(B) + u128_log2(Q) + 0.01);
+        uint32_t G = 1;
+        while (G < c->n && (double)(31 - __builtin_clz(2 * G)) <= lg) G *= 2;
+        c->pack_G = G;
+    }
 
     // flatten constants (utils.jl:162-169)
     const u128 s = (B & 1) ? (B - 1) / 2 : B / 2 - 1;
@@ -749,6 +784,59 @@ int32_t sgfhe_external_product(sgfhe_ctx *c, const uint64_t *a, const uint64_t *
     if (e != hipSuccess && rc == SGFHE_OK) rc = fail(c, SGFHE_ERR_HIP, hipGetErrorString(e));
     (void)hipFree(d_A);
     (void)hipFree(d_ab);
+    return rc;
+}
+
+int32_t sgfhe_pack_encrypted_bits(sgfhe_ctx *c, const uint64_t *a, const uint64_t *b, size_t count,
+                                  uint64_t *out_w, uint64_t *out_v) {
+    if (!c || !a || !b || !out_w || !out_v) return SGFHE_ERR_INVALID_ARG;
+    if (count == 0) return SGFHE_OK;
+    if (!c->have_key) return fail(c, SGFHE_ERR_NO_KEY, "no bootstrap key uploaded");
+    (void)hipSetDevice(c->device);
+    const size_t n = c->n, M = c->M;
+    const size_t nb = count * n;  // bootstraps
+    const uint32_t G = c->pack_G, groups = (uint32_t)(n / G);
+    uint64_t *d_lwe = nullptr, *d_pdig = nullptr, *d_wv = nullptr;
+    ulonglong2 *d_raw = nullptr;
+    uint32_t *d_yg = nullptr;
+    hipError_t e = hipSuccess;
+    int32_t rc = SGFHE_OK;
+    do {
+        // [a1 = 0 | a2 | b1 = Dr | b2]: trivial encryption of 1 paired with every bit (fhe.jl:669-673)
+        if ((e = hipMalloc(&d_lwe, (2 * nb * n + 2 * nb) * 8))) break;
+        uint64_t *d_a1 = d_lwe, *d_a2 = d_lwe + nb * n, *d_b1 = d_a2 + nb * n, *d_b2 = d_b1 + nb;
+        if ((e = hipMalloc(&d_raw, nb * 3 * (n + 1) * 16))) break;
+        if ((e = hipMalloc(&d_pdig, count * n * 2 * n * 8))) break;
+        if ((e = hipMalloc(&d_yg, count * groups * 2 * NPR * M * 4))) break;
+        if ((e = hipMalloc(&d_wv, 2 * count * M * 8))) break;
+        if ((e = hipMemsetAsync(d_a1, 0, nb * n * 8, c->stream))) break;
+        std::vector<uint64_t> ones(nb, c->par.r / 4);
+        if ((e = hipMemcpyAsync(d_b1, ones.data(), nb * 8, hipMemcpyHostToDevice, c->stream))) break;
+        if ((e = hipMemcpyAsync(d_a2, a, nb * n * 8, hipMemcpyHostToDevice, c->stream))) break;
+        if ((e = hipMemcpyAsync(d_b2, b, nb * 8, hipMemcpyHostToDevice, c->stream))) break;
+        rc = bootstrap_device(c, d_a1, d_b1, d_a2, d_b2, nb, (uint64_t *)d_raw, SGFHE_FLAG_RAW_MODQ,
+                              c->n, nullptr, c->stream);
+        if (rc) break;
+        const size_t tf = count * n * n;
+        hipLaunchKernelGGL(k_pack_flatten, dim3((unsigned)((tf + 255) / 256)), dim3(256), 0, c->stream,
+                           d_raw, d_pdig, c->d_crt, (uint32_t)count, (uint32_t)n);
+        rc = launch_shortprod(c, d_pdig, d_yg, (uint32_t)count, G, groups, c->stream);
+        if (rc) break;
+        const size_t tw = count * M;
+        hipLaunchKernelGGL(k_pack_finish, dim3((unsigned)((tw + 255) / 256)), dim3(256), 0, c->stream,
+                           d_yg, d_raw, d_wv, d_wv + count * M, c->d_crt, (uint32_t)count,
+                           (uint32_t)n, (uint32_t)c->logm, groups);
+        if ((e = hipGetLastError())) break;
+        if ((e = hipMemcpyAsync(out_w, d_wv, count * M * 8, hipMemcpyDeviceToHost, c->stream))) break;
+        if ((e = hipMemcpyAsync(out_v, d_wv + count * M, count * M * 8, hipMemcpyDeviceToHost, c->stream))) break;
+        e = hipStreamSynchronize(c->stream);
+    } while (0);
+    if (e != hipSuccess && rc == SGFHE_OK) rc = fail(c, SGFHE_ERR_HIP, hipGetErrorString(e));
+    if (d_lwe) (void)hipFree(d_lwe);
+    if (d_raw) (void)hipFree(d_raw);
+    if (d_pdig) (void)hipFree(d_pdig);
+    if (d_yg) (void)hipFree(d_yg);
+    if (d_wv) (void)hipFree(d_wv);
     return rc;
 }
 

@@ -277,21 +277,14 @@ __device__ __forceinline__ void mad96(U96 &a, uint32_t y, const uint32_t (&c)[3]
     a.w1 = (uint32_t)p1;
     a.w2 = y * c[2] + a.w2 + (uint32_t)(p1 >> 32);
 }
-__global__ void __launch_bounds__(256)
-k_crt_acc(const uint32_t *__restrict__ yres, uint64_t *__restrict__ dig,
-          const CrtConst *__restrict__ CC, uint32_t total, uint32_t logm, uint32_t mode) {
-    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
-    if (t >= total) return;
-    const uint32_t M = 1u << logm;
-    const uint32_t i = t & (M - 1);
-    const size_t bc = t >> logm;
-    const uint32_t *yp = yres + bc * NPR * M + i;
-    uint32_t y[NPR];
+// S = sum_i y_i c_i + T[alpha] (+ hi B + lo of the previous digits) reduced modulo Q: the
+// canonical residue of x'_new (or of D when there is no previous accumulator), as three limbs.
+__device__ __forceinline__ U96 crt_reduce(const uint32_t (&y)[NPR], const CrtConst *__restrict__ CC,
+                                          bool have_old, ulonglong2 d) {
     float f = 0.f;
     double Sd = 0.0;
 #pragma unroll
     for (int q = 0; q < NPR; q++) {
-        y[q] = yp[(size_t)q * M];
         f += (float)y[q] * CC->invp[q];
         Sd += (double)y[q] * CC->cd[q];
     }
@@ -301,9 +294,8 @@ k_crt_acc(const uint32_t *__restrict__ yres, uint64_t *__restrict__ dig,
     Sd += CC->Td[alpha];
 #pragma unroll
     for (int q = 0; q < NPR; q++) mad96(a, y[q], CC->c32[q]);
-    const uint64_t B = (uint64_t)CC->B;
-    if (!(mode & MODE_NOACC)) {
-        const ulonglong2 d = load_digits(dig, bc, i, M);  // x'_old = hi B + lo
+    if (have_old) {  // x'_old = hi B + lo
+        const uint64_t B = (uint64_t)CC->B;
         const uint32_t h0 = (uint32_t)d.y, h1 = (uint32_t)(d.y >> 32);
         const uint32_t b0 = (uint32_t)B, b1 = (uint32_t)(B >> 32);
         const uint64_t p0 = (uint64_t)h0 * b0 + a.w0 + (uint32_t)d.x;
@@ -345,12 +337,31 @@ k_crt_acc(const uint32_t *__restrict__ yres, uint64_t *__restrict__ dig,
         a.w1 = (uint32_t)(lo >> 32);
         a.w2 = hi;
     }
+    return a;
+}
+
+__global__ void __launch_bounds__(256)
+k_crt_acc(const uint32_t *__restrict__ yres, uint64_t *__restrict__ dig,
+          const CrtConst *__restrict__ CC, uint32_t total, uint32_t logm, uint32_t mode) {
+    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= total) return;
+    const uint32_t M = 1u << logm;
+    const uint32_t i = t & (M - 1);
+    const size_t bc = t >> logm;
+    const uint32_t *yp = yres + bc * NPR * M + i;
+    uint32_t y[NPR];
+#pragma unroll
+    for (int q = 0; q < NPR; q++) y[q] = yp[(size_t)q * M];
+    const bool have_old = !(mode & MODE_NOACC);
+    const ulonglong2 d = have_old ? load_digits(dig, bc, i, M) : make_ulonglong2(0, 0);
+    const U96 a = crt_reduce(y, CC, have_old, d);
     const uint64_t xlo = ((uint64_t)a.w1 << 32) | a.w0;
     if (mode & MODE_CANON) {  // canonical residues, interleaved {lo, hi} words
         reinterpret_cast<ulonglong2 *>(dig)[t] = make_ulonglong2(xlo, (uint64_t)a.w2);
         return;
     }
     // digits: hi = x' / B (double estimate +- 1), lo = x' - hi B (exact modulo 2^64)
+    const uint64_t B = (uint64_t)CC->B;
     const double xd = (double)a.w2 * 18446744073709551616.0 + (double)xlo;
     uint64_t hq = (uint64_t)(xd * CC->invB);
     int64_t lo = (int64_t)(xlo - hq * B);
@@ -470,6 +481,145 @@ k_flatten_canon(const ulonglong2 *__restrict__ in, uint64_t *__restrict__ dig,
     uint64_t hi;
     const u128 lo = mod_wide(x, CC->B, CC->invB, &hi);
     store_digits(dig, t >> logm, t & (M - 1), M, (uint64_t)lo, hi);
+}
+
+// ==================================================================================================
+// Packing LWEs into an RLWE ciphertext: pack_encrypted_bits / shortened_external_product
+// (src/fhe.jl:632-641,660-696), second caller of the hot path.
+//   1. n bootstraps (trivial encryption of 1, bit_i), AND branch, un-reduced      (k-loop above)
+//   2. k_pack_flatten: as_i = polynomial of the i-th LWE coefficients (fhe.jl:675-677), flattened
+//   3. k_shortprod:   for a group of slices i: sum_i flatten(as_i) * C_i[2:4, :]  in the NTT domain
+//                     (exact integers stay below M / 8 for `G` slices per group), inverse NTT
+//   4. k_pack_finish: CRT of every group, sum mod Q, w = ModRed(-W), v = ModRed(b - V)
+// ==================================================================================================
+
+// raw: [count * n][3][n + 1] 16-byte residues (RAW_MODQ bootstrap output); only gate 0 (AND) is
+// read.  pdig: [count][n slices][2 digits][n coefficients] uint64.
+__global__ void __launch_bounds__(256)
+k_pack_flatten(const ulonglong2 *__restrict__ raw, uint64_t *__restrict__ pdig,
+               const CrtConst *__restrict__ CC, uint32_t count, uint32_t n) {
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (size_t)count * n * n) return;
+    const uint32_t j = (uint32_t)(t % n);           // bit index = coefficient index of as_i
+    const uint32_t i = (uint32_t)((t / n) % n);     // LWE coefficient index = slice
+    const uint32_t ci = (uint32_t)(t / ((size_t)n * n));
+    const ulonglong2 v = raw[(((size_t)ci * n + j) * 3 + 0) * (n + 1) + i];
+    u128 x = (((u128)v.y << 64) | v.x) + (CC->Q - CC->offneg);   // + off
+    if (x >= CC->Q) x -= CC->Q;
+    uint64_t hi;
+    const u128 lo = mod_wide(x, CC->B, CC->invB, &hi);
+    uint64_t *d = pdig + (((size_t)ci * n + i) * 2) * n + j;
+    d[0] = (uint64_t)lo;
+    d[n] = hi;
+}
+
+// grid = count * groups * NPR workgroups of T threads.  Workgroup (ci, g, pi) runs the 2 G phases
+// (slice i in the group, digit) through the forward NTT and accumulates both product columns
+// lazily (mod 2p; z0 in registers, z1 in LDS), then two inverse NTTs.
+//   yg [count][groups][2][NPR][m] residues (+ hoff), in [0, p]
+template <int LOGM>
+__global__ void __launch_bounds__((NttGeom<LOGM, LOGE>::T), (NttGeom<LOGM, LOGE>::T >= 256 ? 4 : 1))
+k_shortprod(const uint64_t *__restrict__ pdig, const uint32_t *__restrict__ keyhat,
+            uint32_t *__restrict__ yg, PrimeSet PS, const CrtConst *__restrict__ CC, uint32_t n,
+            uint32_t G, uint32_t groups) {
+    using GE = NttGeom<LOGM, LOGE>;
+    constexpr int M = GE::M, T = GE::T, E = GE::E;
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const uint32_t pi = blockIdx.x % NPR;
+    const uint32_t g = (blockIdx.x / NPR) % groups;
+    const uint32_t ci = blockIdx.x / (NPR * groups);
+    const PrimeK P = PS[pi];
+    const uint32_t p = P.p;
+    const Mod md = {P.p, P.ninv, 2 * P.p};
+    // residues of the digits of a zero coefficient (x' = off): the zero padding of as_i
+    const uint32_t zlo = digit_reduce(CC->dig0.x, P), zhi = digit_reduce(CC->dig0.y, P);
+
+    uint32_t z0[1][E];
+#pragma unroll
+    for (int e = 0; e < E; e++) { z0[0][e] = 0; lds[M + e * T + threadIdx.x] = 0; }
+#pragma unroll 1
+    for (uint32_t ph = 0; ph < 2 * G; ph++) {
+        const int tid = (int)threadIdx.x + (int)opaque_zero();
+        const uint32_t i = g * G + (ph >> 1), digit = ph & 1;
+        uint32_t x[1][E];
+        const uint64_t *d = pdig + (((size_t)ci * n + i) * 2 + digit) * n;
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+            const uint32_t idx = tid + T * e;
+            x[0][e] = idx < n ? digit_reduce(d[idx], P) : (digit ? zhi : zlo);
+        }
+        SGFHE_SYNC();
+        ntt_forward<LOGM, 1, LOGE>(x, lds, P.twf, tid, md);
+        // key rows l + 1 .. 2 l of slice i (fhe.jl:638-639): polynomials (2 + digit) * 2 + c
+        const uint32_t *kp = keyhat + (((size_t)i * NPR + pi) * 8 + (2 + digit) * 2) * M + E * tid;
+#pragma unroll
+        for (int h = 0; h < E / 4; h++) {
+            const uint4 a = reinterpret_cast<const uint4 *>(kp)[h];
+            const uint4 bq = reinterpret_cast<const uint4 *>(kp + M)[h];
+            const uint32_t ka[4] = {a.x, a.y, a.z, a.w};
+            const uint32_t kb[4] = {bq.x, bq.y, bq.z, bq.w};
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                const int e = 4 * h + t;
+                const uint32_t u = x[0][e];  // [0, 4p): u K < p 2^32
+                z0[0][e] = condsub(z0[0][e] + redc_mad((uint64_t)u * ka[t], p, P.ninv), md.p2);
+                uint32_t *zp = lds + M + e * T + tid;
+                *zp = condsub(*zp + redc_mad((uint64_t)u * kb[t], p, P.ninv), md.p2);
+            }
+        }
+    }
+    const int tid = threadIdx.x;
+    uint32_t *yb = yg + (((size_t)ci * groups + g) * 2 * NPR + pi) * M;
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+        if (c > 0) {
+#pragma unroll
+            for (int e = 0; e < E; e++) z0[0][e] = lds[M + e * T + tid];
+            SGFHE_SYNC();
+        }
+        ntt_inverse<LOGM, 1, LOGE>(z0, lds, P.twi, tid, md);
+#pragma unroll
+        for (int e = 0; e < E; e++)
+            yb[(size_t)c * NPR * M + tid + T * e] = condsub(condsub(z0[0][e], p) + P.hoff, p);
+    }
+}
+
+// One thread per (ciphertext, coefficient k < m): W = sum_g CRT(y_g column 0), V likewise
+// (fhe.jl:686-687); w = ModRed(-W), v = ModRed(b_k - V) (fhe.jl:689-693), b_k = the un-reduced
+// LWE constant of bit k for k < n and 0 beyond (resize, fhe.jl:678).
+__global__ void __launch_bounds__(256)
+k_pack_finish(const uint32_t *__restrict__ yg, const ulonglong2 *__restrict__ raw,
+              uint64_t *__restrict__ out_w, uint64_t *__restrict__ out_v,
+              const CrtConst *__restrict__ CC, uint32_t count, uint32_t n, uint32_t logm,
+              uint32_t groups) {
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const uint32_t M = 1u << logm;
+    if (t >= (size_t)count * M) return;
+    const uint32_t kk = (uint32_t)(t & (M - 1));
+    const uint32_t ci = (uint32_t)(t >> logm);
+    const u128 Q = CC->Q;
+    u128 acc[2] = {0, 0};
+    for (uint32_t g = 0; g < groups; g++) {
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            const uint32_t *yp = yg + ((((size_t)ci * groups + g) * 2 + c) * NPR) * M + kk;
+            uint32_t y[NPR];
+#pragma unroll
+            for (int q = 0; q < NPR; q++) y[q] = yp[(size_t)q * M];
+            const U96 a = crt_reduce(y, CC, false, make_ulonglong2(0, 0));
+            acc[c] += ((u128)a.w2 << 64) | ((uint64_t)a.w1 << 32) | a.w0;
+            if (acc[c] >= Q) acc[c] -= Q;
+        }
+    }
+    const u128 w1 = acc[0] ? Q - acc[0] : 0;
+    u128 bk = 0;
+    if (kk < n) {
+        const ulonglong2 v = raw[(((size_t)ci * n + kk) * 3 + 0) * (n + 1) + n];
+        bk = ((u128)v.y << 64) | v.x;
+    }
+    const u128 v1 = bk >= acc[1] ? bk - acc[1] : bk + Q - acc[1];
+    out_w[t] = modred(w1, CC);
+    out_v[t] = modred(v1, CC);
 }
 
 // ---- k_key_transform ------------------------------------------------------------------------------

@@ -133,6 +133,22 @@ class Engine:
     def sync(self):
         self._chk(self._L.sgfhe_sync(self._h))
 
+    def pack_encrypted_bits(self, a, b):
+        """pack_encrypted_bits (fhe.jl:660-696) for `count` groups of n LWEs: a [count][n][n],
+        b [count][n] -> (w, v), each [count][m] uint64 over Z_r."""
+        p = self.params
+        a, pa = _c(a)
+        b, pb = _c(b)
+        if a.size % (p.n * p.n) or b.size * p.n != a.size:
+            raise ValueError("pack_encrypted_bits: a is [count][n][n], b is [count][n]")
+        count = a.size // (p.n * p.n)
+        w = np.zeros((count, p.m), dtype=np.uint64)
+        v = np.zeros((count, p.m), dtype=np.uint64)
+        self._chk(self._L.sgfhe_pack_encrypted_bits(self._h, pa, pb, count,
+                                                    w.ctypes.data_as(ctypes.c_void_p),
+                                                    v.ctypes.data_as(ctypes.c_void_p)))
+        return w, v
+
     # ---- parity / debug hooks ---------------------------------------------------------------
     def external_product(self, a, b, A):
         """external_product(nothing, a, b, A, Val(B), Val(2)) (fhe.jl:519-530)."""

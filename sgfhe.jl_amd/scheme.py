@@ -154,6 +154,14 @@ class PackedCiphertext:
         self.params, self.rlwe = params, rlwe
 
 
+class Ciphertext:
+    """Ciphertext (src/fhe.jl:263-266): an RLWE over Z_r[x]/(x^m + 1) produced by
+    pack_encrypted_bits; the message sits in the first n coefficients."""
+
+    def __init__(self, params, rlwe):
+        self.params, self.rlwe = params, rlwe
+
+
 def encrypt(key, rng, message):
     """encrypt(key::PrivateKey, rng, message) (src/fhe.jl:369-372, _encrypt_private :310-328).
     `a` is drawn from `rng` directly instead of the reference's seed expansion
@@ -185,22 +193,41 @@ def extract(a, i, n):
 
 
 def split_ciphertext(ct):
-    """split_ciphertext (src/fhe.jl:287-290)."""
+    """split_ciphertext (src/fhe.jl:287-290) for PackedCiphertext and Ciphertext."""
     p = ct.params
     mask = np.uint64(p.r - 1)
     return [EncryptedBit(LWE(extract(ct.rlwe.a, i, p.n) & mask, ct.rlwe.b[i - 1]))
             for i in range(1, p.n + 1)]
 
 
+def pack_encrypted_bits(bkey, rng, enc_bits):
+    """pack_encrypted_bits(bkey, rng, enc_bits) (src/fhe.jl:660-696): n EncryptedBits -> one
+    RLWE Ciphertext, on the HIP engine.  Deterministic flatten only (rng = nothing)."""
+    if rng is not None:
+        raise NotImplementedError("only the deterministic path (rng = nothing) is implemented")
+    p = bkey.params
+    if len(enc_bits) != p.n:
+        raise AssertionError("exactly n encrypted bits are required (src/fhe.jl:667)")
+    a = np.stack([e.lwe.a for e in enc_bits])[None, :, :]
+    b = np.array([e.lwe.b for e in enc_bits], dtype=np.uint64)[None, :]
+    w, v = bkey.engine.pack_encrypted_bits(a, b)
+    return Ciphertext(p, RLWE(w[0], v[0]))
+
+
 def decrypt(key, ct):
-    """decrypt(key, ::EncryptedBit) (src/fhe.jl:504-507) and decrypt(key, ::PackedCiphertext)
-    (src/fhe.jl:471-494)."""
+    """decrypt(key, ::EncryptedBit) (src/fhe.jl:504-507) and
+    decrypt(key, ::Union{Ciphertext, PackedCiphertext}) (src/fhe.jl:471-494)."""
     p = key.params
     mask = np.uint64(p.r - 1)
     if isinstance(ct, EncryptedBit):
         b1 = (int(ct.lwe.b) - int(np.sum(ct.lwe.a * key.key, dtype=np.uint64))) % p.r
         return bool(((b1 + p.Dr // 2) % p.r) // p.Dr)
-    b1 = (ct.rlwe.b - _negacyclic_mul_small(ct.rlwe.a, key.key, p.r)) & mask
+    key_poly = key.key
+    if isinstance(ct, Ciphertext):                                        # fhe.jl:474-478
+        key_poly = np.concatenate([key.key, np.zeros(p.m - p.n, dtype=np.uint64)])
+    b1 = (ct.rlwe.b - _negacyclic_mul_small(ct.rlwe.a, key_poly, p.r)) & mask
+    if isinstance(ct, Ciphertext):
+        b1 = b1[:p.n]                                                     # fhe.jl:481-482
     return (((b1 + np.uint64(p.Dr // 2)) & mask) // np.uint64(p.Dr)).astype(bool)
 
 

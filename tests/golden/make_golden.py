@@ -105,8 +105,24 @@ def tables():
     return out
 
 
+def pack_case():
+    """test/api.test.jl:86-108 at Params(64): n LWEs -> pack_encrypted_bits -> RLWE (w, v)."""
+    p = O.Params.make(64)
+    sk = O.private_key(p, 1)
+    bk = O.bootstrap_key(p, sk, 2)
+    g = O.SplitMix64(5)
+    bits = [g.next() & 1 for _ in range(p.n)]
+    lwes = [O.lwe_encrypt_bit(p, sk, b, g) for b in bits]
+    w, v = O.pack_encrypted_bits(p, bk, lwes)
+    assert O.decrypt_ciphertext(p, sk, w, v) == bits
+    assert [O.lwe_decrypt_bit(p, sk, l) for l in O.split_ciphertext(p, w, v)] == bits
+    return {"n": p.n, "sk_seed": 1, "key_seed": 2, "in_seed": 5, "bits": bits,
+            "a": [l[0] for l in lwes], "b": [l[1] for l in lwes], "w": w, "v": v,
+            "key_sha256": key_hash(bk)}
+
+
 def main():
-    what = sys.argv[1:] or ["p64", "extprod", "tables", "p512", "p1024"]
+    what = sys.argv[1:] or ["p64", "extprod", "tables", "p512", "p1024", "pack64"]
     pairs4 = [(0, 0), (0, 1), (1, 0), (1, 1)]
     for w in what:
         print(w, flush=True)
@@ -120,6 +136,8 @@ def main():
             d = extprod_case()
         elif w == "tables":
             d = tables()
+        elif w == "pack64":
+            d = pack_case()
         else:
             raise SystemExit("unknown " + w)
         with open(os.path.join(HERE, w + ".json"), "w") as f:

@@ -219,3 +219,67 @@ def test_batch_position_independence_params1024(S):
     single = eng.bootstrap_batch(a1[:1], b1[:1], a2[:1], b2[:1])
     assert np.array_equal(single[0], out[0])
     eng.close()
+
+
+# ---- packing (pack_encrypted_bits, src/fhe.jl:660-696) ---------------------
+
+def test_pack_encrypted_bits_params64(S, oc, p64):
+    """test/api.test.jl:86-108 (deterministic branch): split -> pack_encrypted_bits -> decrypt both
+    ways; the RLWE equals the oracle's bit for bit, and the committed golden vector."""
+    params, o, sk, bkey, eng = p64
+    n = params.n
+    bits = np.random.default_rng(21).integers(0, 2, size=2 * n).astype(np.uint8)
+    a, b = o.lwe_encrypt_bits(sk, bits, 22)
+    w, v = eng.pack_encrypted_bits(a.reshape(2, n, n), b.reshape(2, n))       # two ciphertexts
+    for ci in range(2):
+        rw, rv = o.pack_encrypted_bits(bkey, a[ci * n:(ci + 1) * n], b[ci * n:(ci + 1) * n])
+        assert np.array_equal(w[ci], rw) and np.array_equal(v[ci], rv)
+    # host-side API round trip (Ciphertext -> decrypt directly, and via split_ciphertext)
+    key = S.PrivateKey.__new__(S.PrivateKey)
+    key.params, key.key = params, np.asarray(sk, dtype=np.uint64)
+    ct = S.Ciphertext(params, S.RLWE(w[0], v[0]))
+    assert np.array_equal(S.decrypt(key, ct), bits[:n].astype(bool))
+    assert [S.decrypt(key, eb) for eb in S.split_ciphertext(ct)] == list(bits[:n].astype(bool))
+    path = os.path.join(G, "pack64.json")
+    if os.path.exists(path):
+        d = json.load(open(path))
+        gw, gv = eng.pack_encrypted_bits(np.array(d["a"], dtype=np.uint64)[None],
+                                         np.array(d["b"], dtype=np.uint64)[None])
+        assert [int(x) for x in gw[0]] == d["w"] and [int(x) for x in gv[0]] == d["v"]
+
+
+@pytest.mark.parametrize("n", [8, 32])
+def test_pack_small_synthetic(S, oc, n):
+    import bigint_oracle as BO
+    m = 8 * n
+    Q = BO.find_modulus(2 * m, 1 << 50)
+    params = S.Params.custom(n, Q, 1 << 26)
+    o = oc.Oracle.from_params(params)
+    sk = o.private_key(7)
+    bkey = o.bootstrap_key(sk, 8, noise=2)
+    eng = S.Engine(params)
+    eng.upload_key(bkey)
+    bits = np.random.default_rng(n).integers(0, 2, size=n).astype(np.uint8)
+    a, b = o.lwe_encrypt_bits(sk, bits, 9)
+    w, v = eng.pack_encrypted_bits(a[None], b[None])
+    rw, rv = o.pack_encrypted_bits(bkey, a, b)
+    assert np.array_equal(w[0], rw) and np.array_equal(v[0], rv)
+    eng.close()
+
+
+def test_pack_params512_decrypts(S, oc):
+    """Full-size ring through a size-independent property: pack(bits) decrypts to bits
+    (the oracle's pack at n = 512 would take minutes)."""
+    params = S.Params(512)
+    o = oc.Oracle.from_params(params)
+    sk = o.private_key(31)
+    bkey = o.bootstrap_key(sk, 32)
+    eng = S.Engine(params)
+    eng.upload_key(bkey)
+    bits = np.random.default_rng(33).integers(0, 2, size=params.n).astype(np.uint8)
+    a, b = o.lwe_encrypt_bits(sk, bits, 34)
+    w, v = eng.pack_encrypted_bits(a[None], b[None])
+    key = S.PrivateKey.__new__(S.PrivateKey)
+    key.params, key.key = params, np.asarray(sk, dtype=np.uint64)
+    assert np.array_equal(S.decrypt(key, S.Ciphertext(params, S.RLWE(w[0], v[0]))), bits.astype(bool))
+    eng.close()
