@@ -92,6 +92,17 @@ int32_t sgfhe_bkey_upload(sgfhe_ctx *ctx, const uint64_t *canonical, size_t n_wo
 int32_t sgfhe_bkey_upload_rns2(sgfhe_ctx *ctx, const uint64_t *pairs, size_t n_words, uint64_t m1,
                                uint64_t m2);
 
+/*
+ * BootstrapKey(rng, sk) (src/fhe.jl:181-201) generated on the device, directly in device form:
+ * for every k and gadget row a uniform a_row in [0, Q)^m, noise e_row in [-noise, noise]^m
+ * (the reference uses noise = n, src/fhe.jl:194), b_row = a_row * s + e_row, plus s_k G on the
+ * constant terms.  sk: n words, bit 0 of each is the key bit (PrivateKey.key, src/fhe.jl:130-138).
+ * Randomness: the SplitMix64 stream of `seed` (draw order documented in csrc/kernels.h); the
+ * caller is responsible for a seed of cryptographic quality.
+ */
+int32_t sgfhe_bkey_generate(sgfhe_ctx *ctx, const uint64_t *sk, size_t n_sk, uint64_t seed,
+                            uint32_t noise);
+
 /* Device-form key blob (for the one-time RCCL broadcast rank 0 -> peers). */
 int32_t sgfhe_bkey_device_form_bytes(const sgfhe_ctx *ctx, size_t *bytes);
 int32_t sgfhe_bkey_export_device_form(sgfhe_ctx *ctx, void *dst_device);

@@ -178,6 +178,30 @@ int32_t launch_shortprod(sgfhe_ctx *c, const uint64_t *pdig, uint32_t *yg, uint3
 }
 
 template <int LOGM>
+int32_t launch_keygen_ntt_t(sgfhe_ctx *c, const uint64_t *d_sk, uint32_t *d_shat,
+                            const ulonglong2 *d_acan, uint32_t *d_y, uint32_t R, bool shat_pass,
+                            hipStream_t st) {
+    if (shat_pass)
+        hipLaunchKernelGGL(k_shat<LOGM>, dim3(NPR), dim3(threads_of<LOGM>()), lds_bytes(LOGM, 1), st,
+                           d_sk, d_shat, c->d_primes, c->n);
+    else
+        hipLaunchKernelGGL(k_polymul_s<LOGM>, dim3(R * NPR), dim3(threads_of<LOGM>()),
+                           lds_bytes(LOGM, 1), st, d_acan, d_shat, d_y, c->d_primes, c->d_crt);
+    HIPCHK(c, hipGetLastError());
+    return SGFHE_OK;
+}
+int32_t launch_keygen_ntt(sgfhe_ctx *c, const uint64_t *d_sk, uint32_t *d_shat,
+                          const ulonglong2 *d_acan, uint32_t *d_y, uint32_t R, bool shat_pass,
+                          hipStream_t st) {
+    switch (c->logm) {
+#define X(LM) case LM: return launch_keygen_ntt_t<LM>(c, d_sk, d_shat, d_acan, d_y, R, shat_pass, st);
+        SGFHE_FOR_LOGM(X)
+#undef X
+    }
+    return fail(c, SGFHE_ERR_UNSUPPORTED, "unsupported log2(m)");
+}
+
+template <int LOGM>
 int32_t launch_keytr_t(sgfhe_ctx *c, const ulonglong2 *canon, uint32_t *keyhat, uint32_t poly0,
                        uint32_t npolys, hipStream_t st) {
     hipLaunchKernelGGL(k_key_transform<LOGM>, dim3(npolys * NPR), dim3(threads_of<LOGM>()),
@@ -614,6 +638,59 @@ int32_t sgfhe_bkey_upload(sgfhe_ctx *c, const uint64_t *canonical, size_t n_word
     if (rc) return rc;
     c->have_key = true;
     return SGFHE_OK;
+}
+
+int32_t sgfhe_bkey_generate(sgfhe_ctx *c, const uint64_t *sk, size_t n_sk, uint64_t seed,
+                            uint32_t noise) {
+    if (!c || !sk) return SGFHE_ERR_INVALID_ARG;
+    if (n_sk != c->n) return fail(c, SGFHE_ERR_INVALID_ARG, "bkey_generate: secret key must hold n bits");
+    if (c->Q < ((u128)1 << 16)) return fail(c, SGFHE_ERR_UNSUPPORTED, "bkey_generate needs Q >= 2^16");
+    (void)hipSetDevice(c->device);
+    int32_t rc = key_alloc(c);
+    if (rc) return rc;
+    const uint32_t M = c->M, rows = c->n * 4;
+    uint32_t R = 64;  // rows per batch (16 key slices)
+    if (R > rows) R = rows;
+    uint64_t *d_sk = nullptr;
+    uint32_t *d_shat = nullptr, *d_y = nullptr;
+    ulonglong2 *d_acan = nullptr, *d_prod = nullptr, *d_canon = nullptr;
+    int32_t *d_e = nullptr;
+    hipError_t e = hipSuccess;
+    do {
+        if ((e = hipMalloc(&d_sk, (size_t)c->n * 8))) break;
+        if ((e = hipMalloc(&d_shat, (size_t)NPR * M * 4))) break;
+        if ((e = hipMalloc(&d_y, (size_t)R * NPR * M * 4))) break;
+        if ((e = hipMalloc(&d_acan, (size_t)R * M * 16))) break;
+        if ((e = hipMalloc(&d_prod, (size_t)R * M * 16))) break;
+        if ((e = hipMalloc(&d_canon, (size_t)R * 2 * M * 16))) break;
+        if ((e = hipMalloc(&d_e, (size_t)R * M * 4))) break;
+        if ((e = hipMemcpyAsync(d_sk, sk, (size_t)c->n * 8, hipMemcpyHostToDevice, c->stream))) break;
+        rc = launch_keygen_ntt(c, d_sk, d_shat, nullptr, nullptr, 0, true, c->stream);
+        if (rc) break;
+        for (uint32_t row0 = 0; row0 < rows && rc == SGFHE_OK; row0 += R) {
+            const uint32_t tot = R * M;
+            hipLaunchKernelGGL(k_keygen_draw, dim3((tot + 255) / 256), dim3(256), 0, c->stream, d_acan,
+                               d_e, c->d_crt, seed, noise, row0, R, (uint32_t)c->logm);
+            rc = launch_keygen_ntt(c, d_sk, d_shat, d_acan, d_y, R, false, c->stream);
+            if (rc) break;
+            // CRT of the exact product, canonical residues into d_prod ([row][m] 16-byte values)
+            hipLaunchKernelGGL(k_crt_acc, dim3((tot + 255) / 256), dim3(256), 0, c->stream, d_y,
+                               reinterpret_cast<uint64_t *>(d_prod), c->d_crt, tot, (uint32_t)c->logm,
+                               MODE_NOACC | MODE_CANON);
+            hipLaunchKernelGGL(k_keygen_finish, dim3((tot + 255) / 256), dim3(256), 0, c->stream, d_acan,
+                               d_prod, d_e, d_sk, d_canon, c->d_crt, row0, R, (uint32_t)c->logm);
+            if ((e = hipGetLastError())) break;
+            rc = launch_keytr(c, d_canon, c->d_key, row0 * 2, R * 2, c->stream);
+        }
+        if (rc || e) break;
+        e = hipStreamSynchronize(c->stream);
+    } while (0);
+    if (e != hipSuccess && rc == SGFHE_OK) rc = fail(c, SGFHE_ERR_HIP, hipGetErrorString(e));
+    for (void *ptr : {(void *)d_sk, (void *)d_shat, (void *)d_y, (void *)d_acan, (void *)d_prod,
+                      (void *)d_canon, (void *)d_e})
+        if (ptr) (void)hipFree(ptr);
+    if (rc == SGFHE_OK) c->have_key = true;
+    return rc;
 }
 
 int32_t sgfhe_bkey_upload_rns2(sgfhe_ctx *c, const uint64_t *pairs, size_t n_words, uint64_t m1,

@@ -622,6 +622,140 @@ k_pack_finish(const uint32_t *__restrict__ yg, const ulonglong2 *__restrict__ ra
     out_v[t] = modred(v1, CC);
 }
 
+// ==================================================================================================
+// Bootstrap-key generation on the device: BootstrapKey(rng, sk) (src/fhe.jl:181-201), SURVEY.md 8f
+// row N2.  Randomness: the SplitMix64 stream of the given seed, addressed by draw index (the
+// stream is counter based: draw k = mix(seed + (k + 1) gamma)), in the order
+//   for k, for row:  a_row[0..m) (two draws each: hi, lo; value = (hi 2^64 + lo) mod Q),
+//                    e_row[0..m) (one draw each: d mod (2 noise + 1) - noise)
+// -- the order of the oracle's generator, so that both produce the same key from one seed.
+// Per batch of rows:  k_keygen_draw -> k_polymul_s (a (*) s, exact, per prime) -> k_crt_acc (CANON)
+// -> k_keygen_finish (b = a (*) s + e, + s_k G on the constant terms) -> k_key_transform.
+// ==================================================================================================
+
+__device__ __forceinline__ uint64_t splitmix_at(uint64_t seed, uint64_t k) {
+    uint64_t z = seed + (k + 1) * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+// (hi 2^64 + lo) mod Q for 2^16 <= Q < 2^94: long division in base 2^32 (quotients < 2^32 are
+// exact through the double-precision estimate of mod_wide)
+__device__ __forceinline__ u128 mod128(uint64_t hi, uint64_t lo, const CrtConst *CC) {
+    const u128 Q = CC->Q;
+    u128 r = mod_wide((u128)(hi >> 32), Q, CC->invQ, nullptr);
+    r = mod_wide((r << 32) | (uint32_t)hi, Q, CC->invQ, nullptr);
+    r = mod_wide((r << 32) | (uint32_t)(lo >> 32), Q, CC->invQ, nullptr);
+    return mod_wide((r << 32) | (uint32_t)lo, Q, CC->invQ, nullptr);
+}
+// rows [row0, row0 + R) (row = k * 4 + gadget row): canonical a into acan[r][m], noise into e[r][m]
+__global__ void __launch_bounds__(256)
+k_keygen_draw(ulonglong2 *__restrict__ acan, int32_t *__restrict__ e,
+              const CrtConst *__restrict__ CC, uint64_t seed, uint32_t noise, uint32_t row0,
+              uint32_t R, uint32_t logm) {
+    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t M = 1u << logm;
+    if (t >= R * M) return;
+    const uint32_t i = t & (M - 1), r = t >> logm;
+    const uint64_t base = (uint64_t)(row0 + r) * 3 * M;
+    const u128 a = mod128(splitmix_at(seed, base + 2 * i), splitmix_at(seed, base + 2 * i + 1), CC);
+    acan[t] = make_ulonglong2((uint64_t)a, (uint64_t)(a >> 64));
+    const uint64_t d = splitmix_at(seed, base + 2 * M + i) % (2 * (uint64_t)noise + 1);
+    e[t] = (int32_t)d - (int32_t)noise;
+}
+
+// shat[pi][slot] = NTT(s)[slot] * m^-1 * (M/p)^-1 * R mod p  (s = the secret key, zero padded)
+template <int LOGM>
+__global__ void __launch_bounds__((NttGeom<LOGM, LOGE>::T))
+k_shat(const uint64_t *__restrict__ sk, uint32_t *__restrict__ shat, PrimeSet PS, uint32_t n) {
+    using G = NttGeom<LOGM, LOGE>;
+    constexpr int M = G::M, T = G::T, E = G::E;
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const int tid = threadIdx.x;
+    const uint32_t pi = blockIdx.x;
+    const PrimeK P = PS[pi];
+    const Mod md = {P.p, P.ninv, 2 * P.p};
+    uint32_t x[1][E];
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+        const uint32_t idx = tid + T * e;
+        x[0][e] = idx < n ? (uint32_t)(sk[idx] & 1) : 0u;
+    }
+    ntt_forward<LOGM, 1, LOGE>(x, lds, P.twf, tid, md);
+    // kappaR = R^2 m^-1 (M/p)^-1 * R: mont_mul(mont_mul(x, kappaR), 1) = x R^2 m^-1 e ... we need
+    // x m^-1 e R = mont_mul(x, kappaR) * R^-1: two Montgomery steps with 1 bring R^3 down to R
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+        uint32_t u = condsub(condsub(x[0][e], md.p2), P.p);
+        u = mont_mul(u, P.kappaR, P.p, P.ninv);   // x R^2 m^-1 e
+        u = mont_mul(u, 1u, P.p, P.ninv);         // x R   m^-1 e
+        shat[(size_t)pi * M + E * tid + e] = u;
+    }
+}
+
+// y[r][pi][m] = (M/p)^-1 * (a_r (*) s) mod p (+ hoff), a lifted to (-Q/2, Q/2]
+template <int LOGM>
+__global__ void __launch_bounds__((NttGeom<LOGM, LOGE>::T))
+k_polymul_s(const ulonglong2 *__restrict__ acan, const uint32_t *__restrict__ shat,
+            uint32_t *__restrict__ y, PrimeSet PS, const CrtConst *__restrict__ CC) {
+    using G = NttGeom<LOGM, LOGE>;
+    constexpr int M = G::M, T = G::T, E = G::E;
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const int tid = threadIdx.x;
+    const uint32_t r = blockIdx.x / NPR, pi = blockIdx.x % NPR;
+    const PrimeK P = PS[pi];
+    const uint32_t p = P.p;
+    const Mod md = {P.p, P.ninv, 2 * P.p};
+    const u128 halfQ = CC->halfQ;
+    uint32_t x[1][E];
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+        const ulonglong2 v = acan[(size_t)r * M + tid + T * e];
+        const uint32_t c0 = (uint32_t)v.x, c1 = (uint32_t)(v.x >> 32), c2 = (uint32_t)v.y;
+        uint32_t u = csub(mont_mul(c0, P.r1, p, P.ninv) + mont_mul(c1, P.r2, p, P.ninv), p);
+        u = csub(u + mont_mul(c2, P.r3, p, P.ninv), p);
+        const u128 C = ((u128)v.y << 64) | v.x;
+        if (C > halfQ) { u = u - P.qmodp; u = min(u, u + p); }
+        x[0][e] = u;
+    }
+    ntt_forward<LOGM, 1, LOGE>(x, lds, P.twf, tid, md);
+#pragma unroll
+    for (int e = 0; e < E; e++)  // x in [0, 4p), shat < p: product < p 2^32
+        x[0][e] = redc_mad((uint64_t)x[0][e] * shat[(size_t)pi * M + E * tid + e], p, P.ninv);
+    __syncthreads();
+    ntt_inverse<LOGM, 1, LOGE>(x, lds, P.twi, tid, md);
+#pragma unroll
+    for (int e = 0; e < E; e++)
+        y[((size_t)r * NPR + pi) * M + tid + T * e] = condsub(condsub(x[0][e], p) + P.hoff, p);
+}
+
+// canon[(r * 2 + col)][m]: col 0 = a_r + s_k G[row][0], col 1 = a_r (*) s + e_r + s_k G[row][1]
+// (constant-term adds, fhe.jl:195-196); prod holds the canonical a_r (*) s.
+__global__ void __launch_bounds__(256)
+k_keygen_finish(const ulonglong2 *__restrict__ acan, const ulonglong2 *__restrict__ prod,
+                const int32_t *__restrict__ e, const uint64_t *__restrict__ sk,
+                ulonglong2 *__restrict__ canon, const CrtConst *__restrict__ CC, uint32_t row0,
+                uint32_t R, uint32_t logm) {
+    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t M = 1u << logm;
+    if (t >= R * M) return;
+    const uint32_t i = t & (M - 1), r = t >> logm;
+    const uint32_t grow = (row0 + r) & 3, kk = (row0 + r) >> 2;
+    const u128 Q = CC->Q;
+    u128 a = ((u128)acan[t].y << 64) | acan[t].x;
+    u128 b = ((u128)prod[t].y << 64) | prod[t].x;
+    const int32_t ev = e[t];
+    b += ev >= 0 ? (u128)(uint32_t)ev : Q - (u128)(uint32_t)(-ev);
+    if (b >= Q) b -= Q;
+    if (i == 0 && (sk[kk] & 1)) {  // G = [1 0; B 0; 0 1; 0 B] (fhe.jl:119-122)
+        const u128 g = (grow & 1) ? CC->B % Q : (u128)1;
+        if (grow < 2) { a += g; if (a >= Q) a -= Q; }
+        else { b += g; if (b >= Q) b -= Q; }
+    }
+    canon[((size_t)r * 2 + 0) * M + i] = make_ulonglong2((uint64_t)a, (uint64_t)(a >> 64));
+    canon[((size_t)r * 2 + 1) * M + i] = make_ulonglong2((uint64_t)b, (uint64_t)(b >> 64));
+}
+
 // ---- k_key_transform ------------------------------------------------------------------------------
 // BootstrapKey.key (fhe.jl:176-201) canonical residues -> device form: centred lift to
 // (-Q/2, Q/2], residue mod p_i, scaled by kappa_i, forward NTT, slot order.

@@ -77,6 +77,12 @@ class Engine:
         a, ptr = _c(pairs)
         self._chk(self._L.sgfhe_bkey_upload_rns2(self._h, ptr, a.size, m1, m2))
 
+    def generate_key(self, sk_bits, seed, noise=None):
+        """BootstrapKey(rng, sk) (fhe.jl:181-201) generated on the device from a 64-bit seed."""
+        a, ptr = _c(sk_bits)
+        self._chk(self._L.sgfhe_bkey_generate(self._h, ptr, a.size, seed & 0xFFFFFFFFFFFFFFFF,
+                                              self.params.n if noise is None else noise))
+
     def key_device_form_bytes(self):
         n = ctypes.c_size_t()
         self._chk(self._L.sgfhe_bkey_device_form_bytes(self._h, ctypes.byref(n)))

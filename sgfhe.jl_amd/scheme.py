@@ -71,15 +71,19 @@ class PrivateKey:
 class BootstrapKey:
     """BootstrapKey(rng, sk) (src/fhe.jl:176-201), resident on the GPU in the engine's form.
 
-    `BootstrapKey(rng, sk)` generates the key on the host (one-time) and uploads it;
+    `BootstrapKey(rng, sk)` generates the key on the device (seeded from `rng`);
     `BootstrapKey.from_canonical(params, residues)` uploads an existing key given as
-    value.(coeffs) in [k][row][col][coef] order (what the Julia shim passes)."""
+    value.(coeffs) in [k][row][col][coef] order (what the Julia shim passes);
+    `BootstrapKey(rng, sk, on_host=True)` generates it with host big-integer arithmetic."""
 
-    def __init__(self, rng, sk, device=0, engine=None):
+    def __init__(self, rng, sk, device=0, engine=None, on_host=False):
         params = sk.params
         self.params = params
         self.engine = engine or Engine(params, device)
-        self.engine.upload_key(self._generate(rng, sk))
+        if on_host:
+            self.engine.upload_key(self._generate(rng, sk))
+        else:
+            self.engine.generate_key(sk.key, int(rng.integers(0, 1 << 63, dtype=np.uint64)))
 
     @classmethod
     def from_canonical(cls, params, residues, device=0, engine=None):

@@ -94,3 +94,22 @@ def test_params1024_golden(oc):
     """Accumulator hashes after the first two iterations here; the full-bootstrap golden output is
     compared with the HIP engine in tests/test_gpu_golden.py."""
     _check_bootstrap_golden(oc, "p1024", full=False)
+
+
+def test_pack_encrypted_bits_golden(oc):
+    """the C restatement of pack_encrypted_bits (src/fhe.jl:660-696) against
+    the big-integer golden vector; decrypts both ways (test/api.test.jl:86-108)."""
+    d = load("pack64")
+    n = d["n"]
+    o = oc.Oracle.make(n)
+    sk = o.private_key(d["sk_seed"])
+    bkey = o.bootstrap_key(sk, d["key_seed"])
+    assert hashlib.sha256(np.ascontiguousarray(bkey).tobytes()).hexdigest() == d["key_sha256"]
+    w, v = o.pack_encrypted_bits(bkey, np.array(d["a"], dtype=np.uint64),
+                                 np.array(d["b"], dtype=np.uint64))
+    assert [int(x) for x in w] == d["w"] and [int(x) for x in v] == d["v"]
+    p = BO.Params.make(n)
+    skl = [int(x) for x in sk]
+    assert BO.decrypt_ciphertext(p, skl, d["w"], d["v"]) == d["bits"]
+    lwes = BO.split_ciphertext(p, d["w"], d["v"])
+    assert [BO.lwe_decrypt_bit(p, skl, l) for l in lwes] == d["bits"]

@@ -283,3 +283,54 @@ def test_pack_params512_decrypts(S, oc):
     key.params, key.key = params, np.asarray(sk, dtype=np.uint64)
     assert np.array_equal(S.decrypt(key, S.Ciphertext(params, S.RLWE(w[0], v[0]))), bits.astype(bool))
     eng.close()
+
+
+# ---- key generation on the device (BootstrapKey, src/fhe.jl:181-201) -----------
+
+@pytest.mark.parametrize("n", [64, 512])
+def test_device_keygen_equals_oracle_keygen(S, oc, n):
+    """Same SplitMix64 seed -> the device-generated key is byte-identical (in device form) to the
+    oracle's key uploaded through sgfhe_bkey_upload, and bootstraps with it decrypt correctly."""
+    import torch
+    params = S.Params(n)
+    o = oc.Oracle.from_params(params)
+    sk = o.private_key(51)
+    bkey = o.bootstrap_key(sk, 52)
+    e1 = S.Engine(params)
+    e1.upload_key(bkey)
+    e2 = S.Engine(params)
+    e2.generate_key(sk, 52)
+    nbytes = e1.key_device_form_bytes()
+    b1 = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    b2 = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    e1.export_key_device_form(b1.data_ptr())
+    e2.export_key_device_form(b2.data_ptr())
+    assert torch.equal(b1, b2)
+    bits = np.array([0, 1, 1, 1], dtype=np.uint8)
+    a, b = o.lwe_encrypt_bits(sk, bits, 53)
+    out = e2.bootstrap_batch(a[0::2], b[0::2], a[1::2], b[1::2])
+    dec = [list(o.lwe_decrypt_bits(sk, out[:, g, :n], out[:, g, n])) for g in range(3)]
+    assert dec == [[0, 1], [1, 1], [1, 0]]
+    e1.close()
+    e2.close()
+
+
+def test_host_api_end_to_end(S):
+    """README example of the reference (README.md:10-29) through the Python mirror: keys,
+    encrypt, split, bootstrap, decrypt -- no oracle involved."""
+    rng = np.random.default_rng(3)
+    params = S.Params(64)
+    key = S.PrivateKey(params, rng)
+    bkey = S.BootstrapKey(rng, key)                       # generated on the device
+    msg = rng.integers(0, 2, size=params.n).astype(bool)
+    bits = S.split_ciphertext(S.encrypt(key, rng, msg))
+    for i in range(0, 8, 2):
+        r_and, r_or, r_xor = S.bootstrap(bkey, None, bits[i], bits[i + 1])
+        assert S.decrypt(key, r_and) == (msg[i] & msg[i + 1])
+        assert S.decrypt(key, r_or) == (msg[i] | msg[i + 1])
+        assert S.decrypt(key, r_xor) == (msg[i] ^ msg[i + 1])
+    ct = S.pack_encrypted_bits(bkey, None, bits)
+    assert np.array_equal(S.decrypt(key, ct), msg)
+    bkey_h = S.BootstrapKey(rng, key, on_host=True)       # host big-integer generation
+    r = S.bootstrap(bkey_h, None, bits[0], bits[1])
+    assert S.decrypt(key, r[0]) == (msg[0] & msg[1])

@@ -187,3 +187,25 @@ def test_rns2_roundtrip():
         x = g.below_wide(m1 * m2)
         v1, v2 = BO.rns2_from_int(x, m1, m2)
         assert BO.rns2_to_int(v1, v2, m1, m2) == x
+
+
+# ---- test/api.test.jl:86-108 (packing, deterministic branch) on a small synthetic ring ------------
+
+def test_pack_small_ring_c_equals_bigint(oc):
+    n, m = 8, 64
+    Q = BO.find_modulus(2 * m, 1 << 50)
+    p = BO.Params.custom(n, Q, 1 << 26)
+    o = oc.Oracle.from_params(p)
+    sk = o.private_key(7)
+    bkey = o.bootstrap_key(sk, 8, noise=2)
+    bits = np.array([1, 0, 0, 1, 1, 1, 0, 1], dtype=np.uint8)
+    a, b = o.lwe_encrypt_bits(sk, bits, 9)
+    w, v = o.pack_encrypted_bits(bkey, a, b)
+    skl = [int(x) for x in sk]
+    vals = oc.u128_to_ints(bkey)
+    bk = [[[vals[((k * 4 + r) * 2 + c) * m:((k * 4 + r) * 2 + c + 1) * m] for c in range(2)]
+           for r in range(4)] for k in range(n)]
+    lwes = [([int(x) for x in a[i]], int(b[i])) for i in range(n)]
+    pw, pv = BO.pack_encrypted_bits(p, bk, lwes)
+    assert [int(x) for x in w] == pw and [int(x) for x in v] == pv
+    assert BO.decrypt_ciphertext(p, skl, pw, pv) == [int(x) for x in bits]
