@@ -5,7 +5,8 @@ One "step" = one pass of the hot path (`bootstrap()` of nucypher/SGFHE.jl,
 /root/reference/src/fhe.jl:608-621) over one batch of independent gate bootstraps resident in
 HBM.  Default workload: the reference's own Params(1024) (Q = 92180593745615474572738561,
 86.25-bit prime; SURVEY.md config 4'), batch 4096 per GPU, synthetic uniformly random bootstrap
-key and LWE inputs (the arithmetic does not depend on the key being a valid encryption).
+LWE inputs and a bootstrap key generated on the device from a fixed seed (a valid key of a
+random secret; sgfhe_bkey_generate).
 
 Multi-GPU (launched by torch.distributed.run, one rank per GPU): the batch shards across ranks,
 rank 0 builds the device-form key and broadcasts it once over RCCL; there is no collective in
@@ -74,13 +75,15 @@ def measured_traffic(config, chunk):
         return json.load(f)["kernels"]["k_extprod"]["traffic_bytes_per_launch"]
 
 
-def cpu_baseline(p, key, seconds_target=15.0):
+def cpu_baseline(p, sk, key_seed, seconds_target=15.0):
     """Oracle 'port' (oracle/sgfhe_oracle.c: reference-shaped, 128-bit Montgomery, 24 NTTs per
     iteration) timed on one host core over a truncated k-loop of ONE bootstrap, scaled to a full
-    bootstrap.  Test infrastructure used as a reported baseline only."""
+    bootstrap.  Test infrastructure used as a reported baseline only.  The key is the oracle's
+    own generation from the same seed (the same key as on the device)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle_c
     o = oracle_c.Oracle.from_params(p)
+    key = o.bootstrap_key(sk, key_seed)
     rng = np.random.default_rng(7)
     a = rng.integers(0, p.r, size=(2, p.n), dtype=np.uint64)
     b = rng.integers(0, p.r, size=2, dtype=np.uint64)
@@ -133,11 +136,11 @@ def main():
     eng.set_lanes(args.lanes)
 
     # ---- bootstrap key: rank 0 transforms, peers receive the device form over RCCL -------------
-    key = None
     kbytes = eng.key_device_form_bytes()
+    sk = np.random.default_rng(11).integers(0, 2, size=p.n, dtype=np.uint64)
+    KEY_SEED = 1
     if rank == 0:
-        key = random_key(p, 1)
-        eng.upload_key(key)
+        eng.generate_key(sk, KEY_SEED)
     if world > 1:
         blob = torch.empty(kbytes, dtype=torch.uint8, device="cuda")
         if rank == 0:
@@ -213,7 +216,7 @@ def main():
                                    "deterministic flatten" % (args.config, B),
                        "n": p.n, "m": p.m, "log2_Q": round(float(np.log2(float(p.Q))), 2),
                        "batch_per_gpu": B, "chunk": chunk, "lanes": args.lanes, "rns_primes": 5,
-                       "key": "uniform random residues mod Q (synthetic)",
+                       "key": "generated on the device from a seed (valid key)",
                        "key_broadcast_s": round(bcast_s, 4)},
             "roofline": {"bound": "hbm", "kernel": "k_extprod", "achieved": achieved,
                          "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": achieved / PEAK_HBM_GBS,
@@ -225,7 +228,7 @@ def main():
                          "whole_job_frac": per_boot * value / world / (PEAK_HBM_GBS * 1e9)},
         }
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(p, key)
+            res["cpu_baseline"] = cpu_baseline(p, sk, KEY_SEED)
         print(json.dumps(res))
     if dist:
         dist.destroy_process_group()
