@@ -66,6 +66,9 @@ mutable struct HipBootstrapKey
         finalizer(k -> ccall((:sgfhe_ctx_destroy, libsgfhe_hip), Int32, (Ptr{Cvoid},), k.ctx), key)
         key
     end
+
+    # raw constructor used by the generate-on-device method below
+    HipBootstrapKey(params::Params, ctx::Ptr{Cvoid}, ::Nothing) = new(params, ctx)
 end
 
 # Vector{ModUInt{UInt64, r}} is an isbits array: reinterpret is a zero-copy n x UInt64 view
@@ -104,6 +107,48 @@ function SGFHE.bootstrap(hkey::HipBootstrapKey, rng::Nothing,
         end
     end
     res
+end
+
+"""
+    HipBootstrapKey(params, sk::PrivateKey, seed::UInt64; device=0)
+
+Generates the bootstrap key on the GPU (BootstrapKey(rng, sk), src/fhe.jl:181-201) from a seed.
+"""
+function HipBootstrapKey(params::Params, sk::SGFHE.PrivateKey, seed::UInt64; device::Integer=0)
+    cp = Ref(CParams(params.n, params.r, params.m, 2, words(params.Q), words(params.B),
+                     words(params.DQ_tilde)))
+    ctx = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ctx[], ccall((:sgfhe_ctx_create, libsgfhe_hip), Int32,
+                       (Ref{CParams}, Cint, Ref{Ptr{Cvoid}}), cp, device, ctx))
+    bits = UInt64[UInt64(value(c)) for c in sk.key.coeffs]
+    check(ctx[], ccall((:sgfhe_bkey_generate, libsgfhe_hip), Int32,
+                       (Ptr{Cvoid}, Ptr{UInt64}, Csize_t, UInt64, UInt32),
+                       ctx[], bits, length(bits), seed, UInt32(params.n)))
+    key = HipBootstrapKey(params, ctx[], nothing)
+    finalizer(k -> ccall((:sgfhe_ctx_destroy, libsgfhe_hip), Int32, (Ptr{Cvoid},), k.ctx), key)
+    key
+end
+
+"""
+    pack_encrypted_bits(hkey, nothing, enc_bits)
+
+src/fhe.jl:660-696 on the GPU: n EncryptedBits -> one RLWE Ciphertext.
+"""
+function SGFHE.pack_encrypted_bits(hkey::HipBootstrapKey, rng::Nothing,
+                                   enc_bits::AbstractVector{EncryptedBit})
+    p = hkey.params
+    @assert length(enc_bits) == p.n
+    a, b = lwe_words(enc_bits, p.n)
+    w = Vector{UInt64}(undef, p.m)
+    v = Vector{UInt64}(undef, p.m)
+    rc = ccall((:sgfhe_pack_encrypted_bits, libsgfhe_hip), Int32,
+               (Ptr{Cvoid}, Ptr{UInt64}, Ptr{UInt64}, Csize_t, Ptr{UInt64}, Ptr{UInt64}),
+               hkey.ctx, a, b, 1, w, v)
+    check(hkey.ctx, rc)
+    tp = ModUInt{UInt64, UInt64(p.r)}
+    mk(x) = tp(x, _verbatim)
+    SGFHE.Ciphertext(p, SGFHE.RLWE(Polynomial(mk.(w), negacyclic_modulus),
+                                   Polynomial(mk.(v), negacyclic_modulus)))
 end
 
 # The drop-in: same signature as src/fhe.jl:608-610, batch of one.
