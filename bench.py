@@ -124,7 +124,7 @@ def main():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or "RANK" in os.environ:      # launched by torch.distributed.run: RCCL over xGMI
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
@@ -141,7 +141,7 @@ def main():
     KEY_SEED = 1
     if rank == 0:
         eng.generate_key(sk, KEY_SEED)
-    if world > 1:
+    if dist:
         blob = torch.empty(kbytes, dtype=torch.uint8, device="cuda")
         if rank == 0:
             eng.export_key_device_form(blob.data_ptr())
