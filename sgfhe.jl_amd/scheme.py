@@ -166,20 +166,77 @@ class Ciphertext:
         self.params, self.rlwe = params, rlwe
 
 
-def encrypt(key, rng, message):
-    """encrypt(key::PrivateKey, rng, message) (src/fhe.jl:369-372, _encrypt_private :310-328).
-    `a` is drawn from `rng` directly instead of the reference's seed expansion
-    (prng_expand, src/utils.jl:63-68)."""
+def packbits(bits):
+    """packbits (src/utils.jl:36-42): a (t, n) bit array -> n integers, row i = bit i."""
+    bits = np.asarray(bits, dtype=np.uint64)
+    return (bits << np.arange(bits.shape[0], dtype=np.uint64)[:, None]).sum(axis=0, dtype=np.uint64)
+
+
+def unpackbits(arr, itemsize):
+    """unpackbits (src/utils.jl:48-54): n integers -> (itemsize, n) bit array."""
+    arr = np.asarray(arr, dtype=np.uint64)
+    return ((arr[None, :] >> np.arange(itemsize, dtype=np.uint64)[:, None]) & np.uint64(1)).astype(bool)
+
+
+def prng_expand(seq, factor):
+    """prng_expand (src/utils.jl:63-68): n seed bits -> n pseudo-random `factor`-bit integers,
+    deterministically.  The reference seeds a MersenneTwister with hash(seq) and marks SHAKE as
+    the intended primitive (utils.jl:64); this mirror uses SHAKE-256 of the packed seed bits."""
+    import hashlib
+    seq = np.asarray(seq, dtype=bool)
+    n = len(seq)
+    stream = hashlib.shake_256(np.packbits(seq).tobytes()).digest((factor * n + 7) // 8)
+    bits = np.unpackbits(np.frombuffer(stream, dtype=np.uint8))[:factor * n].reshape(factor, n)
+    return packbits(bits)
+
+
+def deterministic_expand(params, u):
+    """deterministic_expand (src/fhe.jl:304-307)."""
+    return prng_expand(u, params.t + 1) & np.uint64(params.r - 1)
+
+
+class PrivateEncryptedCiphertext:
+    """PrivateEncryptedCiphertext (src/fhe.jl:297-301): 6 n bits for n message bits."""
+
+    def __init__(self, params, u, v):
+        self.params, self.u, self.v = params, u, v
+
+
+def _encrypt_private(key, rng, message):
+    """_encrypt_private (src/fhe.jl:310-328)."""
     p = key.params
     message = np.asarray(message, dtype=np.uint64)
     if len(message) != p.n:
         raise AssertionError("message must have length n (src/fhe.jl:313)")
-    a = rng.integers(0, p.r, size=p.n, dtype=np.uint64)
+    u = rng.integers(0, 2, size=p.n).astype(bool)                         # fhe.jl:315
+    a = deterministic_expand(p, u)                                        # fhe.jl:316
     w_range = p.Dr // 8                                                   # fhe.jl:318
     w = rng.integers(-w_range, w_range + 1, size=p.n).astype(np.int64).astype(np.uint64)
     b = (_negacyclic_mul_small(a, key.key, p.r) + w + message * np.uint64(p.Dr)) & np.uint64(p.r - 1)
     sh = np.uint64(p.t - 4)
     b = (b >> sh) << sh                                                   # fhe.jl:325
+    return u, RLWE(a, b)
+
+
+def encrypt(key, rng, message):
+    """encrypt(key::PrivateKey, rng, message) (src/fhe.jl:369-372)."""
+    u, rlwe = _encrypt_private(key, rng, message)
+    return PackedCiphertext(key.params, rlwe)
+
+
+def encrypt_optimal(key, rng, message):
+    """encrypt_optimal(key::PrivateKey, rng, message) (src/fhe.jl:339-345)."""
+    p = key.params
+    u, rlwe = _encrypt_private(key, rng, message)
+    b_packed = rlwe.b >> np.uint64(p.t - 4)                               # fhe.jl:342
+    return PrivateEncryptedCiphertext(p, u, unpackbits(b_packed, 5))
+
+
+def normalize_ciphertext(ct):
+    """normalize_ciphertext(::PrivateEncryptedCiphertext) (src/fhe.jl:354-359)."""
+    p = ct.params
+    a = deterministic_expand(p, ct.u)
+    b = (packbits(ct.v) << np.uint64(p.t - 4)) & np.uint64(p.r - 1)
     return PackedCiphertext(p, RLWE(a, b))
 
 

@@ -62,6 +62,29 @@ def test_encrypt_split_decrypt_roundtrip(S):
         S.encrypt(sk, rng, msg[:-1])
 
 
+def test_encrypt_optimal_normalize_decrypt(S):
+    """test/api.test.jl:8-17: encrypt_optimal -> normalize_ciphertext -> decrypt, Params(512)."""
+    p = S.Params(512)
+    rng = np.random.default_rng(1)
+    sk = S.PrivateKey(p, rng)
+    msg = rng.integers(0, 2, size=p.n).astype(bool)
+    ct = S.encrypt_optimal(sk, rng, msg)
+    assert ct.u.shape == (p.n,) and ct.v.shape == (5, p.n)          # 6 n bits in total
+    assert np.array_equal(S.decrypt(sk, S.normalize_ciphertext(ct)), msg)
+
+
+def test_packbits_roundtrip_and_expand_determinism(S):
+    rng = np.random.default_rng(2)
+    vals = rng.integers(0, 1 << 13, size=100, dtype=np.uint64)
+    assert np.array_equal(S.packbits(S.unpackbits(vals, 13)), vals)
+    u = rng.integers(0, 2, size=64).astype(bool)
+    a1, a2 = S.prng_expand(u, 10), S.prng_expand(u.copy(), 10)
+    assert np.array_equal(a1, a2) and int(a1.max()) < 1 << 10
+    u2 = u.copy()
+    u2[3] ^= True
+    assert not np.array_equal(S.prng_expand(u2, 10), a1)
+
+
 def test_extract_matches_reference_semantics(S):
     """src/fhe.jl:237-244 against the oracle's literal restatement."""
     Q = 1 << 10
