@@ -78,6 +78,7 @@ struct sgfhe_ctx {
     // device constants
     PrimeK *d_primes = nullptr;
     CrtConst *d_crt = nullptr;
+    uint32_t *d_bad = nullptr;  // set by k_key_transform when a key residue is >= Q
     uint32_t *d_tw = nullptr;  // NPR * 2 * M entries
     CrtConst h_crt;
     uint32_t pack_G = 1;  // key slices per exact-accumulation group of the packing path
@@ -205,7 +206,8 @@ template <int LOGM>
 int32_t launch_keytr_t(sgfhe_ctx *c, const ulonglong2 *canon, uint32_t *keyhat, uint32_t poly0,
                        uint32_t npolys, hipStream_t st) {
     hipLaunchKernelGGL(k_key_transform<LOGM>, dim3(npolys * NPR), dim3(threads_of<LOGM>()),
-                       lds_bytes(LOGM, 1), st, canon, keyhat, c->d_primes, c->d_crt, poly0);
+                       lds_bytes(LOGM, 1), st, canon, keyhat, c->d_primes, c->d_crt, poly0,
+                       c->d_bad);
     HIPCHK(c, hipGetLastError());
     return SGFHE_OK;
 }
@@ -508,6 +510,8 @@ int32_t build_constants(sgfhe_ctx *c) {
     HIPCHK(c, hipMemcpy(c->d_tw, tw.data(), tw.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     HIPCHK(c, hipMalloc(&c->d_primes, NPR * sizeof(PrimeK)));
     HIPCHK(c, hipMemcpy(c->d_primes, pk.data(), NPR * sizeof(PrimeK), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMalloc(&c->d_bad, sizeof(uint32_t)));
+    HIPCHK(c, hipMemset(c->d_bad, 0, sizeof(uint32_t)));
     HIPCHK(c, hipMalloc(&c->d_crt, sizeof(CrtConst)));
     HIPCHK(c, hipMemcpy(c->d_crt, &cc, sizeof(CrtConst), hipMemcpyHostToDevice));
     return SGFHE_OK;
@@ -608,6 +612,7 @@ int32_t sgfhe_ctx_destroy(sgfhe_ctx *c) {
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->d_primes) (void)hipFree(c->d_primes);
     if (c->d_crt) (void)hipFree(c->d_crt);
+    if (c->d_bad) (void)hipFree(c->d_bad);
     if (c->d_tw) (void)hipFree(c->d_tw);
     if (c->d_key) (void)hipFree(c->d_key);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -634,8 +639,15 @@ int32_t sgfhe_bkey_upload(sgfhe_ctx *c, const uint64_t *canonical, size_t n_word
     if (n_words != expect) return fail(c, SGFHE_ERR_INVALID_ARG, "bkey_upload: n_words != n*8*m*2");
     int32_t rc = key_alloc(c);
     if (rc) return rc;
+    HIPCHK(c, hipMemset(c->d_bad, 0, sizeof(uint32_t)));
     rc = key_transform_host(c, canonical, c->n * 8, c->d_key);
     if (rc) return rc;
+    uint32_t bad = 0;
+    HIPCHK(c, hipMemcpy(&bad, c->d_bad, sizeof bad, hipMemcpyDeviceToHost));
+    if (bad) {
+        c->have_key = false;
+        return fail(c, SGFHE_ERR_INVALID_ARG, "bkey_upload: a residue is not in [0, Q)");
+    }
     c->have_key = true;
     return SGFHE_OK;
 }

@@ -764,7 +764,7 @@ k_keygen_finish(const ulonglong2 *__restrict__ acan, const ulonglong2 *__restric
 template <int LOGM>
 __global__ void __launch_bounds__((NttGeom<LOGM, LOGE>::T))
 k_key_transform(const ulonglong2 *__restrict__ canon, uint32_t *__restrict__ keyhat, PrimeSet PS,
-                const CrtConst *__restrict__ CC, uint32_t poly0) {
+                const CrtConst *__restrict__ CC, uint32_t poly0, uint32_t *__restrict__ bad) {
     using G = NttGeom<LOGM, LOGE>;
     constexpr int M = G::M, T = G::T, E = G::E;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
@@ -783,6 +783,7 @@ k_key_transform(const ulonglong2 *__restrict__ canon, uint32_t *__restrict__ key
         uint32_t r = csub(mont_mul(c0, P.r1, p, P.ninv) + mont_mul(c1, P.r2, p, P.ninv), p);
         r = csub(r + mont_mul(c2, P.r3, p, P.ninv), p);
         const u128 C = ((u128)v.y << 64) | v.x;
+        if (C >= CC->Q) *bad = 1u;  // not a canonical residue: reported by the upload call
         if (C > halfQ) { r = r - P.qmodp; r = min(r, r + p); }
         x[0][e] = mont_mul(r, P.kappaR, p, P.ninv);
     }

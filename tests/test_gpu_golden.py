@@ -146,6 +146,13 @@ def test_no_key_and_bad_parameters_fail_loudly(S):
     assert ei.value.code == -5
     with pytest.raises(ValueError):
         eng.upload_key(np.zeros(10, dtype=np.uint64))
+    p = S.Params(64)
+    bad = np.zeros((p.n, 4, 2, p.m, 2), dtype=np.uint64)
+    bad[3, 1, 0, 7, 0] = p.Q & 0xFFFFFFFFFFFFFFFF             # == Q: not canonical
+    bad[3, 1, 0, 7, 1] = p.Q >> 64
+    with pytest.raises(S.SgfheError) as ei:
+        eng.upload_key(bad)
+    assert ei.value.code == -1
     eng.close()
     with pytest.raises(S.SgfheError):
         S.Engine(S.Params.custom(8, 1 << 100, 1 << 61))       # Q >= 2^94
