@@ -77,6 +77,16 @@ int32_t sgfhe_set_chunk(sgfhe_ctx *ctx, uint32_t chunk);
 int32_t sgfhe_set_lanes(sgfhe_ctx *ctx, uint32_t lanes);
 
 /*
+ * Flatten mode of the external product.  enable = 0 (default): deterministic flatten, the
+ * `rng = nothing` branch (src/utils.jl:155-189), bit-exact with the reference.  enable = 1:
+ * randomised flatten, the `rng::AbstractRNG` branch (src/utils.jl:198-241): every digit gets a
+ * uniform v in [-3B/2, 3B/2] drawn from a Philox counter stream of `seed`; digits lie in
+ * (-2B, 2B].  The results decrypt like the reference's but are not bit-comparable with it
+ * (Julia's MersenneTwister stream is not reproduced).  Applies to later bootstrap calls.
+ */
+int32_t sgfhe_set_random_flatten(sgfhe_ctx *ctx, int enable, uint64_t seed);
+
+/*
  * Upload a bootstrap key.  `canonical` (host memory) holds value.(p.coeffs) of
  * `BootstrapKey.key` (src/fhe.jl:176-201) in index order [k in 0..n)[row in 0..4)[col in 0..2)
  * [coef in 0..m), each residue 2 x uint64 little-endian; n_words = n * 8 * m * 2.

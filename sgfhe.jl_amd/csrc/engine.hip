@@ -88,6 +88,10 @@ struct sgfhe_ctx {
     bool have_key = false;
     // work buffers: two lanes, each sized for `cap` bootstraps
     uint32_t chunk = 0, cap = 0, lanes = 1;
+    // randomised flatten (rng != nothing, utils.jl:198-241)
+    bool rnd = false, rnd_ok = false;
+    uint64_t rnd_seed = 0;
+    uint32_t rnd_call = 0;
     struct Lane {
         uint64_t *dig = nullptr;
         uint32_t *yres = nullptr;
@@ -240,10 +244,10 @@ int32_t launch_dbgntt(sgfhe_ctx *c, const uint32_t *in, uint32_t *out, uint32_t 
 }
 
 int32_t launch_crt(sgfhe_ctx *c, const sgfhe_ctx::Lane &L, uint32_t cpad, uint32_t mode,
-                   hipStream_t st) {
+                   hipStream_t st, RndArgs ra = RndArgs{0, 0, 0, 0}, uint32_t iter = 0) {
     const uint32_t total = cpad * 2 * c->M;
     hipLaunchKernelGGL(k_crt_acc, dim3((total + 255) / 256), dim3(256), 0, st, L.yres, L.dig,
-                       c->d_crt, total, (uint32_t)c->logm, mode);
+                       c->d_crt, total, (uint32_t)c->logm, mode, ra, iter);
     HIPCHK(c, hipGetLastError());
     return SGFHE_OK;
 }
@@ -307,7 +311,7 @@ void timing_flush(sgfhe_ctx *c) {
 // ---- the k-loop over one chunk (fhe.jl:579-582) ---------------------------------------------------
 
 int32_t run_iterations(sgfhe_ctx *c, const sgfhe_ctx::Lane &L, uint32_t cpad, uint64_t n_iters,
-                       hipStream_t st, bool full_chunk) {
+                       hipStream_t st, bool full_chunk, uint32_t mode, RndArgs ra) {
     const size_t slice = (size_t)NPR * 8 * c->M;
     for (uint64_t k = 0; k < n_iters; k++) {
         const bool sample = c->timing && full_chunk && (k % 64 == 1) && c->ev.size() < 2048;
@@ -318,10 +322,10 @@ int32_t run_iterations(sgfhe_ctx *c, const sgfhe_ctx::Lane &L, uint32_t cpad, ui
             HIPCHK(c, hipEventCreate(&e2));
             HIPCHK(c, hipEventRecord(e0, st));
         }
-        int32_t rc = launch_extprod(c, L, c->d_key + k * slice, cpad, (uint32_t)k, 0, st);
+        int32_t rc = launch_extprod(c, L, c->d_key + k * slice, cpad, (uint32_t)k, mode, st);
         if (rc) return rc;
         if (sample) HIPCHK(c, hipEventRecord(e1, st));
-        rc = launch_crt(c, L, cpad, 0, st);
+        rc = launch_crt(c, L, cpad, mode, st, ra, (uint32_t)k + 1);
         if (rc) return rc;
         if (sample) {
             HIPCHK(c, hipEventRecord(e2, st));
@@ -339,6 +343,8 @@ int32_t bootstrap_device(sgfhe_ctx *c, const uint64_t *a1, const uint64_t *b1, c
     const uint32_t n = c->n, M = c->M;
     const bool raw = flags & SGFHE_FLAG_RAW_MODQ;
     const bool two_lanes = c->lanes == 2 && batch > chunk;
+    const uint32_t mode = c->rnd ? MODE_RANDOM : 0u;
+    const uint32_t call = c->rnd ? c->rnd_call++ : 0u;
     if (two_lanes) {  // fork: the second lane starts after everything already queued on st
         HIPCHK(c, hipEventRecord(c->ev_fork, st));
         HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
@@ -355,23 +361,24 @@ int32_t bootstrap_device(sgfhe_ctx *c, const uint64_t *a1, const uint64_t *b1, c
         const bool full_chunk = (c0 == 0);  // later chunks are the same size or a smaller tail
         if (full_chunk) c->last_chunk = cpad;
         const uint32_t tot = cpad * M;
+        const RndArgs ra = {(uint32_t)c->rnd_seed, (uint32_t)(c->rnd_seed >> 32), call, (uint32_t)c0};
         hipLaunchKernelGGL(k_init, dim3((tot + 255) / 256), dim3(256), 0, ls, a1 + c0 * n, b1 + c0,
                            a2 + c0 * n, b2 + c0, L.dig, L.ua, c->d_crt, cb, cpad, n,
-                           (uint32_t)c->logm);
+                           (uint32_t)c->logm, mode, ra);
         HIPCHK(c, hipGetLastError());
-        rc = run_iterations(c, L, cpad, n_iters, ls, li == 0 && cpad == c->last_chunk);
+        rc = run_iterations(c, L, cpad, n_iters, ls, li == 0 && cpad == c->last_chunk, mode, ra);
         if (rc) return rc;
         if (acc_out) {
             const uint32_t t2 = cb * 2 * M;
             hipLaunchKernelGGL(k_dump_acc, dim3((t2 + 255) / 256), dim3(256), 0, ls, L.dig,
-                               acc_out + c0 * 2 * M, c->d_crt, t2, (uint32_t)c->logm);
+                               acc_out + c0 * 2 * M, c->d_crt, t2, (uint32_t)c->logm, mode);
             HIPCHK(c, hipGetLastError());
         }
         if (out) {
             const uint32_t t3 = cb * (n + 1);
             hipLaunchKernelGGL(k_final, dim3((t3 + 255) / 256), dim3(256), 0, ls, L.dig,
                                out + c0 * 3 * (n + 1) * (raw ? 2 : 1), c->d_crt, cb, n,
-                               (uint32_t)c->logm, raw ? 1u : 0u);
+                               (uint32_t)c->logm, raw ? 1u : 0u, mode);
             HIPCHK(c, hipGetLastError());
         }
     }
@@ -429,6 +436,14 @@ int32_t build_constants(sgfhe_ctx *c) {
     cc.Q = Q;
     cc.B = B;
     cc.offneg = (Q - off) % Q;
+    {   // randomised flatten: v_i in [-xmax, xmax], digits shifted by s + xmax (utils.jl:204-216)
+        const u128 xmax = (B & 1) ? (B - 1) / 2 * 3 : B / 2 * 3;
+        const u128 stot = s + xmax;
+        cc.xmax = (uint64_t)xmax;
+        cc.offneg_rnd = (Q - (((1 + B) % Q) * (stot % Q)) % Q) % Q;
+        // |u| <= 2 B in that mode: the exactness bound needs 4 x more head-room
+        c->rnd_ok = (log_need + 2.0 <= log_have) && (B >> 60) == 0;
+    }
     cc.DQ = ld128(c->par.DQ_tilde) % Q;
     cc.halfQ = Q / 2;
     cc.roundthr = Q / 2 + (Q & 1);
@@ -493,6 +508,10 @@ int32_t build_constants(sgfhe_ctx *c) {
         P.r2 = mulmod32(R1, R1, p);
         P.r3 = mulmod32(P.r2, R1, p);
         P.sR = p - mulmod32((uint32_t)(s % p), Rinv, p);  // in [1, p]
+        {
+            const u128 xmax = (B & 1) ? (B - 1) / 2 * 3 : B / 2 * 3;
+            P.sRr = p - mulmod32((uint32_t)((s + xmax) % p), Rinv, p);
+        }
         P.hoff = (i == NPR - 1) ? (p - 1) / 2 : 0;
         P.qmodp = (uint32_t)(Q % p);
         uint32_t Mi = 1;  // (M_rns / p_i) mod p_i
@@ -626,6 +645,17 @@ int32_t sgfhe_set_chunk(sgfhe_ctx *c, uint32_t chunk) {
     return SGFHE_OK;
 }
 
+int32_t sgfhe_set_random_flatten(sgfhe_ctx *c, int enable, uint64_t seed) {
+    if (!c) return SGFHE_ERR_INVALID_ARG;
+    if (enable && !c->rnd_ok)
+        return fail(c, SGFHE_ERR_UNSUPPORTED,
+                    "randomised flatten: 32 m B Q exceeds the product of the RNS primes");
+    c->rnd = enable != 0;
+    c->rnd_seed = seed;
+    c->rnd_call = 0;
+    return SGFHE_OK;
+}
+
 int32_t sgfhe_set_lanes(sgfhe_ctx *c, uint32_t lanes) {
     if (!c || lanes < 1 || lanes > 2) return SGFHE_ERR_INVALID_ARG;
     c->lanes = lanes;
@@ -688,7 +718,7 @@ int32_t sgfhe_bkey_generate(sgfhe_ctx *c, const uint64_t *sk, size_t n_sk, uint6
             // CRT of the exact product, canonical residues into d_prod ([row][m] 16-byte values)
             hipLaunchKernelGGL(k_crt_acc, dim3((tot + 255) / 256), dim3(256), 0, c->stream, d_y,
                                reinterpret_cast<uint64_t *>(d_prod), c->d_crt, tot, (uint32_t)c->logm,
-                               MODE_NOACC | MODE_CANON);
+                               MODE_NOACC | MODE_CANON, RndArgs{0, 0, 0, 0}, 0u);
             hipLaunchKernelGGL(k_keygen_finish, dim3((tot + 255) / 256), dim3(256), 0, c->stream, d_acan,
                                d_prod, d_e, d_sk, d_canon, c->d_crt, row0, R, (uint32_t)c->logm);
             if ((e = hipGetLastError())) break;

@@ -30,13 +30,13 @@ struct PrimeK {
     uint32_t p;       // prime
     uint32_t ninv;    // -p^-1 mod 2^32
     uint32_t sR;      // p - (s * R^-1 mod p) (digit offset s of utils.jl:162-166, R = 2^32)
+    uint32_t sRr;     // the same for the randomised flatten: offset s + xmax (utils.jl:198-241)
     uint32_t hoff;    // offset added to the output residue: (p-1)/2 for the last prime, else 0
     uint32_t r1, r2, r3;  // R, R^2, R^3 mod p
     uint32_t qmodp;   // Q mod p
     uint32_t kappaR;  // key scale kappa * R mod p, kappa = R^2 m^-1 (M/p)^-1 mod p
     uint32_t minvR;   // m^-1 * R mod p (debug inverse NTT scaling)
     float invp;       // 1 / p
-    uint32_t pad_;
     const uint32_t *twf;  // forward twiddles psi^bitrev(i) * R mod p (Montgomery form)
     const uint32_t *twi;  // inverse twiddles psi^-bitrev(i) * R mod p
 };
@@ -51,6 +51,8 @@ struct CrtConst {
     u128 c[NPR];         // (M / p_i) mod Q
     u128 T[NPR + 1];     // (-alpha * M - H') mod Q,  H' = (M / p_last) * (p_last - 1) / 2
     u128 offneg;         // (Q - off) mod Q, off = (1 + B) s mod Q
+    u128 offneg_rnd;     // the same with s + xmax in place of s (randomised flatten)
+    uint64_t xmax;       // v_i uniform in [-xmax, xmax], xmax = 3 (B / 2) (utils.jl:210-214)
     u128 DQ;             // DQ_tilde mod Q
     u128 halfQ;          // Q / 2 (centred lift of key residues)
     u128 roundthr;       // Q / 2 + (Q odd)        (utils.jl:84)
@@ -68,7 +70,9 @@ struct CrtConst {
 enum : uint32_t {
     MODE_PLAIN = 1u,  // k_extprod: no (x^j - 1) factor (external_product debug hook)
     MODE_NOACC = 2u,  // k_crt_acc: do not add the previous accumulator
-    MODE_CANON = 4u   // k_crt_acc: write canonical residues instead of digits
+    MODE_CANON = 4u,  // k_crt_acc: write canonical residues instead of digits
+    MODE_RANDOM = 16u // randomised flatten (rng != nothing, utils.jl:198-241): digits e_i hold
+                      // u_i + s + xmax, u_i in (-2B, 2B]
 };
 
 // ---- small 128-bit helpers -----------------------------------------------------------------
@@ -106,11 +110,49 @@ __device__ __forceinline__ void store_digits(uint64_t *__restrict__ dig, size_t 
     dig[(bc * 2 + 1) * M + i] = hi;
 }
 
+// ---- randomised flatten (utils.jl:198-241) ----------------------------------------------------------
+// Philox4x32-10 counter-based generator: (counter, key) -> 128 random bits.  Functional parity
+// only: the reference draws from Julia's MersenneTwister, which is not reproducible here.
+struct RndArgs {
+    uint32_t key0, key1;   // seed
+    uint32_t call, chunk;  // per-call counter, first bootstrap of the chunk
+};
+__device__ __forceinline__ uint4 philox4x32(uint4 c, uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        const uint32_t h0 = __umulhi(0xD2511F53u, c.x), l0 = 0xD2511F53u * c.x;
+        const uint32_t h1 = __umulhi(0xCD9E8D57u, c.z), l1 = 0xCD9E8D57u * c.z;
+        c = make_uint4(h1 ^ c.y ^ k0, l1, h0 ^ c.w ^ k1, l0);
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    return c;
+}
+// Digits of the randomised flatten of acc, given xn = (acc + (s + xmax)(1 + B)) mod Q:
+//   r_i = v_i + xmax uniform in [0, 2 xmax];  x2 = (xn - r_0 - r_1 B) mod Q = a' of utils.jl:179
+//   for the shifted value;  (lo, hi) = divmod(x2, B);  e_i = (lo, hi) + r_i  ( = u_i + s + xmax ).
+__device__ __forceinline__ ulonglong2 random_digits(u128 xn, const CrtConst *CC, const RndArgs &ra,
+                                                    uint32_t t, uint32_t iter) {
+    const uint4 rv = philox4x32(make_uint4(t, iter, ra.chunk, ra.call), ra.key0, ra.key1);
+    const uint64_t span = 2 * CC->xmax + 1;
+    const uint64_t r0 = (uint64_t)(((u128)(((uint64_t)rv.y << 32) | rv.x) * span) >> 64);
+    const uint64_t r1 = (uint64_t)(((u128)(((uint64_t)rv.w << 32) | rv.z) * span) >> 64);
+    const u128 B = CC->B, Q = CC->Q;
+    const u128 tsub = mod_wide((u128)r1 * (uint64_t)B + r0, Q, CC->invQ, nullptr);
+    const u128 x2 = xn >= tsub ? xn - tsub : xn + Q - tsub;
+    uint64_t hi;
+    const u128 lo = mod_wide(x2, B, CC->invB, &hi);
+    return make_ulonglong2((uint64_t)lo + r0, hi + r1);
+}
+
 // ---- digit -> residue ------------------------------------------------------------------------
 // (e - s) * R^-1 mod p, lazily in [0, 4p), for a raw digit e in [0, B), B < 2^62:
 // REDC(e) < e / 2^32 + p < 2^30 + p, plus the constant p - s R^-1.
+__device__ __forceinline__ uint32_t digit_reduce(uint64_t e, const PrimeK &P, uint32_t sR) {
+    return redc_mad(e, P.p, P.ninv) + sR;
+}
 __device__ __forceinline__ uint32_t digit_reduce(uint64_t e, const PrimeK &P) {
-    return redc_mad(e, P.p, P.ninv) + P.sR;
+    return digit_reduce(e, P, P.sR);
 }
 
 // ---- k_extprod ----------------------------------------------------------------------------------
@@ -147,6 +189,7 @@ k_extprod(const uint64_t *__restrict__ dig, const uint32_t *__restrict__ keyk,
     const uint32_t p = P.p;
     const Mod md = {P.p, P.ninv, 2 * P.p};
 
+    const uint32_t sRd = (mode & MODE_RANDOM) ? P.sRr : P.sR;  // digit offset of the flatten mode
     uint64_t acc0[E];  // 64-bit NTT-domain sum of column 0 over the four phases (< 8 p^2 < 2^63)
 #pragma unroll
     for (int e = 0; e < E; e++) { acc0[e] = 0; z1[e * T] = 0; }
@@ -165,7 +208,7 @@ k_extprod(const uint64_t *__restrict__ dig, const uint32_t *__restrict__ keyk,
 #ifdef SGFHE_ABL_NO_DIG
             x[0][e] = digit_reduce((uint64_t)(tid + e) * 0x9E3779B97F4Aull, P);  // timing-only build
 #else
-            x[0][e] = digit_reduce(d[tid + T * e], P);
+            x[0][e] = digit_reduce(d[tid + T * e], P, sRd);
 #endif
         // the exchange buffer is reused: every wave must have finished the previous phase's loads
         SGFHE_SYNC();
@@ -342,7 +385,8 @@ __device__ __forceinline__ U96 crt_reduce(const uint32_t (&y)[NPR], const CrtCon
 
 __global__ void __launch_bounds__(256)
 k_crt_acc(const uint32_t *__restrict__ yres, uint64_t *__restrict__ dig,
-          const CrtConst *__restrict__ CC, uint32_t total, uint32_t logm, uint32_t mode) {
+          const CrtConst *__restrict__ CC, uint32_t total, uint32_t logm, uint32_t mode,
+          RndArgs ra, uint32_t iter) {
     const uint32_t t = blockIdx.x * 256 + threadIdx.x;
     if (t >= total) return;
     const uint32_t M = 1u << logm;
@@ -358,6 +402,11 @@ k_crt_acc(const uint32_t *__restrict__ yres, uint64_t *__restrict__ dig,
     const uint64_t xlo = ((uint64_t)a.w1 << 32) | a.w0;
     if (mode & MODE_CANON) {  // canonical residues, interleaved {lo, hi} words
         reinterpret_cast<ulonglong2 *>(dig)[t] = make_ulonglong2(xlo, (uint64_t)a.w2);
+        return;
+    }
+    if (mode & MODE_RANDOM) {
+        const ulonglong2 e = random_digits(((u128)a.w2 << 64) | xlo, CC, ra, t, iter);
+        store_digits(dig, bc, i, M, e.x, e.y);
         return;
     }
     // digits: hi = x' / B (double estimate +- 1), lo = x' - hi B (exact modulo 2^64)
@@ -379,7 +428,7 @@ __global__ void __launch_bounds__(256)
 k_init(const uint64_t *__restrict__ a1, const uint64_t *__restrict__ b1,
        const uint64_t *__restrict__ a2, const uint64_t *__restrict__ b2,
        uint64_t *__restrict__ dig, uint32_t *__restrict__ ua, const CrtConst *__restrict__ CC,
-       uint32_t nvalid, uint32_t chunk, uint32_t n, uint32_t logm) {
+       uint32_t nvalid, uint32_t chunk, uint32_t n, uint32_t logm, uint32_t mode, RndArgs ra) {
     const uint32_t t = blockIdx.x * 256 + threadIdx.x;
     const uint32_t M = 1u << logm;
     if (t >= chunk * M) return;
@@ -389,24 +438,39 @@ k_init(const uint64_t *__restrict__ a1, const uint64_t *__restrict__ b1,
     const bool valid = b < nvalid;
     if (i < n) ua[(size_t)b * n + i] =
         valid ? (uint32_t)((a1[(size_t)b * n + i] + a2[(size_t)b * n + i]) & rmask) : 0u;
-    store_digits(dig, (size_t)b * 2 + 0, i, M, CC->dig0.x, CC->dig0.y);
-    ulonglong2 d = CC->dig0;
+    int tv = 0;
     if (valid) {
         const uint32_t ub = (uint32_t)((b1[b] + b2[b]) & rmask);
         const uint32_t Dr = M / 2;  // r / 4
         const uint32_t src = (i + ub) & rmask;
         const uint32_t s = src & (M - 1);
-        int tv = s < Dr ? 1 : (s == Dr ? 0 : -1);
+        tv = s < Dr ? 1 : (s == Dr ? 0 : -1);
         if (src & M) tv = -tv;
-        d = tv > 0 ? CC->digP : (tv < 0 ? CC->digN : CC->dig0);
     }
+    if (mode & MODE_RANDOM) {  // flatten(rng, .) of a = 0 and of b in {0, +-DQ_tilde}
+        const u128 Q = CC->Q;
+        const u128 offr = CC->offneg_rnd ? Q - CC->offneg_rnd : 0;
+        u128 xb = offr + (tv > 0 ? CC->DQ : (tv < 0 ? Q - CC->DQ : 0));
+        if (xb >= Q) xb -= Q;
+        const ulonglong2 ea = random_digits(offr, CC, ra, ((b * 2 + 0) << logm) + i, 0u);
+        const ulonglong2 eb = random_digits(xb, CC, ra, ((b * 2 + 1) << logm) + i, 0u);
+        store_digits(dig, (size_t)b * 2 + 0, i, M, ea.x, ea.y);
+        store_digits(dig, (size_t)b * 2 + 1, i, M, eb.x, eb.y);
+        return;
+    }
+    store_digits(dig, (size_t)b * 2 + 0, i, M, CC->dig0.x, CC->dig0.y);
+    ulonglong2 d = CC->dig0;
+    if (valid) d = tv > 0 ? CC->digP : (tv < 0 ? CC->digN : CC->dig0);
     store_digits(dig, (size_t)b * 2 + 1, i, M, d.x, d.y);
 }
 
 // ---- k_final ------------------------------------------------------------------------------------
 // LWE extraction (fhe.jl:585-592, extract :237-244 in its i >= n branch) and ModRed
 // (fhe.jl:616-618,644-648; rescale utils.jl:78-92).  One thread per (bootstrap, t in [0, n]).
-__device__ __forceinline__ u128 acc_from_digits(ulonglong2 d, const CrtConst *CC) {
+__device__ __forceinline__ u128 acc_from_digits(ulonglong2 d, const CrtConst *CC,
+                                                uint32_t mode = 0) {
+    if (mode & MODE_RANDOM)  // digits up to 4 B: reduce properly
+        return mod_wide((u128)d.y * (uint64_t)CC->B + d.x + CC->offneg_rnd, CC->Q, CC->invQ, nullptr);
     u128 x = (u128)d.y * (uint64_t)CC->B + d.x + CC->offneg;
     if (x >= CC->Q) x -= CC->Q;
     return x;
@@ -423,7 +487,8 @@ __device__ __forceinline__ uint64_t modred(u128 x, const CrtConst *CC) {
 }
 __global__ void __launch_bounds__(256)
 k_final(const uint64_t *__restrict__ dig, uint64_t *__restrict__ out,
-        const CrtConst *__restrict__ CC, uint32_t nvalid, uint32_t n, uint32_t logm, uint32_t raw) {
+        const CrtConst *__restrict__ CC, uint32_t nvalid, uint32_t n, uint32_t logm, uint32_t raw,
+        uint32_t mode) {
     const uint32_t t = blockIdx.x * 256 + threadIdx.x;
     if (t >= nvalid * (n + 1)) return;
     const uint32_t M = 1u << logm;
@@ -432,13 +497,13 @@ k_final(const uint64_t *__restrict__ dig, uint64_t *__restrict__ out,
     const u128 Q = CC->Q;
     u128 va, vo;
     if (e < n) {
-        va = acc_from_digits(load_digits(dig, ba, 3 * M / 4 - e, M), CC);
-        const u128 w = acc_from_digits(load_digits(dig, ba, M / 4 - e, M), CC);
+        va = acc_from_digits(load_digits(dig, ba, 3 * M / 4 - e, M), CC, mode);
+        const u128 w = acc_from_digits(load_digits(dig, ba, M / 4 - e, M), CC, mode);
         vo = w ? Q - w : 0;
     } else {
-        va = CC->DQ + acc_from_digits(load_digits(dig, bb, 3 * M / 4, M), CC);
+        va = CC->DQ + acc_from_digits(load_digits(dig, bb, 3 * M / 4, M), CC, mode);
         if (va >= Q) va -= Q;
-        const u128 w = acc_from_digits(load_digits(dig, bb, M / 4, M), CC);
+        const u128 w = acc_from_digits(load_digits(dig, bb, M / 4, M), CC, mode);
         vo = CC->DQ >= w ? CC->DQ - w : CC->DQ + Q - w;
     }
     const u128 vx = vo >= va ? vo - va : vo + Q - va;
@@ -459,11 +524,11 @@ k_final(const uint64_t *__restrict__ dig, uint64_t *__restrict__ out,
 // digits -> canonical accumulators (debug hook)
 __global__ void __launch_bounds__(256)
 k_dump_acc(const uint64_t *__restrict__ dig, ulonglong2 *__restrict__ out,
-           const CrtConst *__restrict__ CC, uint32_t total, uint32_t logm) {
+           const CrtConst *__restrict__ CC, uint32_t total, uint32_t logm, uint32_t mode) {
     const uint32_t t = blockIdx.x * 256 + threadIdx.x;
     if (t >= total) return;
     const uint32_t M = 1u << logm;
-    const u128 x = acc_from_digits(load_digits(dig, t >> logm, t & (M - 1), M), CC);
+    const u128 x = acc_from_digits(load_digits(dig, t >> logm, t & (M - 1), M), CC, mode);
     out[t] = make_ulonglong2((uint64_t)x, (uint64_t)(x >> 64));
 }
 

@@ -101,6 +101,11 @@ class Engine:
     def set_lanes(self, lanes):
         self._chk(self._L.sgfhe_set_lanes(self._h, lanes))
 
+    def set_random_flatten(self, enable, seed=0):
+        """rng != nothing branch of flatten (utils.jl:198-241): Philox stream of `seed`."""
+        self._chk(self._L.sgfhe_set_random_flatten(self._h, int(bool(enable)),
+                                                   seed & 0xFFFFFFFFFFFFFFFF))
+
     def _lwe_args(self, a1, b1, a2, b2):
         n = self.params.n
         a1, p1 = _c(a1)

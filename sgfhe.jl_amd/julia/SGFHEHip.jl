@@ -15,6 +15,7 @@ using SGFHE
 using SGFHE: Params, BootstrapKey, EncryptedBit, LWE
 using DarkIntegers
 using DarkIntegers: ModUInt, value, _verbatim
+using Random: AbstractRNG
 
 const libsgfhe_hip = get(ENV, "SGFHE_HIP_LIB", "libsgfhe_hip.so")
 
@@ -77,13 +78,23 @@ lwe_words(bits::AbstractVector{EncryptedBit}, n) =
     (reduce(vcat, [reinterpret(UInt64, b.lwe.a) for b in bits]),
      UInt64[reinterpret(UInt64, [b.lwe.b])[1] for b in bits])
 
-"""
-    bootstrap(hkey, nothing, enc_bits1, enc_bits2)
+# rng = nothing: deterministic flatten (src/utils.jl:155-189), bit-exact with the CPU path.
+# rng::AbstractRNG: randomised flatten (src/utils.jl:198-241) from a device Philox stream seeded
+# by one draw of `rng` -- same distribution, not the same stream as the CPU path.
+function set_flatten_mode(hkey, rng)
+    seed = rng === nothing ? UInt64(0) : rand(rng, UInt64)
+    check(hkey.ctx, ccall((:sgfhe_set_random_flatten, libsgfhe_hip), Int32,
+                          (Ptr{Cvoid}, Cint, UInt64), hkey.ctx, rng === nothing ? 0 : 1, seed))
+end
 
-Batched deterministic gate bootstrap on the GPU; returns a vector of (AND, OR, XOR) triples.
 """
-function SGFHE.bootstrap(hkey::HipBootstrapKey, rng::Nothing,
+    bootstrap(hkey, rng, enc_bits1, enc_bits2)
+
+Batched gate bootstrap on the GPU; returns a vector of (AND, OR, XOR) triples.
+"""
+function SGFHE.bootstrap(hkey::HipBootstrapKey, rng::Union{AbstractRNG,Nothing},
                          bits1::AbstractVector{EncryptedBit}, bits2::AbstractVector{EncryptedBit})
+    set_flatten_mode(hkey, rng)
     p = hkey.params
     n = p.n
     batch = length(bits1)
@@ -152,7 +163,8 @@ function SGFHE.pack_encrypted_bits(hkey::HipBootstrapKey, rng::Nothing,
 end
 
 # The drop-in: same signature as src/fhe.jl:608-610, batch of one.
-SGFHE.bootstrap(hkey::HipBootstrapKey, rng::Nothing, bit1::EncryptedBit, bit2::EncryptedBit) =
-    SGFHE.bootstrap(hkey, nothing, [bit1], [bit2])[1]
+SGFHE.bootstrap(hkey::HipBootstrapKey, rng::Union{AbstractRNG,Nothing},
+                bit1::EncryptedBit, bit2::EncryptedBit) =
+    SGFHE.bootstrap(hkey, rng, [bit1], [bit2])[1]
 
 end # module

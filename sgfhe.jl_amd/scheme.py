@@ -4,7 +4,8 @@
 Same names, argument order and error behaviour as src/fhe.jl; the work of `bootstrap()`
 (src/fhe.jl:608-621) is done by the HIP engine behind the C ABI.  Random numbers come from a
 numpy Generator (the reference's MersenneTwister streams are not reproducible outside Julia,
-SURVEY.md F6).  Only the deterministic bootstrap (`rng = nothing` -> `rng=None`) is implemented.
+SURVEY.md F6): `rng=None` is the deterministic, bit-exact bootstrap; a Generator selects the
+randomised flatten (functional parity only).
 """
 
 import numpy as np
@@ -294,11 +295,19 @@ def decrypt(key, ct):
 
 # ---- bootstrap -----------------------------------------------------------------------------------
 
+def _set_flatten_mode(bkey, rng):
+    """rng = None: deterministic flatten (bit-exact with the reference's `rng = nothing`); a numpy
+    Generator: randomised flatten on the device, seeded from it."""
+    if rng is None:
+        bkey.engine.set_random_flatten(False)
+    else:
+        bkey.engine.set_random_flatten(True, int(rng.integers(0, 1 << 63, dtype=np.uint64)))
+
+
 def bootstrap(bkey, rng, enc_bit1, enc_bit2):
     """bootstrap(bkey, rng, enc_bit1, enc_bit2) (src/fhe.jl:608-621): returns EncryptedBits of
     AND, OR, XOR.  A batch of 1 through the HIP engine."""
-    if rng is not None:
-        raise NotImplementedError("only the deterministic bootstrap (rng = nothing) is implemented")
+    _set_flatten_mode(bkey, rng)
     out = bkey.engine.bootstrap_batch(enc_bit1.lwe.a[None, :], [enc_bit1.lwe.b],
                                       enc_bit2.lwe.a[None, :], [enc_bit2.lwe.b])
     n = bkey.params.n
@@ -307,8 +316,7 @@ def bootstrap(bkey, rng, enc_bit1, enc_bit2):
 
 def bootstrap_batch(bkey, rng, enc_bits1, enc_bits2):
     """Batched form: two equally long lists of EncryptedBit -> list of (AND, OR, XOR) triples."""
-    if rng is not None:
-        raise NotImplementedError("only the deterministic bootstrap (rng = nothing) is implemented")
+    _set_flatten_mode(bkey, rng)
     if len(enc_bits1) != len(enc_bits2):
         raise ValueError("ragged batch")
     n = bkey.params.n

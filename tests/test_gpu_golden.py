@@ -341,3 +341,76 @@ def test_host_api_end_to_end(S):
     bkey_h = S.BootstrapKey(rng, key, on_host=True)       # host big-integer generation
     r = S.bootstrap(bkey_h, None, bits[0], bits[1])
     assert S.decrypt(key, r[0]) == (msg[0] & msg[1])
+
+
+# ---- randomised flatten (row N4: rng != nothing, src/utils.jl:198-241) ----------------------------------
+
+def test_random_flatten_decrypts_and_differs(S, p64):
+    """flatten(rng, ...) changes ciphertexts, not plaintexts (test/api.test.jl:61-92 runs the same
+    truth table for rng = nothing and a MersenneTwister).  Functional parity only: Julia's stream
+    is not reproducible, so the check is decryption plus noise size."""
+    params, o, sk, bkey, eng = p64
+    bits = np.array([0, 0, 0, 1, 1, 0, 1, 1] * 3, dtype=np.uint8)
+    a, b = o.lwe_encrypt_bits(sk, bits, 79)
+    a1, b1, a2, b2 = a[0::2], b[0::2], a[1::2], b[1::2]
+    det = eng.bootstrap_batch(a1, b1, a2, b2)
+    want = np.stack([bits[0::2] & bits[1::2], bits[0::2] | bits[1::2], bits[0::2] ^ bits[1::2]], 1)
+    outs = []
+    try:
+        for seed in (1, 2, 1):
+            eng.set_random_flatten(True, seed)
+            out = eng.bootstrap_batch(a1, b1, a2, b2)
+            outs.append(out)
+            for g in range(3):
+                dec = o.lwe_decrypt_bits(sk, out[:, g, :-1], out[:, g, -1])
+                assert np.array_equal(dec, want[:, g])
+        assert np.array_equal(outs[0], outs[2])            # same seed, same stream
+        assert not np.array_equal(outs[0], outs[1])
+        assert not np.array_equal(outs[0], det)
+        # the accumulators stay canonical residues and are different RLWE pairs
+        eng.set_random_flatten(True, 5)
+        acc_r = _u128_ints(eng.debug_accumulators(a1, b1, a2, b2, params.n))
+        eng.set_random_flatten(False)
+        acc_d = _u128_ints(eng.debug_accumulators(a1, b1, a2, b2, params.n))
+        assert max(acc_r) < params.Q and acc_r != acc_d
+    finally:
+        eng.set_random_flatten(False)
+    assert np.array_equal(eng.bootstrap_batch(a1, b1, a2, b2), det)   # back to bit-exact
+
+
+def test_random_flatten_chunks_draw_distinct_streams(S, p64):
+    """Identical inputs in different batch positions / chunks must not reuse random draws."""
+    params, o, sk, bkey, eng = p64
+    a, b = o.lwe_encrypt_bits(sk, np.array([1, 1], dtype=np.uint8), 80)
+    a1 = np.repeat(a[0:1], 20, 0); b1 = np.repeat(b[0:1], 20)
+    a2 = np.repeat(a[1:2], 20, 0); b2 = np.repeat(b[1:2], 20)
+    try:
+        eng.set_random_flatten(True, 9)
+        eng.set_chunk(8)
+        out = eng.bootstrap_batch(a1, b1, a2, b2)
+        again = eng.bootstrap_batch(a1, b1, a2, b2)        # call counter advances the stream
+    finally:
+        eng.set_chunk(0)
+        eng.set_random_flatten(False)
+    rows = {out[i].tobytes() for i in range(20)}
+    assert len(rows) == 20
+    assert not np.array_equal(out, again)
+    for g, w in enumerate((1, 1, 0)):
+        assert np.all(o.lwe_decrypt_bits(sk, out[:, g, :-1], out[:, g, -1]) == w)
+
+
+def test_random_flatten_params1024_and_host_api(S):
+    rng = np.random.default_rng(8)
+    params = S.Params(1024)
+    key = S.PrivateKey(params, rng)
+    bkey = S.BootstrapKey(rng, key)
+    msg = rng.integers(0, 2, size=params.n).astype(bool)
+    bits = S.split_ciphertext(S.encrypt(key, rng, msg))
+    res = S.bootstrap_batch(bkey, rng, bits[0:16:2], bits[1:16:2])
+    for i, (r_and, r_or, r_xor) in enumerate(res):
+        x, y = msg[2 * i], msg[2 * i + 1]
+        assert S.decrypt(key, r_and) == (x & y)
+        assert S.decrypt(key, r_or) == (x | y)
+        assert S.decrypt(key, r_xor) == (x ^ y)
+    r = S.bootstrap(bkey, None, bits[0], bits[1])           # and back to deterministic
+    assert S.decrypt(key, r[2]) == (msg[0] ^ msg[1])

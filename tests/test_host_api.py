@@ -95,12 +95,11 @@ def test_extract_matches_reference_semantics(S):
             assert got == BO.extract(a, i, n, Q)
 
 
-def test_bootstrap_rejects_rng(S):
+def test_pack_rejects_rng(S):
     class Dummy:
         params = S.Params(64)
-    eb = S.EncryptedBit(S.LWE(np.zeros(64, dtype=np.uint64), 0))
     with pytest.raises(NotImplementedError):
-        S.bootstrap(Dummy(), np.random.default_rng(0), eb, eb)
+        S.pack_encrypted_bits(Dummy(), np.random.default_rng(0), [])
 
 
 def test_library_exports_every_declared_symbol(S):
