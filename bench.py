@@ -64,15 +64,49 @@ def algorithmic_bytes_per_bootstrap(p, W, batch):
     return p.n * p.m * W * (4 + 8.0 / batch) + 40 * (p.n + 1)
 
 
-def measured_traffic(config, chunk):
-    """HBM bytes per k_extprod launch from the committed rocprofv3 PMC passes (FETCH_SIZE and
-    WRITE_SIZE are collected in separate profiler runs, not inside this process): see
-    profiles/r01_v2_hbm_traffic.json.  None unless the profile matches this workload."""
-    path = os.path.join(ROOT, "profiles", "r01_v2_hbm_traffic.json")
-    if config != "params1024" or chunk != 256 or not os.path.exists(path):
+def _counters(config, chunk):
+    """Per-launch PMC averages of the newest committed profile (tools/profile_round.sh collects
+    them in separate profiler runs, not inside this process).  None unless they match this
+    workload (Params(1024), chunk 256)."""
+    if config != "params1024" or chunk != 256:
         return None
-    with open(path) as f:
-        return json.load(f)["kernels"]["k_extprod"]["traffic_bytes_per_launch"]
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_counters.json")))
+    if files:
+        with open(files[-1]) as f:
+            return dict(json.load(f)["kernels"], source=os.path.basename(files[-1]))
+    path = os.path.join(ROOT, "profiles", "r01_v2_hbm_traffic.json")
+    if os.path.exists(path):
+        with open(path) as f:
+            return dict(json.load(f)["kernels"], source=os.path.basename(path))
+    return None
+
+
+def measured_traffic(config, chunk):
+    """HBM bytes per k_extprod launch (2 FETCH_SIZE + WRITE_SIZE, gfx950 correction) or None."""
+    c = _counters(config, chunk)
+    return c["k_extprod"].get("traffic_bytes_per_launch") if c else None
+
+
+# Issue rates measured on the MI355X by tools/ubench_int.hip (profiles/r01_ubench_valu.txt), in
+# 10^12 lane-operations per second, and k_extprod's static instruction mix (fractions of its VALU
+# instructions: v_mad_u64_u32, v_mul_lo_u32, everything else).
+VALU_RATE = {"mad64": 32.39, "mul": 34.38, "simple": 56.08}
+VALU_MIX = {"mad64": 0.205, "mul": 0.103, "simple": 0.692}
+
+
+def valu_roofline(config, chunk, ext_s):
+    """The bound that actually limits k_extprod: integer VALU issue.  achieved = VALU
+    instructions per launch (PMC SQ_INSTS_VALU) x 64 lanes / launch time; peak = the
+    micro-benchmarked issue rate of the same instruction mix."""
+    c = _counters(config, chunk)
+    if not c or "SQ_INSTS_VALU" not in c.get("k_extprod", {}) or ext_s <= 0:
+        return None
+    insts = c["k_extprod"]["SQ_INSTS_VALU"]
+    peak = 1.0 / sum(VALU_MIX[k] / VALU_RATE[k] for k in VALU_MIX)
+    ach = insts * 64 / ext_s / 1e12
+    return {"bound": "valu-int32", "achieved": ach, "peak": peak, "unit": "Tlane-op/s",
+            "frac": ach / peak, "valu_insts_per_launch": insts, "source": c["source"]}
 
 
 def cpu_baseline(p, sk, key_seed, seconds_target=15.0):
@@ -225,7 +259,8 @@ def main():
                          "algorithmic_bytes_per_launch": launch_bytes,
                          "pair_kernel": "k_crt_acc", "pair_launch_ms": tm["crt_ms"],
                          "pair_achieved": pair, "pair_frac": pair / PEAK_HBM_GBS,
-                         "whole_job_frac": per_boot * value / world / (PEAK_HBM_GBS * 1e9)},
+                         "whole_job_frac": per_boot * value / world / (PEAK_HBM_GBS * 1e9),
+                         "valu": valu_roofline(args.config, chunk, ext_s)},
         }
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(p, sk, KEY_SEED)

@@ -179,7 +179,11 @@ __device__ __forceinline__ uint32_t opaque_zero() {
 // the loads (they may alias, so it does).
 template <int LOGE, int SLOW>
 __device__ __forceinline__ void exchange_sync() {
+#ifdef SGFHE_ABL_ONEBAR  // timing-only build: the S = LOGE <-> 2 LOGE exchange without a barrier (wrong results)
+    if constexpr ((SLOW == 0 || SLOW == LOGE) && (1 << LOGE) <= 64) {
+#else
     if constexpr (SLOW == 0 && (1 << LOGE) <= 64) {
+#endif
 #ifndef SGFHE_ABL_NO_BARRIER
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 #endif

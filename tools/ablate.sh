@@ -6,6 +6,8 @@ cd "$(dirname "$0")/../sgfhe.jl_amd/csrc"
 mkdir -p ../../tools/abl
 build() { /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared $2 -o ../../tools/abl/lib_$1.so engine.hip 2>/dev/null; }
 build base ""
+build nobar "-DSGFHE_ABL_NO_BARRIER"
+build onebar "-DSGFHE_ABL_ONEBAR"
 build nolds "-DSGFHE_ABL_NO_LDS"
 build noldsbar "-DSGFHE_ABL_NO_LDS -DSGFHE_ABL_NO_BARRIER"
 build notw "-DSGFHE_ABL_NO_TW"

@@ -1,0 +1,68 @@
+"""Condense a tools/profile_round.sh output directory into the small files kept under profiles/:
+  profiles/<tag>_kernel_stats.csv   rocprofv3 --kernel-trace --stats summary of the default bench
+  profiles/<tag>_counters.json      per-launch averages of the PMC passes (HBM traffic with the
+                                    gfx950 FETCH_SIZE correction, VALU / LDS instruction counts)
+usage: python tools/summarize_profile.py gpurun_out/prof_<tag> <tag>"""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+
+def counter_avgs(d):
+    # group by grid size and keep the k-loop's launches (the most frequent grid): k_crt_acc is also
+    # launched, with other sizes, by the key generation that precedes the timed batch
+    res = collections.defaultdict(lambda: collections.defaultdict(lambda: collections.defaultdict(list)))
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            name = r["Kernel_Name"]
+            for k in ("k_extprod", "k_crt_acc", "k_init", "k_final"):
+                if k in name:
+                    res[k][r["Grid_Size"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    out = {}
+    for k, grids in res.items():
+        cs = max(grids.values(), key=lambda g: max(len(v) for v in g.values()))
+        out[k] = {c: (sum(v) / len(v), len(v)) for c, v in cs.items()}
+    return out
+
+
+def main():
+    src, tag = sys.argv[1], sys.argv[2]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    prof = os.path.join(root, "profiles")
+    os.makedirs(prof, exist_ok=True)
+    stats = glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursive=True)
+    if stats:
+        shutil.copy(stats[0], os.path.join(prof, "%s_kernel_stats.csv" % tag))
+    log = os.path.join(src, "bench_stats.log")
+    if os.path.exists(log):
+        lines = [l for l in open(log) if l.startswith("{")]
+        if lines:
+            open(os.path.join(prof, "%s_bench_under_rocprof.json" % tag), "w").write(lines[-1])
+    out = {"note": "rocprofv3 --pmc passes (one counter group per run, --kernel-trace only), "
+                   "bench.py --batch 256 --steps 1 --warmup 0 = one chunk of 256 bootstraps, "
+                   "Params(1024); per-launch averages. FETCH_SIZE / WRITE_SIZE are reported in KB; "
+                   "on gfx950 FETCH_SIZE counts half the bytes of wide coalesced reads "
+                   "(MI355X_MICROARCH.md, HBM section): traffic = (2 FETCH_SIZE + WRITE_SIZE) * 1024 B.",
+           "kernels": {}}
+    merged = collections.defaultdict(dict)
+    for sub in ("pmc_FETCH_SIZE", "pmc_WRITE_SIZE", "pmc_SQ"):
+        for k, cs in counter_avgs(os.path.join(src, sub)).items():
+            for c, (avg, n) in cs.items():
+                merged[k][c] = avg
+                merged[k]["launches"] = n
+    for k, cs in merged.items():
+        if "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
+            cs["traffic_bytes_per_launch"] = (2 * cs["FETCH_SIZE"] + cs["WRITE_SIZE"]) * 1024
+        if "SQ_INSTS_VALU" in cs and "SQ_WAVES" in cs and cs["SQ_WAVES"]:
+            cs["valu_insts_per_wave"] = cs["SQ_INSTS_VALU"] / cs["SQ_WAVES"]
+        out["kernels"][k] = cs
+    json.dump(out, open(os.path.join(prof, "%s_counters.json" % tag), "w"), indent=1)
+    print(json.dumps(out["kernels"], indent=1))
+
+
+if __name__ == "__main__":
+    main()
