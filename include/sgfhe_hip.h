@@ -153,7 +153,8 @@ int32_t sgfhe_external_product(sgfhe_ctx *ctx, const uint64_t *a, const uint64_t
  *   out_w, out_v : [count][m] uint64 in [0, r)         (Ciphertext.rlwe.a / .b coefficients)
  * Runs count * n gate bootstraps (trivial encryption of 1 paired with every bit, AND branch,
  * un-reduced), then the n half-width external products against the key on the device.
- * Host pointers; synchronous.
+ * Always the deterministic flatten (rng = nothing), whatever sgfhe_set_random_flatten selected
+ * for gate bootstraps.  Host pointers; synchronous.
  */
 int32_t sgfhe_pack_encrypted_bits(sgfhe_ctx *ctx, const uint64_t *a, const uint64_t *b,
                                   size_t count, uint64_t *out_w, uint64_t *out_v);

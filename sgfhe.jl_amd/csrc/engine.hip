@@ -933,8 +933,11 @@ int32_t sgfhe_pack_encrypted_bits(sgfhe_ctx *c, const uint64_t *a, const uint64_
         if ((e = hipMemcpyAsync(d_b1, ones.data(), nb * 8, hipMemcpyHostToDevice, c->stream))) break;
         if ((e = hipMemcpyAsync(d_a2, a, nb * n * 8, hipMemcpyHostToDevice, c->stream))) break;
         if ((e = hipMemcpyAsync(d_b2, b, nb * 8, hipMemcpyHostToDevice, c->stream))) break;
+        const bool rnd_saved = c->rnd;  // packing is deterministic whatever the bootstrap mode
+        c->rnd = false;
         rc = bootstrap_device(c, d_a1, d_b1, d_a2, d_b2, nb, (uint64_t *)d_raw, SGFHE_FLAG_RAW_MODQ,
                               c->n, nullptr, c->stream);
+        c->rnd = rnd_saved;
         if (rc) break;
         const size_t tf = count * n * n;
         hipLaunchKernelGGL(k_pack_flatten, dim3((unsigned)((tf + 255) / 256)), dim3(256), 0, c->stream,

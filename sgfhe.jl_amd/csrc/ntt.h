@@ -58,6 +58,8 @@ struct NttGeom {
     static constexpr int SLAST_INV = RHO ? LOGM - RHO - LOGE : STOP;   // last full inverse pass
 };
 
+typedef __attribute__((address_space(1))) uint32_t gmem_u32;  // a word known to be in global memory
+
 // ---- twiddles of one pass ---------------------------------------------------------------------
 // The E - 1 twiddles of a radix-E pass sit in registers in heap order: stage "local bit B" owns
 // entries [NG - 1, 2 NG - 1), NG = 2^(LOGE-1-B).  They are loaded (from L1/L2) BEFORE the LDS
@@ -67,7 +69,10 @@ template <int LOGM, int LOGE, int S, int BHI, int BLO>
 __device__ __forceinline__ void load_twiddles(uint32_t (&t)[(1 << LOGE) - 1], const uint32_t *tw,
                                               uint32_t hi) {
     constexpr int NG = 1 << (LOGE - 1 - BHI);
-    const uint32_t *w = tw + (1u << (LOGM - 1 - S - BHI)) + (hi << (LOGE - 1 - BHI));
+    // The table pointer comes out of a PrimeK record in memory, so the compiler only knows it as
+    // a generic pointer and would emit flat_load, which counts on lgkmcnt as well as vmcnt: every
+    // wait for an LDS exchange would then also wait for the twiddles prefetched across it.
+    const gmem_u32 *w = (const gmem_u32 *)tw + (1u << (LOGM - 1 - S - BHI)) + (hi << (LOGE - 1 - BHI));
 #pragma unroll
     for (int g = 0; g < NG; g++)
 #ifdef SGFHE_ABL_NO_TW

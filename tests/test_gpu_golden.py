@@ -399,6 +399,19 @@ def test_random_flatten_chunks_draw_distinct_streams(S, p64):
         assert np.all(o.lwe_decrypt_bits(sk, out[:, g, :-1], out[:, g, -1]) == w)
 
 
+def test_pack_stays_deterministic_in_random_mode(S, oc, p64):
+    params, o, sk, bkey, eng = p64
+    bits = np.random.default_rng(6).integers(0, 2, size=params.n).astype(np.uint8)
+    a, b = o.lwe_encrypt_bits(sk, bits, 81)
+    w0, v0 = eng.pack_encrypted_bits(a[None], b[None])
+    try:
+        eng.set_random_flatten(True, 3)
+        w1, v1 = eng.pack_encrypted_bits(a[None], b[None])
+    finally:
+        eng.set_random_flatten(False)
+    assert np.array_equal(w0, w1) and np.array_equal(v0, v1)
+
+
 def test_random_flatten_params1024_and_host_api(S):
     rng = np.random.default_rng(8)
     params = S.Params(1024)
@@ -414,3 +427,35 @@ def test_random_flatten_params1024_and_host_api(S):
         assert S.decrypt(key, r_xor) == (x ^ y)
     r = S.bootstrap(bkey, None, bits[0], bits[1])           # and back to deterministic
     assert S.decrypt(key, r[2]) == (msg[0] ^ msg[1])
+
+
+def test_chained_gates_soak(S):
+    """examples/depth.jl:36-78: feed (AND, XOR) of one level into the next for many levels; every
+    level must decrypt and the LWE error must stay inside the decryption margin (no growth with
+    depth: each bootstrap refreshes the noise).  16 independent chains in one batch, alternating
+    the deterministic and the randomised flatten."""
+    rng = np.random.default_rng(21)
+    params = S.Params(64)
+    key = S.PrivateKey(params, rng)
+    bkey = S.BootstrapKey(rng, key)
+    msg = rng.integers(0, 2, size=params.n).astype(bool)
+    bits = S.split_ciphertext(S.encrypt(key, rng, msg))
+    e1, e2 = list(bits[0:32:2]), list(bits[1:32:2])
+    y1, y2 = msg[0:32:2].copy(), msg[1:32:2].copy()
+
+    def lwe_error(eb, ref):
+        e = (int(eb.lwe.b) - int(np.sum(eb.lwe.a * key.key, dtype=np.uint64)) - int(ref) * params.Dr) % params.r
+        return e - params.r if e > params.r // 2 else e
+
+    worst = 0
+    for level in range(24):
+        res = S.bootstrap_batch(bkey, rng if level % 2 else None, e1, e2)
+        for i, (r_and, r_or, r_xor) in enumerate(res):
+            assert S.decrypt(key, r_and) == (y1[i] & y2[i])
+            assert S.decrypt(key, r_or) == (y1[i] | y2[i])
+            assert S.decrypt(key, r_xor) == (y1[i] ^ y2[i])
+        e1 = [r[0] for r in res]
+        e2 = [r[2] for r in res]
+        y1, y2 = y1 & y2, y1 ^ y2
+        worst = max(worst, max(abs(lwe_error(e, y)) for e, y in zip(e1 + e2, list(y1) + list(y2))))
+    assert worst < params.Dr // 2
