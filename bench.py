@@ -67,18 +67,15 @@ def algorithmic_bytes_per_bootstrap(p, W, batch):
 def _counters(config, chunk):
     """Per-launch PMC averages of the newest committed profile (tools/profile_round.sh collects
     them in separate profiler runs, not inside this process).  None unless they match this
-    workload (Params(1024), chunk 256)."""
-    if config != "params1024" or chunk != 256:
+    workload (Params(1024), same chunk)."""
+    if config != "params1024":
         return None
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_counters.json")))
-    if files:
-        with open(files[-1]) as f:
-            return dict(json.load(f)["kernels"], source=os.path.basename(files[-1]))
-    path = os.path.join(ROOT, "profiles", "r01_v2_hbm_traffic.json")
-    if os.path.exists(path):
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_counters.json")), reverse=True):
         with open(path) as f:
-            return dict(json.load(f)["kernels"], source=os.path.basename(path))
+            d = json.load(f)
+        if d.get("chunk", 256) == chunk:
+            return dict(d["kernels"], source=os.path.basename(path))
     return None
 
 

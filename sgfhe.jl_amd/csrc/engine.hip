@@ -260,10 +260,13 @@ size_t per_bootstrap_bytes(const sgfhe_ctx *c) {
     return (size_t)2 * c->M * sizeof(ulonglong2) + (size_t)2 * NPR * c->M * 4 + (size_t)c->n * 4;
 }
 
-// Default chunk: keep the per-iteration working set (digits + residues) of a chunk inside the
-// 256 MiB Infinity Cache, and give every CU several workgroups.
+// Default chunk: the per-iteration working set (digits + residues) of a chunk stays near the size
+// of the 256 MiB Infinity Cache while a launch is long enough to amortise its ramp-up and drain
+// (about 9 us per k_extprod launch).  Measured at Params(1024) (tools/chunk_sweep.py, us of
+// k_extprod per bootstrap and iteration): chunk 256 0.568, 408 0.553, 512 0.547, 608 0.572,
+// 816 0.575.
 uint32_t default_chunk(const sgfhe_ctx *c) {
-    size_t budget = (size_t)160 << 20;
+    size_t budget = (size_t)320 << 20;
     size_t k = budget / per_bootstrap_bytes(c);
     if (k >= 256) k = (k / 256) * 256;
     else k = (k / 8) * 8;

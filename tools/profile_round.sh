@@ -2,18 +2,19 @@
 # Run on the GPU box (through gpurun): kernel-trace stats of the default bench, then separate PMC
 # passes (never combined with other trace domains) on a one-chunk batch.  Results land in
 # gpurun_out/prof_$TAG; tools/summarize_profile.py turns them into the files kept under profiles/.
-#   usage: tools/profile_round.sh TAG
+#   usage: tools/profile_round.sh TAG [CHUNK]
 set -e
 TAG=${1:-rXX}
+CHUNK=${2:-512}   # one chunk of the engine default size at Params(1024)
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o run -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline > $OUT/bench_stats.log 2>&1
 echo "stats done"
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_$C -o run -- python3 bench.py --batch 256 --steps 1 --warmup 0 --no-cpu-baseline > $OUT/pmc_$C.log 2>&1
+  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_$C -o run -- python3 bench.py --batch $CHUNK --steps 1 --warmup 0 --no-cpu-baseline > $OUT/pmc_$C.log 2>&1
   echo "$C done"
 done
-rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVES --kernel-trace --output-format csv -d $OUT/pmc_SQ -o run -- python3 bench.py --batch 256 --steps 1 --warmup 0 --no-cpu-baseline > $OUT/pmc_SQ.log 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVES --kernel-trace --output-format csv -d $OUT/pmc_SQ -o run -- python3 bench.py --batch $CHUNK --steps 1 --warmup 0 --no-cpu-baseline > $OUT/pmc_SQ.log 2>&1
 echo "SQ done"
-python3 tools/summarize_profile.py $OUT $TAG
+python3 tools/summarize_profile.py $OUT $TAG $CHUNK

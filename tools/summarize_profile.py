@@ -2,7 +2,7 @@
   profiles/<tag>_kernel_stats.csv   rocprofv3 --kernel-trace --stats summary of the default bench
   profiles/<tag>_counters.json      per-launch averages of the PMC passes (HBM traffic with the
                                     gfx950 FETCH_SIZE correction, VALU / LDS instruction counts)
-usage: python tools/summarize_profile.py gpurun_out/prof_<tag> <tag>"""
+usage: python tools/summarize_profile.py gpurun_out/prof_<tag> <tag> [chunk]"""
 import collections
 import csv
 import glob
@@ -31,6 +31,7 @@ def counter_avgs(d):
 
 def main():
     src, tag = sys.argv[1], sys.argv[2]
+    chunk = int(sys.argv[3]) if len(sys.argv) > 3 else 256
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     prof = os.path.join(root, "profiles")
     os.makedirs(prof, exist_ok=True)
@@ -43,11 +44,11 @@ def main():
         if lines:
             open(os.path.join(prof, "%s_bench_under_rocprof.json" % tag), "w").write(lines[-1])
     out = {"note": "rocprofv3 --pmc passes (one counter group per run, --kernel-trace only), "
-                   "bench.py --batch 256 --steps 1 --warmup 0 = one chunk of 256 bootstraps, "
+                   "bench.py --batch %d --steps 1 --warmup 0 = one chunk of %d bootstraps, " % (chunk, chunk) +
                    "Params(1024); per-launch averages. FETCH_SIZE / WRITE_SIZE are reported in KB; "
                    "on gfx950 FETCH_SIZE counts half the bytes of wide coalesced reads "
                    "(MI355X_MICROARCH.md, HBM section): traffic = (2 FETCH_SIZE + WRITE_SIZE) * 1024 B.",
-           "kernels": {}}
+           "chunk": chunk, "kernels": {}}
     merged = collections.defaultdict(dict)
     for sub in ("pmc_FETCH_SIZE", "pmc_WRITE_SIZE", "pmc_SQ"):
         for k, cs in counter_avgs(os.path.join(src, sub)).items():
