@@ -242,55 +242,56 @@ k_extprod(const uint64_t *__restrict__ dig, const uint32_t *__restrict__ keyk,
             }
         }
     }
-    uint32_t z0[1][E];
+    // 4. inverse NTT of both columns at once (same twiddles, one set of exchanges; the second
+    //    exchange buffer is the LDS area that held z_1):
+    //    P_c = (M/p)^-1 * sum_row u_row (*) C_row[c]  mod p
+    uint32_t z[2][E];
 #pragma unroll
     for (int e = 0; e < E; e++) {
         const uint32_t r = redc_mad(acc0[e], p, P.ninv);  // [0, 3p)
-        z0[0][e] = condsub(r, md.p2);                     // [0, 2p)
+        z[0][e] = condsub(r, md.p2);                      // [0, 2p)
+        z[1][e] = z1[e * T];
     }
+    SGFHE_SYNC();  // every thread has taken its z_1 out of the buffer the exchanges now reuse
+    ntt_inverse<LOGM, 2, LOGE>(z, lds, P.twi, tid, md);
+#pragma unroll
+    for (int c = 0; c < 2; c++)
+#pragma unroll
+        for (int e = 0; e < E; e++) z[c][e] = csub(z[c][e], p);
 
     uint32_t *yb = yres + ((size_t)b * 2 * NPR + pi) * M;
-    const uint32_t j = (mode & MODE_PLAIN) ? 0u : ua[(size_t)b * n + k];
+    // 5. y = x^j P - P  (mul_by_xj_minus_one, fhe.jl:554-556, applied to the product)
+    if (mode & MODE_PLAIN) {
 #pragma unroll
-    for (int c = 0; c < 2; c++) {
-        // 4. inverse NTT -> P_c = (M/p)^-1 * sum_row u_row (*) C_row[c]  mod p
-        if (c > 0) {
-#pragma unroll
-            for (int e = 0; e < E; e++) z0[0][e] = z1[e * T];
-            SGFHE_SYNC();  // rotated reads of c = 0 are done before the buffer is rewritten
-        }
-        ntt_inverse<LOGM, 1, LOGE>(z0, lds, P.twi, tid, md);
-#pragma unroll
-        for (int e = 0; e < E; e++) z0[0][e] = csub(z0[0][e], p);
-
-        // 5. y = x^j P - P  (mul_by_xj_minus_one, fhe.jl:554-556, applied to the product)
-        if (mode & MODE_PLAIN) {
+        for (int c = 0; c < 2; c++)
 #pragma unroll
             for (int e = 0; e < E; e++)
-                yb[(size_t)c * NPR * M + tid + T * e] = csub(z0[0][e] + P.hoff, p);
-            continue;
-        }
-        lds_store<LOGM, 1, LOGE, G::STOP>(z0, lds, tid);
-        SGFHE_SYNC();
-        // Source index of output coefficient i = tid + T e is s_e = (i - j) mod 2m = s_0 + T e:
-        // the swizzled low part is computed once per thread.  Residues leave in [0, p]
-        // (p == 0 mod p: k_crt_acc's alpha estimate absorbs it exactly).
-        {
-            constexpr uint32_t LOWMASK = (1u << G::STOP) - 1u;
-            const uint32_t s0 = ((uint32_t)tid - j) & (2 * M - 1);
-            const uint32_t lowswz = swz<LOGE>(s0 & LOWMASK);
-            const uint32_t h0 = s0 >> G::STOP;
+                yb[(size_t)c * NPR * M + tid + T * e] = csub(z[c][e] + P.hoff, p);
+        return;
+    }
+    const uint32_t j = ua[(size_t)b * n + k];
+    lds_store<LOGM, 2, LOGE, G::STOP>(z, lds, tid);
+    SGFHE_SYNC();
+    // Source index of output coefficient i = tid + T e is s_e = (i - j) mod 2m = s_0 + T e:
+    // the swizzled low part is computed once per thread.  Residues leave in [0, p]
+    // (p == 0 mod p: k_crt_acc's alpha estimate absorbs it exactly).
+    {
+        constexpr uint32_t LOWMASK = (1u << G::STOP) - 1u;
+        const uint32_t s0 = ((uint32_t)tid - j) & (2 * M - 1);
+        const uint32_t lowswz = swz<LOGE>(s0 & LOWMASK);
+        const uint32_t h0 = s0 >> G::STOP;
 #pragma unroll
-            for (int e = 0; e < E; e++) {
-                const uint32_t he = h0 + e;
-                const uint32_t hipart = (he & (E - 1)) << G::STOP;
-                // swz is XOR-linear; for m = 8192 the e bits lie above every bit it reads
-                const uint32_t addr =
-                    hipart ^ lowswz ^ (G::STOP >= 9 ? 0u : swz_bits<LOGE>(hipart));
-                const uint32_t v = lds[addr];
+        for (int e = 0; e < E; e++) {
+            const uint32_t he = h0 + e;
+            const uint32_t hipart = (he & (E - 1)) << G::STOP;
+            // swz is XOR-linear; for m = 8192 the e bits lie above every bit it reads
+            const uint32_t addr = hipart ^ lowswz ^ (G::STOP >= 9 ? 0u : swz_bits<LOGE>(hipart));
+#pragma unroll
+            for (int c = 0; c < 2; c++) {
+                const uint32_t v = lds[c * M + addr];
                 const uint32_t vs = (he & E) ? p - v : v;  // x^m = -1
                 uint32_t d;
-                const bool borrow = __builtin_usub_overflow(vs, z0[0][e], &d);
+                const bool borrow = __builtin_usub_overflow(vs, z[c][e], &d);
                 uint32_t y = borrow ? d + p : d;           // [0, p]
                 if (P.hoff) y = condsub(y + P.hoff, p);    // wave-uniform: only the last prime
                 yb[(size_t)c * NPR * M + tid + T * e] = y;
