@@ -195,7 +195,11 @@ k_extprod(const uint64_t *__restrict__ dig, const uint32_t *__restrict__ keyk,
     for (int e = 0; e < E; e++) { acc0[e] = 0; z1[e * T] = 0; }
     // A real loop (not unrolled): one copy of the forward NTT in the instruction stream, and the
     // loads of a later phase cannot be hoisted over the registers of an earlier one.
+#ifdef SGFHE_PH_UNROLL
+#pragma unroll SGFHE_PH_UNROLL
+#else
 #pragma unroll 1
+#endif
     for (int ph = 0; ph < 4; ph++) {
         // The thread index is made opaque per iteration: otherwise the ~60 loop-invariant LDS /
         // twiddle addresses derived from it are hoisted out of the loop and spilled.

@@ -58,21 +58,36 @@ struct NttGeom {
     static constexpr int SLAST_INV = RHO ? LOGM - RHO - LOGE : STOP;   // last full inverse pass
 };
 
-typedef __attribute__((address_space(1))) uint32_t gmem_u32;  // a word known to be in global memory
+// A zero the compiler cannot see through.  Added to the twiddle pointer once per pass so that the
+// (read-only, hence freely hoistable) twiddle loads stay one pass ahead of their use and no
+// further: hoisting all ~46 loads of an NTT to its top costs that many registers.
+__device__ __forceinline__ uint32_t opaque_zero() {
+    uint32_t z = 0;
+    asm volatile("" : "+v"(z));
+    return z;
+}
+// The same in a scalar register, for addresses that are uniform over the wavefront.
+__device__ __forceinline__ uint32_t opaque_zero_s() {
+    uint32_t z = 0;
+    asm volatile("" : "+s"(z));
+    return z;
+}
+
+typedef __attribute__((address_space(4))) uint32_t gmem_u32;  // a word of read-only global memory ("constant")
 
 // ---- twiddles of one pass ---------------------------------------------------------------------
 // The E - 1 twiddles of a radix-E pass sit in registers in heap order: stage "local bit B" owns
 // entries [NG - 1, 2 NG - 1), NG = 2^(LOGE-1-B).  They are loaded (from L1/L2) BEFORE the LDS
 // exchange that precedes the pass, so the load latency overlaps the exchange and its barrier.
 
+// Pass S reads the table at an index built from tid >> S: for 2^S >= 64 that is the same for
+// every lane of a wavefront, so the loads are scalar (s_load into SGPRs: no VGPRs, no VMEM
+// traffic, no address arithmetic on the vector ALU).
 template <int LOGM, int LOGE, int S, int BHI, int BLO>
-__device__ __forceinline__ void load_twiddles(uint32_t (&t)[(1 << LOGE) - 1], const uint32_t *tw,
-                                              uint32_t hi) {
+__device__ __forceinline__ void load_twiddles_at(uint32_t (&t)[(1 << LOGE) - 1], const gmem_u32 *tw,
+                                                 uint32_t hi) {
     constexpr int NG = 1 << (LOGE - 1 - BHI);
-    // The table pointer comes out of a PrimeK record in memory, so the compiler only knows it as
-    // a generic pointer and would emit flat_load, which counts on lgkmcnt as well as vmcnt: every
-    // wait for an LDS exchange would then also wait for the twiddles prefetched across it.
-    const gmem_u32 *w = (const gmem_u32 *)tw + (1u << (LOGM - 1 - S - BHI)) + (hi << (LOGE - 1 - BHI));
+    const gmem_u32 *w = tw + (1u << (LOGM - 1 - S - BHI)) + (hi << (LOGE - 1 - BHI));
 #pragma unroll
     for (int g = 0; g < NG; g++)
 #ifdef SGFHE_ABL_NO_TW
@@ -80,7 +95,21 @@ __device__ __forceinline__ void load_twiddles(uint32_t (&t)[(1 << LOGE) - 1], co
 #else
         t[NG - 1 + g] = w[g];
 #endif
-    if constexpr (BHI > BLO) load_twiddles<LOGM, LOGE, S, BHI - 1, BLO>(t, tw, hi);
+    if constexpr (BHI > BLO) load_twiddles_at<LOGM, LOGE, S, BHI - 1, BLO>(t, tw, hi);
+}
+template <int LOGM, int LOGE, int S, int BHI, int BLO>
+__device__ __forceinline__ void load_twiddles(uint32_t (&t)[(1 << LOGE) - 1], const uint32_t *tw,
+                                              uint32_t hi) {
+    // The table pointer comes out of a PrimeK record in memory, so the compiler only knows it as
+    // a generic pointer and would emit flat_load, which counts on lgkmcnt as well as vmcnt: every
+    // wait for an LDS exchange would then also wait for the twiddles prefetched across it.
+    // The opaque zero keeps the loads one pass ahead of their use and no further.
+    if constexpr ((1 << S) >= 64) {
+        const uint32_t hu = __builtin_amdgcn_readfirstlane(hi);
+        load_twiddles_at<LOGM, LOGE, S, BHI, BLO>(t, (const gmem_u32 *)tw + opaque_zero_s(), hu);
+    } else {
+        load_twiddles_at<LOGM, LOGE, S, BHI, BLO>(t, (const gmem_u32 *)tw, hi);
+    }
 }
 
 // ---- one butterfly stage on local bit B of the register index e -----------------------------
@@ -168,15 +197,6 @@ __device__ __forceinline__ void lds_load(uint32_t (&x)[NP][1 << LOGE], const uin
 
 // ---- pass recursions ---------------------------------------------------------------------------
 
-// A zero the compiler cannot see through.  Added to the twiddle pointer once per pass so that the
-// (read-only, hence freely hoistable) twiddle loads stay one pass ahead of their use and no
-// further: hoisting all ~46 loads of an NTT to its top costs that many registers.
-__device__ __forceinline__ uint32_t opaque_zero() {
-    uint32_t z = 0;
-    asm volatile("" : "+v"(z));
-    return z;
-}
-
 // Synchronisation of the exchange between the layouts S = SLOW + LOGE and S = SLOW.  The exchange
 // between S = LOGE and S = 0 moves data only inside aligned groups of 2^LOGE consecutive threads
 // (thread (hi, lo) <-> thread (hi, e)), i.e. inside one wavefront: the LDS queue of a wave is
@@ -203,7 +223,7 @@ struct FwdPasses {
     static __device__ __forceinline__ void run(uint32_t (&x)[NP][1 << LOGE], uint32_t *lds,
                                                const uint32_t *tw, int tid, const Mod &md) {
         uint32_t t[(1 << LOGE) - 1];
-        load_twiddles<LOGM, LOGE, SCUR, LOGE - 1, 0>(t, tw + opaque_zero(), (uint32_t)tid >> SCUR);
+        load_twiddles<LOGM, LOGE, SCUR, LOGE - 1, 0>(t, tw, (uint32_t)tid >> SCUR);
         lds_store<LOGM, NP, LOGE, SPREV>(x, lds, tid);
         exchange_sync<LOGE, SCUR>();
         lds_load<LOGM, NP, LOGE, SCUR>(x, lds, tid);
@@ -222,7 +242,7 @@ struct InvPasses {
         inv_stages<NP, LOGE, 0, LOGE - 1>(x, t, md);
         if constexpr (SCUR < SLAST) {
             uint32_t tn[(1 << LOGE) - 1];
-            load_twiddles<LOGM, LOGE, SCUR + LOGE, LOGE - 1, 0>(tn, tw + opaque_zero(),
+            load_twiddles<LOGM, LOGE, SCUR + LOGE, LOGE - 1, 0>(tn, tw,
                                                                 (uint32_t)tid >> (SCUR + LOGE));
             lds_store<LOGM, NP, LOGE, SCUR>(x, lds, tid);
             exchange_sync<LOGE, SCUR>();
@@ -240,7 +260,7 @@ __device__ __forceinline__ void ntt_forward(uint32_t (&x)[NP][1 << LOGE], uint32
     using G = NttGeom<LOGM, LOGE>;
     constexpr int BLO = G::RHO == 0 ? 0 : LOGE - G::RHO;
     uint32_t t[(1 << LOGE) - 1];
-    load_twiddles<LOGM, LOGE, G::STOP, LOGE - 1, BLO>(t, tw + opaque_zero(), 0u);
+    load_twiddles<LOGM, LOGE, G::STOP, LOGE - 1, BLO>(t, tw, 0u);
     fwd_stages<NP, LOGE, LOGE - 1, BLO>(x, t, md);
     if constexpr (G::SFIRST >= 0)
         FwdPasses<LOGM, NP, LOGE, G::STOP, G::SFIRST>::run(x, lds, tw, tid, md);
@@ -254,20 +274,20 @@ __device__ __forceinline__ void ntt_inverse(uint32_t (&x)[NP][1 << LOGE], uint32
     using G = NttGeom<LOGM, LOGE>;
     if constexpr (G::RHO == 0) {
         uint32_t t[(1 << LOGE) - 1];
-        load_twiddles<LOGM, LOGE, 0, LOGE - 1, 0>(t, tw + opaque_zero(), (uint32_t)tid);
+        load_twiddles<LOGM, LOGE, 0, LOGE - 1, 0>(t, tw, (uint32_t)tid);
         InvPasses<LOGM, NP, LOGE, 0, G::STOP>::run(x, lds, tw, tid, md, t);
     } else {
         uint32_t tp[(1 << LOGE) - 1];
         if constexpr (G::SLAST_INV >= 0) {
             uint32_t t[(1 << LOGE) - 1];
-            load_twiddles<LOGM, LOGE, 0, LOGE - 1, 0>(t, tw + opaque_zero(), (uint32_t)tid);
+            load_twiddles<LOGM, LOGE, 0, LOGE - 1, 0>(t, tw, (uint32_t)tid);
             InvPasses<LOGM, NP, LOGE, 0, G::SLAST_INV>::run(x, lds, tw, tid, md, t);
-            load_twiddles<LOGM, LOGE, G::STOP, LOGE - 1, LOGE - G::RHO>(tp, tw + opaque_zero(), 0u);
+            load_twiddles<LOGM, LOGE, G::STOP, LOGE - 1, LOGE - G::RHO>(tp, tw, 0u);
             lds_store<LOGM, NP, LOGE, G::SLAST_INV>(x, lds, tid);
             SGFHE_SYNC();
             lds_load<LOGM, NP, LOGE, G::STOP>(x, lds, tid);
         } else {
-            load_twiddles<LOGM, LOGE, G::STOP, LOGE - 1, LOGE - G::RHO>(tp, tw + opaque_zero(), 0u);
+            load_twiddles<LOGM, LOGE, G::STOP, LOGE - 1, LOGE - G::RHO>(tp, tw, 0u);
         }
         inv_stages<NP, LOGE, LOGE - G::RHO, LOGE - 1>(x, tp, md);
     }
