@@ -166,18 +166,21 @@ __device__ __forceinline__ uint32_t lds_base(int tid) {
     const uint32_t hi = (uint32_t)tid >> S;
     return swz<LOGE>((hi << (S + LOGE)) | lo);
 }
+// Addresses are formed in bytes: the thread's swizzled base is shifted once and every element
+// costs one XOR with a compile-time constant (an index-then-scale form costs a shift per element).
 template <int LOGM, int NP, int LOGE, int S>
 __device__ __forceinline__ void lds_store(const uint32_t (&x)[NP][1 << LOGE], uint32_t *lds, int tid) {
 #ifdef SGFHE_ABL_NO_LDS
     return;  // timing-only build: no LDS exchange (wrong results)
 #endif
     constexpr int M = 1 << LOGM;
-    const uint32_t pb = lds_base<LOGE, S>(tid);
+    const uint32_t pb = lds_base<LOGE, S>(tid) << 2;
+    char *const base = reinterpret_cast<char *>(lds);
 #pragma unroll
     for (int e = 0; e < (1 << LOGE); e++) {
-        const uint32_t a = pb ^ swz<LOGE>((uint32_t)e << S);
+        const uint32_t a = pb ^ (swz<LOGE>((uint32_t)e << S) << 2);
 #pragma unroll
-        for (int q = 0; q < NP; q++) lds[q * M + a] = x[q][e];
+        for (int q = 0; q < NP; q++) *reinterpret_cast<uint32_t *>(base + q * M * 4 + a) = x[q][e];
     }
 }
 template <int LOGM, int NP, int LOGE, int S>
@@ -186,12 +189,13 @@ __device__ __forceinline__ void lds_load(uint32_t (&x)[NP][1 << LOGE], const uin
     return;
 #endif
     constexpr int M = 1 << LOGM;
-    const uint32_t pb = lds_base<LOGE, S>(tid);
+    const uint32_t pb = lds_base<LOGE, S>(tid) << 2;
+    const char *const base = reinterpret_cast<const char *>(lds);
 #pragma unroll
     for (int e = 0; e < (1 << LOGE); e++) {
-        const uint32_t a = pb ^ swz<LOGE>((uint32_t)e << S);
+        const uint32_t a = pb ^ (swz<LOGE>((uint32_t)e << S) << 2);
 #pragma unroll
-        for (int q = 0; q < NP; q++) x[q][e] = lds[q * M + a];
+        for (int q = 0; q < NP; q++) x[q][e] = *reinterpret_cast<const uint32_t *>(base + q * M * 4 + a);
     }
 }
 
