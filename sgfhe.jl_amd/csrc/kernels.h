@@ -217,21 +217,36 @@ k_extprod(const uint64_t *__restrict__ dig, const uint32_t *__restrict__ keyk,
         // the exchange buffer is reused: every wave must have finished the previous phase's loads
         SGFHE_SYNC();
 
-        // 2. forward NTT of u[ph]
-        ntt_forward<LOGM, 1, LOGE>(x, lds, P.twf, tid, md);
+        // 2. forward NTT of u[ph].  At m = 8192 the key slice rows of this phase are requested
+        //    before the last pass of the transform, so they have arrived (from L2) when the
+        //    products start; at smaller m the extra live registers cost more than the wait.
+        constexpr bool KEY_EARLY = LOGM >= 13;
+        const uint32_t *kp = keyk + ((size_t)pi * 8 + ph * 2) * M + E * tid;
+        uint4 ka4[E / 4], kb4[E / 4];
+        auto load_key = [&]() {
+#pragma unroll
+            for (int h = 0; h < E / 4; h++) {
+#ifdef SGFHE_ABL_NO_KEY
+                ka4[h] = make_uint4(tid, h, ph, 7u), kb4[h] = make_uint4(h, tid, 5u, ph);  // timing-only
+#else
+                ka4[h] = reinterpret_cast<const uint4 *>(kp)[h];
+                kb4[h] = reinterpret_cast<const uint4 *>(kp + M)[h];
+#endif
+            }
+        };
+        if constexpr (KEY_EARLY) {
+            ntt_forward<LOGM, 1, LOGE>(x, lds, P.twf, tid, md, load_key);
+        } else {
+            ntt_forward<LOGM, 1, LOGE>(x, lds, P.twf, tid, md);
+            load_key();
+        }
 
         // 3. pointwise: z_c += U * K[ph][c]   (fhe.jl:527-528 in the NTT domain), U in [0, 2p)
         //    column 0: 64-bit multiply-accumulate, reduced once after the loop
         //    column 1: Montgomery-reduced and added lazily (mod 2p) to the LDS accumulator
-        const uint32_t *kp = keyk + ((size_t)pi * 8 + ph * 2) * M + E * tid;
 #pragma unroll
         for (int h = 0; h < E / 4; h++) {
-#ifdef SGFHE_ABL_NO_KEY
-            const uint4 a = make_uint4(tid, h, ph, 7u), bq = make_uint4(h, tid, 5u, ph);  // timing-only
-#else
-            const uint4 a = reinterpret_cast<const uint4 *>(kp)[h];
-            const uint4 bq = reinterpret_cast<const uint4 *>(kp + M)[h];
-#endif
+            const uint4 a = ka4[h], bq = kb4[h];
             const uint32_t ka[4] = {a.x, a.y, a.z, a.w};
             const uint32_t kb[4] = {bq.x, bq.y, bq.z, bq.w};
 #pragma unroll

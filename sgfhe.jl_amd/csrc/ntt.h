@@ -222,18 +222,26 @@ __device__ __forceinline__ void exchange_sync() {
 }
 
 // forward LDS passes S = SCUR, SCUR - LOGE, ..., 0; data arrives in registers in layout SPREV
+struct NoHook {
+    __device__ __forceinline__ void operator()() const {}
+};
+// `before_last` runs just before the exchange into the last pass: the caller's place to issue
+// loads it needs right after the transform, so that their latency overlaps that pass.
 template <int LOGM, int NP, int LOGE, int SPREV, int SCUR>
 struct FwdPasses {
+    template <class F>
     static __device__ __forceinline__ void run(uint32_t (&x)[NP][1 << LOGE], uint32_t *lds,
-                                               const uint32_t *tw, int tid, const Mod &md) {
+                                               const uint32_t *tw, int tid, const Mod &md,
+                                               const F &before_last) {
         uint32_t t[(1 << LOGE) - 1];
         load_twiddles<LOGM, LOGE, SCUR, LOGE - 1, 0>(t, tw, (uint32_t)tid >> SCUR);
+        if constexpr (SCUR < LOGE) before_last();
         lds_store<LOGM, NP, LOGE, SPREV>(x, lds, tid);
         exchange_sync<LOGE, SCUR>();
         lds_load<LOGM, NP, LOGE, SCUR>(x, lds, tid);
         fwd_stages<NP, LOGE, LOGE - 1, 0>(x, t, md);
         if constexpr (SCUR >= LOGE)
-            FwdPasses<LOGM, NP, LOGE, SCUR, SCUR - LOGE>::run(x, lds, tw, tid, md);
+            FwdPasses<LOGM, NP, LOGE, SCUR, SCUR - LOGE>::run(x, lds, tw, tid, md, before_last);
     }
 };
 // inverse passes S = SCUR, SCUR + LOGE, ..., SLAST; data arrives in registers in layout SCUR and
@@ -258,16 +266,19 @@ struct InvPasses {
 
 // Forward transform.  In: x[q][e] = coefficient tid + T e of polynomial q, in [0, 4p).
 // Out: x[q][e] = slot E tid + e, in [0, 4p).  `lds` must hold NP * m words.
-template <int LOGM, int NP, int LOGE>
+template <int LOGM, int NP, int LOGE, class F = NoHook>
 __device__ __forceinline__ void ntt_forward(uint32_t (&x)[NP][1 << LOGE], uint32_t *lds,
-                                            const uint32_t *tw, int tid, const Mod &md) {
+                                            const uint32_t *tw, int tid, const Mod &md,
+                                            const F &before_last = F()) {
     using G = NttGeom<LOGM, LOGE>;
     constexpr int BLO = G::RHO == 0 ? 0 : LOGE - G::RHO;
     uint32_t t[(1 << LOGE) - 1];
     load_twiddles<LOGM, LOGE, G::STOP, LOGE - 1, BLO>(t, tw, 0u);
     fwd_stages<NP, LOGE, LOGE - 1, BLO>(x, t, md);
     if constexpr (G::SFIRST >= 0)
-        FwdPasses<LOGM, NP, LOGE, G::STOP, G::SFIRST>::run(x, lds, tw, tid, md);
+        FwdPasses<LOGM, NP, LOGE, G::STOP, G::SFIRST>::run(x, lds, tw, tid, md, before_last);
+    else
+        before_last();
 }
 
 // Inverse transform (unscaled).  In: slots E tid + e in [0, 2p).  Out: coefficient tid + T e in
