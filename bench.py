@@ -89,7 +89,7 @@ def measured_traffic(config, chunk):
 # 10^12 lane-operations per second, and k_extprod's static instruction mix (fractions of its VALU
 # instructions: v_mad_u64_u32, v_mul_lo_u32, everything else).
 VALU_RATE = {"mad64": 32.39, "mul": 34.38, "simple": 56.08}
-VALU_MIX = {"mad64": 0.205, "mul": 0.103, "simple": 0.692}
+VALU_MIX = {"mad64": 0.216, "mul": 0.111, "simple": 0.673}
 
 
 def valu_roofline(config, chunk, ext_s):
