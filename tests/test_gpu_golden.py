@@ -204,8 +204,43 @@ def test_rns2_key_upload_matches_canonical(S, oc):
     e2.close()
 
 
+def test_config4_full_ring_composite_modulus(S, oc):
+    """BASELINE.json config 4 at its real size: n = 1024, m = 8192, Q = B * Bp with the two primes
+    of the src/fhe2.jl:57-58 rule near 2^43.13 (Q ~ 2^86.3, not prime: the oracle multiplies by
+    schoolbook, so only the first k-loop iteration is compared), key handed over as RNS2Number
+    limb pairs (src/rns.jl:16-18)."""
+    import bench
+    import bigint_oracle as BO
+    n, m, r = 1024, 8192, 16384
+    bound = int((1220 * r ** 4 * n ** 2) ** 0.5)
+    Bp = BO.find_modulus(r, bound)
+    B = BO.find_modulus(r, Bp + 1)
+    Q = B * Bp
+    params = S.Params.custom(n, Q, B)
+    assert (params.m, params.r) == (m, r) and 86 < np.log2(float(Q)) < 87
+    o = oc.Oracle.from_params(params)
+    assert not o.uses_ntt
+    key = bench.random_key(params, 5)[:1]                      # only slice k = 0 is used
+    full = np.zeros((n, 4, 2, m, 2), dtype=np.uint64)
+    full[0] = key[0]
+    vals = oc.u128_to_ints(full[0])
+    pairs = np.zeros_like(full)
+    pairs[0] = np.array([BO.rns2_from_int(v, B, Bp) for v in vals], dtype=np.uint64).reshape(full[0].shape)
+    eng = S.Engine(params)
+    eng.upload_key_rns2(pairs, B, Bp)
+    rng = np.random.default_rng(6)
+    a1 = rng.integers(0, r, size=(2, n), dtype=np.uint64)
+    a2 = rng.integers(0, r, size=(2, n), dtype=np.uint64)
+    b1 = rng.integers(0, r, size=2, dtype=np.uint64)
+    b2 = rng.integers(0, r, size=2, dtype=np.uint64)
+    _, acc_ref = o.bootstrap_batch(full, a1, b1, a2, b2, n_iters=1, want_acc=True, threads=2)
+    acc = eng.debug_accumulators(a1, b1, a2, b2, 1)
+    assert np.array_equal(acc, acc_ref)
+    eng.close()
+
+
 def test_batch_position_independence_params1024(S):
-    """Full-size ring, 600 bootstraps (more than one 256-chunk): identical inputs at different
+    """Full-size ring, 600 bootstraps (more than one 512-chunk): identical inputs at different
     batch positions / chunks give identical outputs, different inputs give different ones."""
     import bench
     params = S.Params(1024)
