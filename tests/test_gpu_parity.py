@@ -158,10 +158,51 @@ def test_params512_vs_oracle(S, oc):
               iters_checked=(1, 2))
 
 
+def test_params512_full_batch_1024(S, oc):
+    """BASELINE.json config 2 at its full batch: 1024 bootstraps in one call (one 1024-chunk).
+    The oracle covers 8 distinct input pairs; the batch tiles them 128 times in a shuffled order,
+    so every one of the 1024 x 3 x 513 output words is pinned to an oracle word."""
+    params = S.Params(512)
+    o = oc.Oracle.from_params(params)
+    sk = o.private_key(11)
+    bkey = o.bootstrap_key(sk, 12)
+    eng = S.Engine(params)
+    eng.upload_key(bkey)
+    bits, a1, b1, a2, b2 = _inputs(o, sk, 8, 13)
+    ref = o.bootstrap_batch(bkey, a1, b1, a2, b2)
+    idx = np.random.default_rng(14).permutation(np.repeat(np.arange(8), 128))
+    out = eng.bootstrap_batch(a1[idx], b1[idx], a2[idx], b2[idx])
+    assert out.shape == (1024, 3, params.n + 1)
+    assert np.array_equal(out, ref[idx])
+    eng.close()
+
+
 def test_params1024_vs_oracle(S, oc):
     """BASELINE.json config 4' (the reference's own Params(1024), Q 86.25 bits)."""
     _big_case(S, oc, S.Params(1024), batch=4, key_seed=21, in_seed=22, valid_key=True,
               iters_checked=(1, 2))
+
+
+def test_params1024_full_batch_4096(S, oc):
+    """The bench workload at full size (Params(1024), batch 4096 = 8 chunks of 512): 4 input pairs
+    verified by the oracle, tiled 1024 times in a shuffled order; every output word is pinned to
+    an oracle word, across all chunks and batch positions.  The key comes from the device
+    generator (byte-identical to the oracle's for the same seed, tests/test_gpu_golden.py)."""
+    params = S.Params(1024)
+    o = oc.Oracle.from_params(params)
+    sk = o.private_key(21)
+    bkey = o.bootstrap_key(sk, 22)
+    eng = S.Engine(params)
+    eng.generate_key(sk, 22)
+    bits, a1, b1, a2, b2 = _inputs(o, sk, 4, 23)
+    ref = o.bootstrap_batch(bkey, a1, b1, a2, b2)
+    idx = np.random.default_rng(24).permutation(np.repeat(np.arange(4), 1024))
+    out = eng.bootstrap_batch(a1[idx], b1[idx], a2[idx], b2[idx])
+    assert np.array_equal(out, ref[idx])
+    y1, y2 = bits[0::2], bits[1::2]
+    dec = o.lwe_decrypt_bits(sk, out[:4096:512, 2, :params.n], out[:4096:512, 2, params.n])
+    assert np.array_equal(dec, (y1 ^ y2)[idx[:4096:512]])
+    eng.close()
 
 
 def test_synthetic_single_limb_1024(S, oc):
