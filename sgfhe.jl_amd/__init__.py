@@ -10,13 +10,14 @@ from ._lib import build, lib, LIB_PATH, EXPORTED_SYMBOLS
 from .engine import Engine, SgfheError, FLAG_RAW_MODQ
 from .params import Params, find_modulus, isprime
 from . import distributed
-from .scheme import (PrivateKey, BootstrapKey, LWE, RLWE, EncryptedBit, PackedCiphertext,
+from .scheme import (PrivateKey, PublicKey, PublicEncryptedCiphertext, BootstrapKey, LWE, RLWE, EncryptedBit, PackedCiphertext,
                      Ciphertext, encrypt, extract, split_ciphertext, decrypt, bootstrap,
                      bootstrap_batch, pack_encrypted_bits, encrypt_optimal, normalize_ciphertext,
                      PrivateEncryptedCiphertext, packbits, unpackbits, prng_expand)
 
 __all__ = ["distributed", "build", "lib", "LIB_PATH", "EXPORTED_SYMBOLS", "Engine", "SgfheError",
            "FLAG_RAW_MODQ", "Params", "find_modulus", "isprime", "PrivateKey", "BootstrapKey",
+           "PublicKey", "PublicEncryptedCiphertext",
            "LWE", "RLWE", "EncryptedBit", "PackedCiphertext", "encrypt", "extract",
            "split_ciphertext", "decrypt", "bootstrap", "bootstrap_batch", "Ciphertext",
            "pack_encrypted_bits", "encrypt_optimal", "normalize_ciphertext",

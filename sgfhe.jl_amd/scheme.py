@@ -30,6 +30,26 @@ def _negacyclic_mul_small(a, s, r):
     return (full[:n] - full[n:]) & np.uint64(r - 1)
 
 
+def _negacyclic_mul_signed(a, s, q):
+    """a * s mod (x^n + 1, q) for a in [0, q) (q < 2^31) and a short signed s (|s_i| small):
+    the `Polynomial * Polynomial` over Z_q of src/fhe.jl:164,399-400."""
+    n = len(a)
+    full = np.convolve(np.asarray(a, dtype=np.int64), np.asarray(s, dtype=np.int64))
+    full = np.concatenate([full, np.zeros(2 * n - len(full), dtype=np.int64)])
+    return ((full[:n] - full[n:]) % q).astype(np.uint64)
+
+
+def _rescale(new_max, x, old_max, round_result):
+    """rescale (src/utils.jl:78-92) on a vector: floor or round of x new_max / old_max, with the
+    rounded value new_max wrapping to 0.  All operands below 2^31."""
+    prod = np.asarray(x, dtype=np.uint64) * np.uint64(new_max)
+    quo, rem = prod // np.uint64(old_max), prod % np.uint64(old_max)
+    if round_result:
+        quo = quo + (rem >= np.uint64(old_max // 2 + (old_max & 1))).astype(np.uint64)
+        quo[quo == new_max] = 0
+    return quo
+
+
 def _negacyclic_mul_big(a, b, Q):
     """Exact product mod (x^N + 1, Q) of Python-int coefficient lists (Kronecker substitution)."""
     N = len(a)
@@ -67,6 +87,25 @@ class PrivateKey:
     def __init__(self, params, rng):
         self.params = params
         self.key = rng.integers(0, 2, size=params.n, dtype=np.uint64)
+
+
+class PublicKey:
+    """PublicKey(rng, sk) (src/fhe.jl:146-168): (k0, k1 = k0 s + e) over Z_q[x]/(x^n + 1).
+    The noise is centred on every coefficient, e_i in [-e_max, e_max] (the reference writes
+    `polynomial - e_max`, a DarkIntegers Polynomial - scalar whose coefficient rule cannot be
+    checked here; decryption holds either way)."""
+
+    def __init__(self, rng, sk):
+        p = sk.params
+        if not p.q:
+            raise AssertionError("synthetic parameter sets have no public-key modulus q")
+        self.params = p
+        self.k0 = rng.integers(0, p.q, size=p.n, dtype=np.uint64)               # fhe.jl:156
+        quo, rem = divmod(p.Dq, 41 * p.n)                                        # fhe.jl:159-160
+        e_max = quo - (rem == 0)
+        e = rng.integers(0, 2 * e_max + 1, size=p.n).astype(np.int64) - e_max    # fhe.jl:161
+        self.k1 = ((_negacyclic_mul_signed(self.k0, sk.key.astype(np.int64), p.q).astype(np.int64)
+                    + e) % p.q).astype(np.uint64)                                # fhe.jl:163-164
 
 
 class BootstrapKey:
@@ -219,23 +258,65 @@ def _encrypt_private(key, rng, message):
     return u, RLWE(a, b)
 
 
+class PublicEncryptedCiphertext:
+    """PublicEncryptedCiphertext (src/fhe.jl:380-384): (t + 1) + 6 bits per message bit."""
+
+    def __init__(self, params, a_bits, b_bits):
+        self.params, self.a_bits, self.b_bits = params, a_bits, b_bits
+
+
+def _encrypt_public(key, rng, message):
+    """_encrypt_public (src/fhe.jl:386-409)."""
+    p = key.params
+    message = np.asarray(message, dtype=np.int64)
+    if len(message) != p.n:
+        raise AssertionError("message must have length n")
+    u = rng.integers(-1, 2, size=p.n).astype(np.int64)                    # fhe.jl:390
+    w1_max = p.Dq // (41 * p.n)                                           # fhe.jl:392
+    w1 = rng.integers(-w1_max, w1_max + 1, size=p.n).astype(np.int64)
+    w2_max = p.Dq // 82                                                   # fhe.jl:395
+    w2 = rng.integers(-w2_max, w2_max + 1, size=p.n).astype(np.int64)
+    a1 = (_negacyclic_mul_signed(key.k0, u, p.q).astype(np.int64) + w1) % p.q
+    a2 = (_negacyclic_mul_signed(key.k1, u, p.q).astype(np.int64) + w2 + message * p.Dq) % p.q
+    a = _rescale(p.r, a1, p.q, True)                                      # fhe.jl:402
+    shift = p.t - 5
+    if p.r % (1 << shift):
+        raise AssertionError("r must be a multiple of 2^(t - 5) (src/fhe.jl:404)")
+    b = _rescale(p.r >> shift, a2, p.q, False) << np.uint64(shift)        # fhe.jl:405-406
+    return RLWE(a, b & np.uint64(p.r - 1))
+
+
 def encrypt(key, rng, message):
-    """encrypt(key::PrivateKey, rng, message) (src/fhe.jl:369-372)."""
+    """encrypt(key::PrivateKey, rng, message) (src/fhe.jl:369-372) and
+    encrypt(key::PublicKey, rng, message) (src/fhe.jl:457-459)."""
+    if isinstance(key, PublicKey):
+        return PackedCiphertext(key.params, _encrypt_public(key, rng, message))
     u, rlwe = _encrypt_private(key, rng, message)
     return PackedCiphertext(key.params, rlwe)
 
 
 def encrypt_optimal(key, rng, message):
-    """encrypt_optimal(key::PrivateKey, rng, message) (src/fhe.jl:339-345)."""
+    """encrypt_optimal(key::PrivateKey, rng, message) (src/fhe.jl:339-345): 6 bits per message
+    bit; encrypt_optimal(key::PublicKey, ...) (src/fhe.jl:420-436): t + 7 bits per message bit."""
     p = key.params
+    if isinstance(key, PublicKey):
+        rlwe = _encrypt_public(key, rng, message)
+        a_bits = unpackbits(rlwe.a, p.t + 1)                              # fhe.jl:429
+        b_bits = unpackbits(rlwe.b >> np.uint64(p.t - 5), 6)              # fhe.jl:431-432
+        return PublicEncryptedCiphertext(p, a_bits, b_bits)
     u, rlwe = _encrypt_private(key, rng, message)
     b_packed = rlwe.b >> np.uint64(p.t - 4)                               # fhe.jl:342
     return PrivateEncryptedCiphertext(p, u, unpackbits(b_packed, 5))
 
 
 def normalize_ciphertext(ct):
-    """normalize_ciphertext(::PrivateEncryptedCiphertext) (src/fhe.jl:354-359)."""
+    """normalize_ciphertext(::PrivateEncryptedCiphertext) (src/fhe.jl:354-359) and
+    normalize_ciphertext(::PublicEncryptedCiphertext) (src/fhe.jl:445-450)."""
     p = ct.params
+    if isinstance(ct, PublicEncryptedCiphertext):
+        a = packbits(ct.a_bits) & np.uint64(p.r - 1)
+        b = (packbits(ct.b_bits) << np.uint64(p.t - 5)) & np.uint64(p.r - 1)
+        return PackedCiphertext(p, RLWE(a, b))
     a = deterministic_expand(p, ct.u)
     b = (packbits(ct.v) << np.uint64(p.t - 4)) & np.uint64(p.r - 1)
     return PackedCiphertext(p, RLWE(a, b))

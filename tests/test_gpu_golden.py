@@ -373,6 +373,12 @@ def test_host_api_end_to_end(S):
         assert S.decrypt(key, r_xor) == (msg[i] ^ msg[i + 1])
     ct = S.pack_encrypted_bits(bkey, None, bits)
     assert np.array_equal(S.decrypt(key, ct), msg)
+    pkey = S.PublicKey(rng, key)                          # public-key ciphertexts feed the gates too
+    pbits = S.split_ciphertext(S.encrypt(pkey, rng, msg))
+    for i in range(0, 8, 2):
+        r_and, r_or, r_xor = S.bootstrap(bkey, None, pbits[i], pbits[i + 1])
+        assert S.decrypt(key, r_and) == (msg[i] & msg[i + 1])
+        assert S.decrypt(key, r_xor) == (msg[i] ^ msg[i + 1])
     bkey_h = S.BootstrapKey(rng, key, on_host=True)       # host big-integer generation
     r = S.bootstrap(bkey_h, None, bits[0], bits[1])
     assert S.decrypt(key, r[0]) == (msg[0] & msg[1])

@@ -73,6 +73,25 @@ def test_encrypt_optimal_normalize_decrypt(S):
     assert np.array_equal(S.decrypt(sk, S.normalize_ciphertext(ct)), msg)
 
 
+@pytest.mark.parametrize("n", [64, 512])
+def test_public_key_encryption(S, n):
+    """test/api.test.jl:20-30: encrypt_optimal with a PublicKey -> normalize -> decrypt with the
+    private key; also encrypt(::PublicKey) -> PackedCiphertext -> split -> per-bit decrypt."""
+    rng = np.random.default_rng(5 + n)
+    params = S.Params(n)
+    key = S.PrivateKey(params, rng)
+    pkey = S.PublicKey(rng, key)
+    for trial in range(4):
+        message = rng.integers(0, 2, size=params.n).astype(bool)
+        ct = S.encrypt_optimal(pkey, rng, message)
+        assert ct.a_bits.shape == (params.t + 1, params.n) and ct.b_bits.shape == (6, params.n)
+        assert np.array_equal(S.decrypt(key, S.normalize_ciphertext(ct)), message)
+        packed = S.encrypt(pkey, rng, message)
+        assert np.array_equal(S.decrypt(key, packed), message)
+    bits = S.split_ciphertext(packed)
+    assert [S.decrypt(key, eb) for eb in bits[:16]] == list(message[:16])
+
+
 def test_packbits_roundtrip_and_expand_determinism(S):
     rng = np.random.default_rng(2)
     vals = rng.integers(0, 1 << 13, size=100, dtype=np.uint64)
