@@ -51,7 +51,7 @@ typedef struct {
     uint64_t m;           /* bootstrap polynomial length, power of two, 2^6 .. 2^13 */
     uint64_t ell;         /* gadget decomposition length; must be 2 */
     uint64_t Q[2];        /* bootstrap modulus, Q < 2^94 */
-    uint64_t B[2];        /* gadget base, B^2 >= Q, B < 2^62 */
+    uint64_t B[2];        /* gadget base, B^2 >= Q, B < 2^46 */
     uint64_t DQ_tilde[2]; /* Q / 8 for Params(n) */
 } sgfhe_params;
 

@@ -445,7 +445,7 @@ int32_t build_constants(sgfhe_ctx *c) {
         cc.xmax = (uint64_t)xmax;
         cc.offneg_rnd = (Q - (((1 + B) % Q) * (stot % Q)) % Q) % Q;
         // |u| <= 2 B in that mode: the exactness bound needs 4 x more head-room
-        c->rnd_ok = (log_need + 2.0 <= log_have) && (B >> 60) == 0;
+        c->rnd_ok = (log_need + 2.0 <= log_have);
     }
     cc.DQ = ld128(c->par.DQ_tilde) % Q;
     cc.halfQ = Q / 2;
@@ -608,9 +608,9 @@ int32_t sgfhe_ctx_create(const sgfhe_params *p, int device, sgfhe_ctx **out) {
     c->Q = ld128(p->Q);
     c->B = ld128(p->B);
     if (c->Q < 3 || (c->Q >> 94)) return fail(c, SGFHE_ERR_UNSUPPORTED, "Q must be in [3, 2^94)");
-    if (c->B < 2 || (c->B >> 62)) return fail(c, SGFHE_ERR_UNSUPPORTED, "B must be in [2, 2^62)");
+    if (c->B < 2 || (c->B >> 46)) return fail(c, SGFHE_ERR_UNSUPPORTED, "B must be in [2, 2^46)");
     {
-        // B^2 >= Q (utils.jl:145); B < 2^62 so B*B fits 128 bits
+        // B^2 >= Q (utils.jl:145); B < 2^46 so B*B fits 128 bits
         if (c->B * c->B < c->Q) return fail(c, SGFHE_ERR_INVALID_ARG, "B^2 must be >= Q");
     }
     if (ld128(p->DQ_tilde) >= c->Q) return fail(c, SGFHE_ERR_INVALID_ARG, "DQ_tilde must be < Q");

@@ -97,17 +97,33 @@ __device__ __forceinline__ u128 mod_wide(u128 x, u128 d, double inv, uint64_t *q
 }
 
 // ---- digit planes ---------------------------------------------------------------------------------
-// dig[bootstrap][c][digit][coef] (uint64): digit 0 = lo, digit 1 = hi of x' for acc_a (c = 0) and
-// acc_b (c = 1).  Plane p = 2 c + digit is the p-th row of u = [a_lo, a_hi, b_lo, b_hi]
-// (fhe.jl:524-526) and multiplies key row p.
+// Per (bootstrap, c) a record of 16 m bytes (the size of the canonical residues it replaces):
+//   [lo words: digit 0 | digit 1] 2 m x uint32      bits 0..31 of the digits
+//   [hi words: digit 0 | digit 1] 2 m x uint16      bits 32..47          (12 m bytes in use)
+// digit 0 = lo, digit 1 = hi of x' for acc_a (c = 0) and acc_b (c = 1); every stored digit is
+// below 2^48 (B < 2^46 is checked at ctx creation; the randomised mode stores up to 4 B).  Plane
+// p = 2 c + digit is the p-th row of u = [a_lo, a_hi, b_lo, b_hi] (fhe.jl:524-526) and multiplies
+// key row p.  6 bytes per digit instead of 8: the CRT kernel is bound by these bytes.
+__device__ __forceinline__ const uint32_t *digit_lo_plane(const uint64_t *dig, size_t bc, uint32_t M) {
+    return reinterpret_cast<const uint32_t *>(dig + bc * 2 * M);
+}
+__device__ __forceinline__ const uint16_t *digit_hi_plane(const uint64_t *dig, size_t bc, uint32_t M) {
+    return reinterpret_cast<const uint16_t *>(dig + bc * 2 * M + M);
+}
 __device__ __forceinline__ ulonglong2 load_digits(const uint64_t *__restrict__ dig, size_t bc,
                                                   uint32_t i, uint32_t M) {
-    return make_ulonglong2(dig[(bc * 2 + 0) * M + i], dig[(bc * 2 + 1) * M + i]);
+    const uint32_t *lo = digit_lo_plane(dig, bc, M);
+    const uint16_t *hi = digit_hi_plane(dig, bc, M);
+    return make_ulonglong2(lo[i] | ((uint64_t)hi[i] << 32), lo[M + i] | ((uint64_t)hi[M + i] << 32));
 }
 __device__ __forceinline__ void store_digits(uint64_t *__restrict__ dig, size_t bc, uint32_t i,
                                              uint32_t M, uint64_t lo, uint64_t hi) {
-    dig[(bc * 2 + 0) * M + i] = lo;
-    dig[(bc * 2 + 1) * M + i] = hi;
+    uint32_t *l = const_cast<uint32_t *>(digit_lo_plane(dig, bc, M));
+    uint16_t *h = const_cast<uint16_t *>(digit_hi_plane(dig, bc, M));
+    l[i] = (uint32_t)lo;
+    l[M + i] = (uint32_t)hi;
+    h[i] = (uint16_t)(lo >> 32);
+    h[M + i] = (uint16_t)(hi >> 32);
 }
 
 // ---- randomised flatten (utils.jl:198-241) ----------------------------------------------------------
@@ -146,8 +162,8 @@ __device__ __forceinline__ ulonglong2 random_digits(u128 xn, const CrtConst *CC,
 }
 
 // ---- digit -> residue ------------------------------------------------------------------------
-// (e - s) * R^-1 mod p, lazily in [0, 4p), for a raw digit e in [0, B), B < 2^62:
-// REDC(e) < e / 2^32 + p < 2^30 + p, plus the constant p - s R^-1.
+// (e - s) * R^-1 mod p, lazily in [0, 4p), for a stored digit e < 2^48:
+// REDC(e) < e / 2^32 + p < 2^16 + p, plus the constant p - s R^-1.
 __device__ __forceinline__ uint32_t digit_reduce(uint64_t e, const PrimeK &P, uint32_t sR) {
     return redc_mad(e, P.p, P.ninv) + sR;
 }
@@ -206,13 +222,14 @@ k_extprod(const uint64_t *__restrict__ dig, const uint32_t *__restrict__ keyk,
         const int tid = (int)threadIdx.x + (int)opaque_zero();
         // 1. digits -> residues (flatten_poly, utils.jl:253-264, lifted to signed integers)
         uint32_t x[1][E];
-        const uint64_t *d = dig + ((size_t)b * 4 + ph) * M;
+        const uint32_t *dl = digit_lo_plane(dig, (size_t)b * 2 + (ph >> 1), M) + (ph & 1) * M;
+        const uint16_t *dh = digit_hi_plane(dig, (size_t)b * 2 + (ph >> 1), M) + (ph & 1) * M;
 #pragma unroll
         for (int e = 0; e < E; e++)
 #ifdef SGFHE_ABL_NO_DIG
             x[0][e] = digit_reduce((uint64_t)(tid + e) * 0x9E3779B97F4Aull, P);  // timing-only build
 #else
-            x[0][e] = digit_reduce(d[tid + T * e], P, sRd);
+            x[0][e] = digit_reduce(dl[tid + T * e] | ((uint64_t)dh[tid + T * e] << 32), P, sRd);
 #endif
         // the exchange buffer is reused: every wave must have finished the previous phase's loads
         SGFHE_SYNC();
