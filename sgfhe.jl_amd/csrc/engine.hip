@@ -644,6 +644,8 @@ int32_t sgfhe_ctx_destroy(sgfhe_ctx *c) {
 
 int32_t sgfhe_set_chunk(sgfhe_ctx *c, uint32_t chunk) {
     if (!c) return SGFHE_ERR_INVALID_ARG;
+    if (chunk > 8192)  // the kernels index a chunk's planes with 32-bit element offsets
+        return fail(c, SGFHE_ERR_INVALID_ARG, "chunk must be at most 8192 bootstraps");
     c->chunk = chunk ? round_up8(chunk) : 0;
     return SGFHE_OK;
 }

@@ -104,6 +104,17 @@ __device__ __forceinline__ u128 mod_wide(u128 x, u128 d, double inv, uint64_t *q
 // below 2^48 (B < 2^46 is checked at ctx creation; the randomised mode stores up to 4 B).  Plane
 // p = 2 c + digit is the p-th row of u = [a_lo, a_hi, b_lo, b_hi] (fhe.jl:524-526) and multiplies
 // key row p.  6 bytes per digit instead of 8: the CRT kernel is bound by these bytes.
+// Byte offsets inside a chunk's buffers fit 32 bits (chunk <= 8192, buffers below 4 GB): a uniform
+// base plus a 32-bit byte offset takes the SGPR-base addressing mode, with no 64-bit address
+// arithmetic on the vector ALU.
+template <class T>
+__device__ __forceinline__ T ld_off(const void *base, uint32_t byte_off) {
+    return *reinterpret_cast<const T *>(reinterpret_cast<const char *>(base) + byte_off);
+}
+template <class T>
+__device__ __forceinline__ void st_off(void *base, uint32_t byte_off, T v) {
+    *reinterpret_cast<T *>(reinterpret_cast<char *>(base) + byte_off) = v;
+}
 __device__ __forceinline__ const uint32_t *digit_lo_plane(const uint64_t *dig, size_t bc, uint32_t M) {
     return reinterpret_cast<const uint32_t *>(dig + bc * 2 * M);
 }
@@ -112,18 +123,20 @@ __device__ __forceinline__ const uint16_t *digit_hi_plane(const uint64_t *dig, s
 }
 __device__ __forceinline__ ulonglong2 load_digits(const uint64_t *__restrict__ dig, size_t bc,
                                                   uint32_t i, uint32_t M) {
-    const uint32_t *lo = digit_lo_plane(dig, bc, M);
-    const uint16_t *hi = digit_hi_plane(dig, bc, M);
-    return make_ulonglong2(lo[i] | ((uint64_t)hi[i] << 32), lo[M + i] | ((uint64_t)hi[M + i] << 32));
+    const uint32_t rec = (uint32_t)bc * 16u * M;           // byte offset of the record
+    const uint32_t lo = rec + 4u * i, hi = rec + 8u * M + 2u * i;
+    return make_ulonglong2(
+        ld_off<uint32_t>(dig, lo) | ((uint64_t)ld_off<uint16_t>(dig, hi) << 32),
+        ld_off<uint32_t>(dig, lo + 4u * M) | ((uint64_t)ld_off<uint16_t>(dig, hi + 2u * M) << 32));
 }
 __device__ __forceinline__ void store_digits(uint64_t *__restrict__ dig, size_t bc, uint32_t i,
                                              uint32_t M, uint64_t lo, uint64_t hi) {
-    uint32_t *l = const_cast<uint32_t *>(digit_lo_plane(dig, bc, M));
-    uint16_t *h = const_cast<uint16_t *>(digit_hi_plane(dig, bc, M));
-    l[i] = (uint32_t)lo;
-    l[M + i] = (uint32_t)hi;
-    h[i] = (uint16_t)(lo >> 32);
-    h[M + i] = (uint16_t)(hi >> 32);
+    const uint32_t rec = (uint32_t)bc * 16u * M;
+    const uint32_t ol = rec + 4u * i, oh = rec + 8u * M + 2u * i;
+    st_off<uint32_t>(dig, ol, (uint32_t)lo);
+    st_off<uint32_t>(dig, ol + 4u * M, (uint32_t)hi);
+    st_off<uint16_t>(dig, oh, (uint16_t)(lo >> 32));
+    st_off<uint16_t>(dig, oh + 2u * M, (uint16_t)(hi >> 32));
 }
 
 // ---- randomised flatten (utils.jl:198-241) ----------------------------------------------------------
@@ -428,11 +441,11 @@ k_crt_acc(const uint32_t *__restrict__ yres, uint64_t *__restrict__ dig,
     if (t >= total) return;
     const uint32_t M = 1u << logm;
     const uint32_t i = t & (M - 1);
-    const size_t bc = t >> logm;
-    const uint32_t *yp = yres + bc * NPR * M + i;
+    const uint32_t bc = t >> logm;
+    const uint32_t yo = 4u * ((bc * NPR << logm) + i);  // byte offset
     uint32_t y[NPR];
 #pragma unroll
-    for (int q = 0; q < NPR; q++) y[q] = yp[(size_t)q * M];
+    for (int q = 0; q < NPR; q++) y[q] = ld_off<uint32_t>(yres, yo + ((uint32_t)(4 * q) << logm));
     const bool have_old = !(mode & MODE_NOACC);
     const ulonglong2 d = have_old ? load_digits(dig, bc, i, M) : make_ulonglong2(0, 0);
     const U96 a = crt_reduce(y, CC, have_old, d);
