@@ -343,7 +343,9 @@ k_extprod(const uint64_t *__restrict__ dig, const uint32_t *__restrict__ keyk,
                 const bool borrow = __builtin_usub_overflow(vs, z[c][e], &d);
                 uint32_t y = borrow ? d + p : d;           // [0, p]
                 if (P.hoff) y = condsub(y + P.hoff, p);    // wave-uniform: only the last prime
-                yb[(size_t)c * NPR * M + tid + T * e] = y;
+                // streamed out: the residues are not read again by this launch, so they should
+                // not displace the digit planes the other prime-workgroups still want from L2
+                __builtin_nontemporal_store(y, &yb[(size_t)c * NPR * M + tid + T * e]);
             }
         }
     }
