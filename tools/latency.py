@@ -1,0 +1,21 @@
+"""Latency of small batches at Params(1024): one call of bootstrap_batch_device per size."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import sgfhe_jl_amd as S
+
+p = S.Params(1024)
+eng = S.Engine(p)
+eng.generate_key(np.random.default_rng(11).integers(0, 2, size=p.n, dtype=np.uint64), 1)
+g = torch.Generator(device="cuda"); g.manual_seed(1)
+for B in [int(x) for x in sys.argv[1:]] or [1, 8, 64, 256, 512]:
+    a1 = torch.randint(0, p.r, (B, p.n), dtype=torch.int64, device="cuda", generator=g)
+    a2 = torch.randint(0, p.r, (B, p.n), dtype=torch.int64, device="cuda", generator=g)
+    b1 = torch.randint(0, p.r, (B,), dtype=torch.int64, device="cuda", generator=g)
+    b2 = torch.randint(0, p.r, (B,), dtype=torch.int64, device="cuda", generator=g)
+    out = torch.zeros((B, 3, p.n + 1), dtype=torch.int64, device="cuda")
+    for rep in range(2):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        eng.bootstrap_batch_device(a1.data_ptr(), b1.data_ptr(), a2.data_ptr(), b2.data_ptr(), B, out.data_ptr())
+        eng.sync(); dt = time.perf_counter() - t0
+    print("batch %4d: %8.2f ms per call, %8.1f bootstraps/s" % (B, dt * 1e3, B / dt), flush=True)
