@@ -70,7 +70,7 @@ int32_t sgfhe_ctx_destroy(sgfhe_ctx *ctx);
 const char *sgfhe_last_error_string(const sgfhe_ctx *ctx);
 
 /* Batch-scheduling knobs.  chunk: bootstraps that move through the k-loop in lock-step
- * (0 = default).  lanes: 1 (default) runs the chunks of a batch one after the other; 2 runs
+ * (0 = default, at most 8192; rounded up to a multiple of 8).  lanes: 1 (default) runs the chunks of a batch one after the other; 2 runs
  * consecutive chunks on two HIP streams so that the memory-bound CRT kernel of one overlaps the
  * VALU-bound external-product kernel of the other. */
 int32_t sgfhe_set_chunk(sgfhe_ctx *ctx, uint32_t chunk);
