@@ -70,9 +70,9 @@ int32_t sgfhe_ctx_destroy(sgfhe_ctx *ctx);
 const char *sgfhe_last_error_string(const sgfhe_ctx *ctx);
 
 /* Batch-scheduling knobs.  chunk: bootstraps that move through the k-loop in lock-step
- * (0 = default, at most 8192; rounded up to a multiple of 8).  lanes: 1 (default) runs the chunks of a batch one after the other; 2 runs
- * consecutive chunks on two HIP streams so that the memory-bound CRT kernel of one overlaps the
- * VALU-bound external-product kernel of the other. */
+ * (0 = default, at most 8192; rounded up to a multiple of 8).  lanes: 1 (default) runs the
+ * chunks of a batch one after the other; 2 runs consecutive chunks on two HIP streams (measured
+ * equal to one stream with twice the chunk).  Every setting gives bit-identical results. */
 int32_t sgfhe_set_chunk(sgfhe_ctx *ctx, uint32_t chunk);
 int32_t sgfhe_set_lanes(sgfhe_ctx *ctx, uint32_t lanes);
 
