@@ -255,7 +255,8 @@ def main():
             "config": {"workload": "%s gate bootstraps (AND/OR/XOR), batch %d per GPU, "
                                    "deterministic flatten" % (args.config, B),
                        "n": p.n, "m": p.m, "log2_Q": round(float(np.log2(float(p.Q))), 2),
-                       "batch_per_gpu": B, "chunk": chunk, "lanes": args.lanes, "rns_primes": 5,
+                       "batch_per_gpu": B, "chunk": chunk, "lanes": args.lanes,
+                       "rns_primes": len(eng.primes()),
                        "key": "generated on the device from a seed (valid key)",
                        "key_broadcast_s": round(bcast_s, 4)},
             "roofline": {"bound": "hbm", "kernel": "k_extprod", "achieved": achieved,

@@ -69,7 +69,8 @@ struct sgfhe_ctx {
     int logm = 0;
     uint32_t M = 0, n = 0;
     u128 Q = 0, B = 0;
-    uint32_t primes[NPR];
+    uint32_t primes[NPR_MAX];
+    uint32_t npr = 0;  // RNS primes in use: the fewest whose product covers the exactness bound
     std::string err;
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;  // second lane: chunk i+1 overlaps its memory-bound k_crt_acc
@@ -79,7 +80,7 @@ struct sgfhe_ctx {
     PrimeK *d_primes = nullptr;
     CrtConst *d_crt = nullptr;
     uint32_t *d_bad = nullptr;  // set by k_key_transform when a key residue is >= Q
-    uint32_t *d_tw = nullptr;  // NPR * 2 * M entries
+    uint32_t *d_tw = nullptr;  // npr * 2 * M entries
     CrtConst h_crt;
     uint32_t pack_G = 1;  // key slices per exact-accumulation group of the packing path
     // key
@@ -142,7 +143,7 @@ int32_t launch_extprod_t(sgfhe_ctx *c, const sgfhe_ctx::Lane &L, const uint32_t 
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_done[c->device & 15] = true;
     }
-    hipLaunchKernelGGL(k_extprod<LOGM>, dim3(cpad * NPR), dim3(threads_of<LOGM>()), lds, st, L.dig,
+    hipLaunchKernelGGL(k_extprod<LOGM>, dim3(cpad * c->npr), dim3(threads_of<LOGM>()), lds, st, L.dig,
                        keyk, L.yres, L.ua, c->d_primes, k, c->n, mode);
     HIPCHK(c, hipGetLastError());
     return SGFHE_OK;
@@ -167,7 +168,7 @@ int32_t launch_shortprod_t(sgfhe_ctx *c, const uint64_t *pdig, uint32_t *yg, uin
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_done[c->device & 15] = true;
     }
-    hipLaunchKernelGGL(k_shortprod<LOGM>, dim3(count * groups * NPR), dim3(threads_of<LOGM>()), lds,
+    hipLaunchKernelGGL(k_shortprod<LOGM>, dim3(count * groups * c->npr), dim3(threads_of<LOGM>()), lds,
                        st, pdig, c->d_key, yg, c->d_primes, c->d_crt, c->n, G, groups);
     HIPCHK(c, hipGetLastError());
     return SGFHE_OK;
@@ -187,10 +188,10 @@ int32_t launch_keygen_ntt_t(sgfhe_ctx *c, const uint64_t *d_sk, uint32_t *d_shat
                             const ulonglong2 *d_acan, uint32_t *d_y, uint32_t R, bool shat_pass,
                             hipStream_t st) {
     if (shat_pass)
-        hipLaunchKernelGGL(k_shat<LOGM>, dim3(NPR), dim3(threads_of<LOGM>()), lds_bytes(LOGM, 1), st,
+        hipLaunchKernelGGL(k_shat<LOGM>, dim3(c->npr), dim3(threads_of<LOGM>()), lds_bytes(LOGM, 1), st,
                            d_sk, d_shat, c->d_primes, c->n);
     else
-        hipLaunchKernelGGL(k_polymul_s<LOGM>, dim3(R * NPR), dim3(threads_of<LOGM>()),
+        hipLaunchKernelGGL(k_polymul_s<LOGM>, dim3(R * c->npr), dim3(threads_of<LOGM>()),
                            lds_bytes(LOGM, 1), st, d_acan, d_shat, d_y, c->d_primes, c->d_crt);
     HIPCHK(c, hipGetLastError());
     return SGFHE_OK;
@@ -209,7 +210,7 @@ int32_t launch_keygen_ntt(sgfhe_ctx *c, const uint64_t *d_sk, uint32_t *d_shat,
 template <int LOGM>
 int32_t launch_keytr_t(sgfhe_ctx *c, const ulonglong2 *canon, uint32_t *keyhat, uint32_t poly0,
                        uint32_t npolys, hipStream_t st) {
-    hipLaunchKernelGGL(k_key_transform<LOGM>, dim3(npolys * NPR), dim3(threads_of<LOGM>()),
+    hipLaunchKernelGGL(k_key_transform<LOGM>, dim3(npolys * c->npr), dim3(threads_of<LOGM>()),
                        lds_bytes(LOGM, 1), st, canon, keyhat, c->d_primes, c->d_crt, poly0,
                        c->d_bad);
     HIPCHK(c, hipGetLastError());
@@ -243,13 +244,26 @@ int32_t launch_dbgntt(sgfhe_ctx *c, const uint32_t *in, uint32_t *out, uint32_t 
     return fail(c, SGFHE_ERR_UNSUPPORTED, "unsupported log2(m)");
 }
 
-int32_t launch_crt(sgfhe_ctx *c, const sgfhe_ctx::Lane &L, uint32_t cpad, uint32_t mode,
-                   hipStream_t st, RndArgs ra = RndArgs{0, 0, 0, 0}, uint32_t iter = 0) {
-    const uint32_t total = cpad * 2 * c->M;
-    hipLaunchKernelGGL(k_crt_acc, dim3((total + 255) / 256), dim3(256), 0, st, L.yres, L.dig,
-                       c->d_crt, total, (uint32_t)c->logm, mode, ra, iter);
+// k_crt_acc is compiled once per prime count (its residue loops are unrolled)
+#define SGFHE_FOR_NPR(X) X(2) X(3) X(4) X(5) X(6)
+int32_t launch_crt_raw(sgfhe_ctx *c, const uint32_t *yres, uint64_t *dig, uint32_t total,
+                       uint32_t mode, hipStream_t st, RndArgs ra, uint32_t iter) {
+    switch (c->npr) {
+#define X(NP)                                                                                     \
+    case NP:                                                                                      \
+        hipLaunchKernelGGL(k_crt_acc<NP>, dim3((total + 255) / 256), dim3(256), 0, st, yres, dig, \
+                           c->d_crt, total, (uint32_t)c->logm, mode, ra, iter);                   \
+        break;
+        SGFHE_FOR_NPR(X)
+#undef X
+    default: return fail(c, SGFHE_ERR_UNSUPPORTED, "unsupported number of RNS primes");
+    }
     HIPCHK(c, hipGetLastError());
     return SGFHE_OK;
+}
+int32_t launch_crt(sgfhe_ctx *c, const sgfhe_ctx::Lane &L, uint32_t cpad, uint32_t mode,
+                   hipStream_t st, RndArgs ra = RndArgs{0, 0, 0, 0}, uint32_t iter = 0) {
+    return launch_crt_raw(c, L.yres, L.dig, cpad * 2 * c->M, mode, st, ra, iter);
 }
 
 // ---- buffers ------------------------------------------------------------------------------------
@@ -257,7 +271,7 @@ int32_t launch_crt(sgfhe_ctx *c, const sgfhe_ctx::Lane &L, uint32_t cpad, uint32
 uint32_t round_up8(uint32_t x) { return (x + 7u) & ~7u; }
 
 size_t per_bootstrap_bytes(const sgfhe_ctx *c) {
-    return (size_t)2 * c->M * sizeof(ulonglong2) + (size_t)2 * NPR * c->M * 4 + (size_t)c->n * 4;
+    return (size_t)2 * c->M * sizeof(ulonglong2) + (size_t)2 * c->npr * c->M * 4 + (size_t)c->n * 4;
 }
 
 // Default chunk: the per-iteration working set (digits + residues) of a chunk stays near the size
@@ -290,7 +304,7 @@ int32_t ensure_work(sgfhe_ctx *c, uint32_t cpad) {
     free_lanes(c);
     for (auto &L : c->lane) {
         HIPCHK(c, hipMalloc(&L.dig, (size_t)cpad * 4 * c->M * sizeof(uint64_t)));
-        HIPCHK(c, hipMalloc(&L.yres, (size_t)cpad * 2 * NPR * c->M * 4));
+        HIPCHK(c, hipMalloc(&L.yres, (size_t)cpad * 2 * c->npr * c->M * 4));
         HIPCHK(c, hipMalloc(&L.ua, (size_t)cpad * c->n * 4));
     }
     c->cap = cpad;
@@ -315,7 +329,7 @@ void timing_flush(sgfhe_ctx *c) {
 
 int32_t run_iterations(sgfhe_ctx *c, const sgfhe_ctx::Lane &L, uint32_t cpad, uint64_t n_iters,
                        hipStream_t st, bool full_chunk, uint32_t mode, RndArgs ra) {
-    const size_t slice = (size_t)NPR * 8 * c->M;
+    const size_t slice = (size_t)c->npr * 8 * c->M;
     for (uint64_t k = 0; k < n_iters; k++) {
         const bool sample = c->timing && full_chunk && (k % 64 == 1) && c->ev.size() < 2048;
         hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
@@ -399,23 +413,40 @@ int32_t build_constants(sgfhe_ctx *c) {
     const int logm = c->logm;
     const u128 Q = c->Q, B = c->B;
 
-    // RNS primes: the NPR largest primes below 2^30 with p = 1 mod 2^15 (covers 2 m | p - 1
-    // for every supported m, and leaves room for m = 2^14).
+    // RNS primes: the largest primes below 2^30 with p = 1 mod 2^15 (2 m | p - 1 for every
+    // supported m), as many as the exactness bound needs: |D| <= 2 m B Q must stay below
+    // M_rns / 4 (see k_crt_acc), i.e. 8 m B Q <= M_rns; one more factor 4 if that still fits
+    // the same number of primes or NPR_MAX allows it (randomised flatten, digits up to 2 B).
+    uint32_t cand_primes[NPR_MAX];
     {
         int found = 0;
-        for (uint64_t kk = ((1ull << 30) - 1) >> 15; kk > 0 && found < NPR; kk--) {
+        for (uint64_t kk = ((1ull << 30) - 1) >> 15; kk > 0 && found < NPR_MAX; kk--) {
             uint32_t cand = (uint32_t)((kk << 15) + 1);
-            if (cand < (1u << 30) && is_prime32(cand)) c->primes[found++] = cand;
+            if (cand < (1u << 30) && is_prime32(cand)) cand_primes[found++] = cand;
         }
-        if (found < NPR) return fail(c, SGFHE_ERR_UNSUPPORTED, "could not find RNS primes");
+        if (found < NPR_MAX) return fail(c, SGFHE_ERR_UNSUPPORTED, "could not find RNS primes");
     }
-    // Exactness bound: |D| <= 2 m B Q must stay below M_rns / 8 (see k_crt_acc).
-    double log_need = 3.0 + logm + u128_log2(B) + u128_log2(Q) + 0.01;
+    const double log_need = 3.0 + logm + u128_log2(B) + u128_log2(Q) + 0.01;
     double log_have = 0;
-    for (int i = 0; i < NPR; i++) log_have += log2((double)c->primes[i]);
+    uint32_t npr = 0;
+    while (npr < NPR_MAX && (npr < 2 || log_have < log_need + 2.0)) {
+        log_have += log2((double)cand_primes[npr]);
+        npr++;
+    }
+    if (log_have < log_need + 2.0) {  // the randomised mode does not fit: deterministic only
+        npr = 0;
+        log_have = 0;
+        while (npr < NPR_MAX && (npr < 2 || log_have < log_need)) {
+            log_have += log2((double)cand_primes[npr]);
+            npr++;
+        }
+    }
     if (log_need > log_have)
         return fail(c, SGFHE_ERR_UNSUPPORTED,
                     "8 m B Q exceeds the product of the RNS primes (need more primes)");
+    c->npr = npr;
+    for (uint32_t i = 0; i < npr; i++) c->primes[i] = cand_primes[i];
+    const int NPR = (int)npr;  // the loops below run over the primes in use
 
     // Packing (fhe.jl:683-687): G slices of two digit polynomials each are summed exactly before a
     // CRT: |sum| <= G m B Q / 2 must stay below M_rns / 8.
@@ -445,7 +476,7 @@ int32_t build_constants(sgfhe_ctx *c) {
         cc.xmax = (uint64_t)xmax;
         cc.offneg_rnd = (Q - (((1 + B) % Q) * (stot % Q)) % Q) % Q;
         // |u| <= 2 B in that mode: the exactness bound needs 4 x more head-room
-        c->rnd_ok = (log_need + 2.0 <= log_have);
+        c->rnd_ok = (log_need + 2.0 <= log_have) && (B >> 46) == 0;
     }
     cc.DQ = ld128(c->par.DQ_tilde) % Q;
     cc.halfQ = Q / 2;
@@ -479,6 +510,7 @@ int32_t build_constants(sgfhe_ctx *c) {
     // twiddle tables and per-prime constants
     std::vector<uint32_t> tw((size_t)NPR * 2 * M);
     std::vector<PrimeK> pk(NPR);
+    cc.npr = npr;
     HIPCHK(c, hipMalloc(&c->d_tw, tw.size() * sizeof(uint32_t)));
     for (int i = 0; i < NPR; i++) {
         const uint32_t p = c->primes[i];
@@ -528,6 +560,7 @@ int32_t build_constants(sgfhe_ctx *c) {
         P.invp = 1.0f / (float)p;
         P.twf = c->d_tw + (size_t)(2 * i) * M;
         P.twi = c->d_tw + (size_t)(2 * i + 1) * M;
+        P.npr = npr;
     }
     HIPCHK(c, hipMemcpy(c->d_tw, tw.data(), tw.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     HIPCHK(c, hipMalloc(&c->d_primes, NPR * sizeof(PrimeK)));
@@ -541,7 +574,7 @@ int32_t build_constants(sgfhe_ctx *c) {
 
 int32_t key_alloc(sgfhe_ctx *c) {
     if (c->d_key) return SGFHE_OK;
-    c->key_bytes = (size_t)c->n * NPR * 8 * c->M * 4;
+    c->key_bytes = (size_t)c->n * c->npr * 8 * c->M * 4;
     HIPCHK(c, hipMalloc(&c->d_key, c->key_bytes));
     return SGFHE_OK;
 }
@@ -608,7 +641,7 @@ int32_t sgfhe_ctx_create(const sgfhe_params *p, int device, sgfhe_ctx **out) {
     c->Q = ld128(p->Q);
     c->B = ld128(p->B);
     if (c->Q < 3 || (c->Q >> 94)) return fail(c, SGFHE_ERR_UNSUPPORTED, "Q must be in [3, 2^94)");
-    if (c->B < 2 || (c->B >> 46)) return fail(c, SGFHE_ERR_UNSUPPORTED, "B must be in [2, 2^46)");
+    if (c->B < 2 || (c->B >> 47)) return fail(c, SGFHE_ERR_UNSUPPORTED, "B must be in [2, 2^47)");
     {
         // B^2 >= Q (utils.jl:145); B < 2^46 so B*B fits 128 bits
         if (c->B * c->B < c->Q) return fail(c, SGFHE_ERR_INVALID_ARG, "B^2 must be >= Q");
@@ -705,8 +738,8 @@ int32_t sgfhe_bkey_generate(sgfhe_ctx *c, const uint64_t *sk, size_t n_sk, uint6
     hipError_t e = hipSuccess;
     do {
         if ((e = hipMalloc(&d_sk, (size_t)c->n * 8))) break;
-        if ((e = hipMalloc(&d_shat, (size_t)NPR * M * 4))) break;
-        if ((e = hipMalloc(&d_y, (size_t)R * NPR * M * 4))) break;
+        if ((e = hipMalloc(&d_shat, (size_t)c->npr * M * 4))) break;
+        if ((e = hipMalloc(&d_y, (size_t)R * c->npr * M * 4))) break;
         if ((e = hipMalloc(&d_acan, (size_t)R * M * 16))) break;
         if ((e = hipMalloc(&d_prod, (size_t)R * M * 16))) break;
         if ((e = hipMalloc(&d_canon, (size_t)R * 2 * M * 16))) break;
@@ -721,9 +754,9 @@ int32_t sgfhe_bkey_generate(sgfhe_ctx *c, const uint64_t *sk, size_t n_sk, uint6
             rc = launch_keygen_ntt(c, d_sk, d_shat, d_acan, d_y, R, false, c->stream);
             if (rc) break;
             // CRT of the exact product, canonical residues into d_prod ([row][m] 16-byte values)
-            hipLaunchKernelGGL(k_crt_acc, dim3((tot + 255) / 256), dim3(256), 0, c->stream, d_y,
-                               reinterpret_cast<uint64_t *>(d_prod), c->d_crt, tot, (uint32_t)c->logm,
-                               MODE_NOACC | MODE_CANON, RndArgs{0, 0, 0, 0}, 0u);
+            if ((rc = launch_crt_raw(c, d_y, reinterpret_cast<uint64_t *>(d_prod), tot,
+                                     MODE_NOACC | MODE_CANON, c->stream, RndArgs{0, 0, 0, 0}, 0u)))
+                break;
             hipLaunchKernelGGL(k_keygen_finish, dim3((tot + 255) / 256), dim3(256), 0, c->stream, d_acan,
                                d_prod, d_e, d_sk, d_canon, c->d_crt, row0, R, (uint32_t)c->logm);
             if ((e = hipGetLastError())) break;
@@ -778,7 +811,7 @@ int32_t sgfhe_bkey_upload_rns2(sgfhe_ctx *c, const uint64_t *pairs, size_t n_wor
 
 int32_t sgfhe_bkey_device_form_bytes(const sgfhe_ctx *c, size_t *bytes) {
     if (!c || !bytes) return SGFHE_ERR_INVALID_ARG;
-    *bytes = (size_t)c->n * NPR * 8 * c->M * 4;
+    *bytes = (size_t)c->n * c->npr * 8 * c->M * 4;
     return SGFHE_OK;
 }
 
@@ -885,7 +918,7 @@ int32_t sgfhe_external_product(sgfhe_ctx *c, const uint64_t *a, const uint64_t *
     const sgfhe_ctx::Lane &L = c->lane[0];
     uint32_t *d_A = nullptr;
     ulonglong2 *d_ab = nullptr;
-    HIPCHK(c, hipMalloc(&d_A, (size_t)NPR * 8 * M * 4));
+    HIPCHK(c, hipMalloc(&d_A, (size_t)c->npr * 8 * M * 4));
     hipError_t e = hipMalloc(&d_ab, (size_t)2 * M * 16);
     if (e != hipSuccess) { (void)hipFree(d_A); return fail(c, SGFHE_ERR_HIP, hipGetErrorString(e)); }
     do {
@@ -931,7 +964,7 @@ int32_t sgfhe_pack_encrypted_bits(sgfhe_ctx *c, const uint64_t *a, const uint64_
         uint64_t *d_a1 = d_lwe, *d_a2 = d_lwe + nb * n, *d_b1 = d_a2 + nb * n, *d_b2 = d_b1 + nb;
         if ((e = hipMalloc(&d_raw, nb * 3 * (n + 1) * 16))) break;
         if ((e = hipMalloc(&d_pdig, count * n * 2 * n * 8))) break;
-        if ((e = hipMalloc(&d_yg, count * groups * 2 * NPR * M * 4))) break;
+        if ((e = hipMalloc(&d_yg, count * groups * 2 * c->npr * M * 4))) break;
         if ((e = hipMalloc(&d_wv, 2 * count * M * 8))) break;
         if ((e = hipMemsetAsync(d_a1, 0, nb * n * 8, c->stream))) break;
         std::vector<uint64_t> ones(nb, c->par.r / 4);
@@ -950,9 +983,16 @@ int32_t sgfhe_pack_encrypted_bits(sgfhe_ctx *c, const uint64_t *a, const uint64_
         rc = launch_shortprod(c, d_pdig, d_yg, (uint32_t)count, G, groups, c->stream);
         if (rc) break;
         const size_t tw = count * M;
-        hipLaunchKernelGGL(k_pack_finish, dim3((unsigned)((tw + 255) / 256)), dim3(256), 0, c->stream,
-                           d_yg, d_raw, d_wv, d_wv + count * M, c->d_crt, (uint32_t)count,
-                           (uint32_t)n, (uint32_t)c->logm, groups);
+        switch (c->npr) {
+#define X(NP)                                                                                     \
+    case NP:                                                                                      \
+        hipLaunchKernelGGL(k_pack_finish<NP>, dim3((unsigned)((tw + 255) / 256)), dim3(256), 0,   \
+                           c->stream, d_yg, d_raw, d_wv, d_wv + count * M, c->d_crt,              \
+                           (uint32_t)count, (uint32_t)n, (uint32_t)c->logm, groups);              \
+        break;
+            SGFHE_FOR_NPR(X)
+#undef X
+        }
         if ((e = hipGetLastError())) break;
         if ((e = hipMemcpyAsync(out_w, d_wv, count * M * 8, hipMemcpyDeviceToHost, c->stream))) break;
         if ((e = hipMemcpyAsync(out_v, d_wv + count * M, count * M * 8, hipMemcpyDeviceToHost, c->stream))) break;
@@ -969,7 +1009,7 @@ int32_t sgfhe_pack_encrypted_bits(sgfhe_ctx *c, const uint64_t *a, const uint64_
 
 int32_t sgfhe_debug_ntt(sgfhe_ctx *c, uint32_t prime_index, int inverse, const uint32_t *in,
                         uint32_t *out) {
-    if (!c || !in || !out || prime_index >= NPR) return SGFHE_ERR_INVALID_ARG;
+    if (!c || !in || !out || prime_index >= c->npr) return SGFHE_ERR_INVALID_ARG;
     (void)hipSetDevice(c->device);
     uint32_t *d = nullptr;
     HIPCHK(c, hipMalloc(&d, (size_t)2 * c->M * 4));
@@ -989,8 +1029,8 @@ int32_t sgfhe_debug_ntt(sgfhe_ctx *c, uint32_t prime_index, int inverse, const u
 
 int32_t sgfhe_debug_primes(const sgfhe_ctx *c, uint32_t *count, uint32_t *primes) {
     if (!c || !count || !primes) return SGFHE_ERR_INVALID_ARG;
-    *count = NPR;
-    for (int i = 0; i < NPR; i++) primes[i] = c->primes[i];
+    *count = c->npr;
+    for (int i = 0; i < c->npr; i++) primes[i] = c->primes[i];
     return SGFHE_OK;
 }
 

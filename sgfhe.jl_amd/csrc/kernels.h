@@ -20,7 +20,8 @@ namespace sgfhe {
 
 typedef unsigned __int128 u128;
 
-constexpr int NPR = 5;   // RNS primes (p_i < 2^30), product M ~ 2^150
+constexpr int NPR_MAX = 6;  // at most this many RNS primes (p_i < 2^30); a ctx uses the fewest whose
+                            // product covers 8 m B Q (4 at Params(64), 5 at Params(512/1024))
 #ifndef SGFHE_LOGE
 #define SGFHE_LOGE 4
 #endif
@@ -39,17 +40,18 @@ struct PrimeK {
     float invp;       // 1 / p
     const uint32_t *twf;  // forward twiddles psi^bitrev(i) * R mod p (Montgomery form)
     const uint32_t *twi;  // inverse twiddles psi^-bitrev(i) * R mod p
+    uint32_t npr;     // number of primes of the ctx (the same in every record)
 };
 
-// The NPR PrimeK records live in device memory and are indexed by the (wave-uniform) prime
+// The npr PrimeK records live in device memory and are indexed by the (wave-uniform) prime
 // index of the workgroup.
 typedef const PrimeK *__restrict__ PrimeSet;
 
 // CRT / flatten constants, resident in device memory.
 struct CrtConst {
     u128 Q, B;
-    u128 c[NPR];         // (M / p_i) mod Q
-    u128 T[NPR + 1];     // (-alpha * M - H') mod Q,  H' = (M / p_last) * (p_last - 1) / 2
+    u128 c[NPR_MAX];     // (M / p_i) mod Q
+    u128 T[NPR_MAX + 1]; // (-alpha * M - H') mod Q,  H' = (M / p_last) * (p_last - 1) / 2
     u128 offneg;         // (Q - off) mod Q, off = (1 + B) s mod Q
     u128 offneg_rnd;     // the same with s + xmax in place of s (randomised flatten)
     uint64_t xmax;       // v_i uniform in [-xmax, xmax], xmax = 3 (B / 2) (utils.jl:210-214)
@@ -58,11 +60,12 @@ struct CrtConst {
     u128 roundthr;       // Q / 2 + (Q odd)        (utils.jl:84)
     double invQ, invB;
     // 32-bit limb / double views of the same constants for k_crt_acc's 96-bit arithmetic
-    uint32_t c32[NPR][3];
+    uint32_t c32[NPR_MAX][3];
     uint32_t Q32[3];
-    alignas(16) uint32_t T32[NPR + 1][4];
-    double cd[NPR], Td[NPR + 1], Bd;
-    float invp[NPR];
+    alignas(16) uint32_t T32[NPR_MAX + 1][4];
+    double cd[NPR_MAX], Td[NPR_MAX + 1], Bd;
+    float invp[NPR_MAX];
+    uint32_t npr;        // number of primes in use
     uint32_t logr;
     ulonglong2 dig0, digP, digN;  // (lo, hi) digits of x' for acc = 0, DQ_tilde, Q - DQ_tilde
 };
@@ -212,8 +215,9 @@ k_extprod(const uint64_t *__restrict__ dig, const uint32_t *__restrict__ keyk,
     const int tid = threadIdx.x;
     const uint32_t g = blockIdx.x;
     const uint32_t slot = g >> 3;
-    const uint32_t b = (slot / NPR) * 8 + (g & 7);
-    const uint32_t pi = slot % NPR;
+    const uint32_t npr = PS[0].npr;
+    const uint32_t b = (slot / npr) * 8 + (g & 7);
+    const uint32_t pi = slot % npr;
     const PrimeK P = PS[pi];
     const uint32_t p = P.p;
     const Mod md = {P.p, P.ninv, 2 * P.p};
@@ -308,14 +312,14 @@ k_extprod(const uint64_t *__restrict__ dig, const uint32_t *__restrict__ keyk,
 #pragma unroll
         for (int e = 0; e < E; e++) z[c][e] = csub(z[c][e], p);
 
-    uint32_t *yb = yres + ((size_t)b * 2 * NPR + pi) * M;
+    uint32_t *yb = yres + ((size_t)b * 2 * npr + pi) * M;
     // 5. y = x^j P - P  (mul_by_xj_minus_one, fhe.jl:554-556, applied to the product)
     if (mode & MODE_PLAIN) {
 #pragma unroll
         for (int c = 0; c < 2; c++)
 #pragma unroll
             for (int e = 0; e < E; e++)
-                yb[(size_t)c * NPR * M + tid + T * e] = csub(z[c][e] + P.hoff, p);
+                yb[(size_t)c * npr * M + tid + T * e] = csub(z[c][e] + P.hoff, p);
         return;
     }
     const uint32_t j = ua[(size_t)b * n + k];
@@ -345,7 +349,7 @@ k_extprod(const uint64_t *__restrict__ dig, const uint32_t *__restrict__ keyk,
                 if (P.hoff) y = condsub(y + P.hoff, p);    // wave-uniform: only the last prime
                 // streamed out: the residues are not read again by this launch, so they should
                 // not displace the digit planes the other prime-workgroups still want from L2
-                __builtin_nontemporal_store(y, &yb[(size_t)c * NPR * M + tid + T * e]);
+                __builtin_nontemporal_store(y, &yb[(size_t)c * npr * M + tid + T * e]);
             }
         }
     }
@@ -374,12 +378,13 @@ __device__ __forceinline__ void mad96(U96 &a, uint32_t y, const uint32_t (&c)[3]
 }
 // S = sum_i y_i c_i + T[alpha] (+ hi B + lo of the previous digits) reduced modulo Q: the
 // canonical residue of x'_new (or of D when there is no previous accumulator), as three limbs.
-__device__ __forceinline__ U96 crt_reduce(const uint32_t (&y)[NPR], const CrtConst *__restrict__ CC,
+template <int NP>
+__device__ __forceinline__ U96 crt_reduce(const uint32_t (&y)[NP], const CrtConst *__restrict__ CC,
                                           bool have_old, ulonglong2 d) {
     float f = 0.f;
     double Sd = 0.0;
 #pragma unroll
-    for (int q = 0; q < NPR; q++) {
+    for (int q = 0; q < NP; q++) {
         f += (float)y[q] * CC->invp[q];
         Sd += (double)y[q] * CC->cd[q];
     }
@@ -388,7 +393,7 @@ __device__ __forceinline__ U96 crt_reduce(const uint32_t (&y)[NPR], const CrtCon
     U96 a = {tv.x, tv.y, tv.z};
     Sd += CC->Td[alpha];
 #pragma unroll
-    for (int q = 0; q < NPR; q++) mad96(a, y[q], CC->c32[q]);
+    for (int q = 0; q < NP; q++) mad96(a, y[q], CC->c32[q]);
     if (have_old) {  // x'_old = hi B + lo
         const uint64_t B = (uint64_t)CC->B;
         const uint32_t h0 = (uint32_t)d.y, h1 = (uint32_t)(d.y >> 32);
@@ -435,6 +440,7 @@ __device__ __forceinline__ U96 crt_reduce(const uint32_t (&y)[NPR], const CrtCon
     return a;
 }
 
+template <int NP>
 __global__ void __launch_bounds__(256)
 k_crt_acc(const uint32_t *__restrict__ yres, uint64_t *__restrict__ dig,
           const CrtConst *__restrict__ CC, uint32_t total, uint32_t logm, uint32_t mode,
@@ -444,10 +450,10 @@ k_crt_acc(const uint32_t *__restrict__ yres, uint64_t *__restrict__ dig,
     const uint32_t M = 1u << logm;
     const uint32_t i = t & (M - 1);
     const uint32_t bc = t >> logm;
-    const uint32_t yo = 4u * ((bc * NPR << logm) + i);  // byte offset
-    uint32_t y[NPR];
+    const uint32_t yo = 4u * ((bc * NP << logm) + i);  // byte offset
+    uint32_t y[NP];
 #pragma unroll
-    for (int q = 0; q < NPR; q++) y[q] = ld_off<uint32_t>(yres, yo + ((uint32_t)(4 * q) << logm));
+    for (int q = 0; q < NP; q++) y[q] = ld_off<uint32_t>(yres, yo + ((uint32_t)(4 * q) << logm));
     const bool have_old = !(mode & MODE_NOACC);
     const ulonglong2 d = have_old ? load_digits(dig, bc, i, M) : make_ulonglong2(0, 0);
     const U96 a = crt_reduce(y, CC, have_old, d);
@@ -642,9 +648,10 @@ k_shortprod(const uint64_t *__restrict__ pdig, const uint32_t *__restrict__ keyh
     using GE = NttGeom<LOGM, LOGE>;
     constexpr int M = GE::M, T = GE::T, E = GE::E;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-    const uint32_t pi = blockIdx.x % NPR;
-    const uint32_t g = (blockIdx.x / NPR) % groups;
-    const uint32_t ci = blockIdx.x / (NPR * groups);
+    const uint32_t npr = PS[0].npr;
+    const uint32_t pi = blockIdx.x % npr;
+    const uint32_t g = (blockIdx.x / npr) % groups;
+    const uint32_t ci = blockIdx.x / (npr * groups);
     const PrimeK P = PS[pi];
     const uint32_t p = P.p;
     const Mod md = {P.p, P.ninv, 2 * P.p};
@@ -668,7 +675,7 @@ k_shortprod(const uint64_t *__restrict__ pdig, const uint32_t *__restrict__ keyh
         SGFHE_SYNC();
         ntt_forward<LOGM, 1, LOGE>(x, lds, P.twf, tid, md);
         // key rows l + 1 .. 2 l of slice i (fhe.jl:638-639): polynomials (2 + digit) * 2 + c
-        const uint32_t *kp = keyhat + (((size_t)i * NPR + pi) * 8 + (2 + digit) * 2) * M + E * tid;
+        const uint32_t *kp = keyhat + (((size_t)i * npr + pi) * 8 + (2 + digit) * 2) * M + E * tid;
 #pragma unroll
         for (int h = 0; h < E / 4; h++) {
             const uint4 a = reinterpret_cast<const uint4 *>(kp)[h];
@@ -686,7 +693,7 @@ k_shortprod(const uint64_t *__restrict__ pdig, const uint32_t *__restrict__ keyh
         }
     }
     const int tid = threadIdx.x;
-    uint32_t *yb = yg + (((size_t)ci * groups + g) * 2 * NPR + pi) * M;
+    uint32_t *yb = yg + (((size_t)ci * groups + g) * 2 * npr + pi) * M;
 #pragma unroll
     for (int c = 0; c < 2; c++) {
         if (c > 0) {
@@ -697,13 +704,14 @@ k_shortprod(const uint64_t *__restrict__ pdig, const uint32_t *__restrict__ keyh
         ntt_inverse<LOGM, 1, LOGE>(z0, lds, P.twi, tid, md);
 #pragma unroll
         for (int e = 0; e < E; e++)
-            yb[(size_t)c * NPR * M + tid + T * e] = condsub(condsub(z0[0][e], p) + P.hoff, p);
+            yb[(size_t)c * npr * M + tid + T * e] = condsub(condsub(z0[0][e], p) + P.hoff, p);
     }
 }
 
 // One thread per (ciphertext, coefficient k < m): W = sum_g CRT(y_g column 0), V likewise
 // (fhe.jl:686-687); w = ModRed(-W), v = ModRed(b_k - V) (fhe.jl:689-693), b_k = the un-reduced
 // LWE constant of bit k for k < n and 0 beyond (resize, fhe.jl:678).
+template <int NP>
 __global__ void __launch_bounds__(256)
 k_pack_finish(const uint32_t *__restrict__ yg, const ulonglong2 *__restrict__ raw,
               uint64_t *__restrict__ out_w, uint64_t *__restrict__ out_v,
@@ -719,10 +727,10 @@ k_pack_finish(const uint32_t *__restrict__ yg, const ulonglong2 *__restrict__ ra
     for (uint32_t g = 0; g < groups; g++) {
 #pragma unroll
         for (int c = 0; c < 2; c++) {
-            const uint32_t *yp = yg + ((((size_t)ci * groups + g) * 2 + c) * NPR) * M + kk;
-            uint32_t y[NPR];
+            const uint32_t *yp = yg + ((((size_t)ci * groups + g) * 2 + c) * NP) * M + kk;
+            uint32_t y[NP];
 #pragma unroll
-            for (int q = 0; q < NPR; q++) y[q] = yp[(size_t)q * M];
+            for (int q = 0; q < NP; q++) y[q] = yp[(size_t)q * M];
             const U96 a = crt_reduce(y, CC, false, make_ulonglong2(0, 0));
             acc[c] += ((u128)a.w2 << 64) | ((uint64_t)a.w1 << 32) | a.w0;
             if (acc[c] >= Q) acc[c] -= Q;
@@ -819,7 +827,8 @@ k_polymul_s(const ulonglong2 *__restrict__ acan, const uint32_t *__restrict__ sh
     constexpr int M = G::M, T = G::T, E = G::E;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const int tid = threadIdx.x;
-    const uint32_t r = blockIdx.x / NPR, pi = blockIdx.x % NPR;
+    const uint32_t npr = PS[0].npr;
+    const uint32_t r = blockIdx.x / npr, pi = blockIdx.x % npr;
     const PrimeK P = PS[pi];
     const uint32_t p = P.p;
     const Mod md = {P.p, P.ninv, 2 * P.p};
@@ -843,7 +852,7 @@ k_polymul_s(const ulonglong2 *__restrict__ acan, const uint32_t *__restrict__ sh
     ntt_inverse<LOGM, 1, LOGE>(x, lds, P.twi, tid, md);
 #pragma unroll
     for (int e = 0; e < E; e++)
-        y[((size_t)r * NPR + pi) * M + tid + T * e] = condsub(condsub(x[0][e], p) + P.hoff, p);
+        y[((size_t)r * npr + pi) * M + tid + T * e] = condsub(condsub(x[0][e], p) + P.hoff, p);
 }
 
 // canon[(r * 2 + col)][m]: col 0 = a_r + s_k G[row][0], col 1 = a_r (*) s + e_r + s_k G[row][1]
@@ -886,8 +895,9 @@ k_key_transform(const ulonglong2 *__restrict__ canon, uint32_t *__restrict__ key
     constexpr int M = G::M, T = G::T, E = G::E;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const int tid = threadIdx.x;
-    const uint32_t pl = blockIdx.x / NPR;  // polynomial within this staging batch
-    const uint32_t pi = blockIdx.x % NPR;
+    const uint32_t npr = PS[0].npr;
+    const uint32_t pl = blockIdx.x / npr;  // polynomial within this staging batch
+    const uint32_t pi = blockIdx.x % npr;
     const PrimeK P = PS[pi];
     const uint32_t p = P.p;
     const Mod md = {P.p, P.ninv, 2 * P.p};
@@ -906,7 +916,7 @@ k_key_transform(const ulonglong2 *__restrict__ canon, uint32_t *__restrict__ key
     }
     ntt_forward<LOGM, 1, LOGE>(x, lds, P.twf, tid, md);
     const uint32_t pg = poly0 + pl;  // global polynomial index = k * 8 + row * 2 + col
-    uint32_t *dst = keyhat + (((size_t)(pg >> 3) * NPR + pi) * 8 + (pg & 7)) * M + E * tid;
+    uint32_t *dst = keyhat + (((size_t)(pg >> 3) * npr + pi) * 8 + (pg & 7)) * M + E * tid;
 #pragma unroll
     for (int h = 0; h < E / 4; h++) {
         uint32_t o[4];

@@ -7,7 +7,7 @@ Test infrastructure only (used by tests/test_rns_model.py).
 
 import numpy as np
 
-NPR = 5
+NPR_MAX = 6
 MASK32 = 0xFFFFFFFF
 
 
@@ -36,15 +36,37 @@ def is_prime32(x):
     return True
 
 
-def rns_primes():
+def rns_primes(count=NPR_MAX):
+    """The `count` largest primes below 2^30 that are 1 mod 2^15 (candidates of build_constants)."""
     out = []
     kk = ((1 << 30) - 1) >> 15
-    while len(out) < NPR:
+    while len(out) < count:
         cand = (kk << 15) + 1
         if cand < (1 << 30) and is_prime32(cand):
             out.append(cand)
         kk -= 1
     return out
+
+
+def select_npr(logm, B, Q):
+    """build_constants: the fewest primes covering 8 m B Q (times 4 for the randomised flatten when
+    NPR_MAX primes allow it), at least 2; same floating-point rule as the engine."""
+    import math
+    cand = rns_primes()
+    need = 3.0 + logm + math.log2(float(B)) + math.log2(float(Q)) + 0.01
+
+    def count(target):
+        have, k = 0.0, 0
+        while k < NPR_MAX and (k < 2 or have < target):
+            have += math.log2(float(cand[k]))
+            k += 1
+        return k, have
+
+    k, have = count(need + 2.0)
+    if have < need + 2.0:
+        k, have = count(need)
+    assert have >= need, "exactness bound"
+    return k
 
 
 def bitrev(x, bits):
@@ -59,7 +81,8 @@ class Consts:
     def __init__(self, n, m, Q, B, DQ_tilde):
         self.n, self.M, self.Q, self.B = n, m, Q, B
         self.logm = m.bit_length() - 1
-        self.primes = rns_primes()
+        self.npr = NPR = select_npr(self.logm, B, Q)
+        self.primes = rns_primes()[:NPR]
         prod = 1
         for p in self.primes:
             prod *= p
@@ -306,6 +329,7 @@ class EngineModel:
         """k_extprod for one bootstrap: dig_* lists of (lo, hi); keyslice[pi][row*2+col] slot
         arrays; returns y[c][pi] arrays (natural order)."""
         C = self.C
+        NPR = C.npr
         M, T = C.M, self.ntt.T
         ys = [[None] * NPR for _ in range(2)]
         for pi in range(NPR):
@@ -350,6 +374,7 @@ class EngineModel:
     def crt_acc(self, ys_c, dig_old, noacc=False, canon=False):
         """k_crt_acc for one polynomial: ys_c[pi] arrays -> new digits (or canonical values)."""
         C = self.C
+        NPR = C.npr
         out = []
         for i in range(C.M):
             y = [int(ys_c[pi][i]) for pi in range(NPR)]

@@ -162,7 +162,8 @@ def test_device_form_export_import(S, p64):
     import torch
     params, o, sk, bkey, eng = p64
     nbytes = eng.key_device_form_bytes()
-    assert nbytes == params.n * 5 * 8 * params.m * 4
+    assert len(eng.primes()) == 4                        # Params(64): 4 primes cover 32 m B Q
+    assert nbytes == params.n * 4 * 8 * params.m * 4
     blob = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
     eng.export_key_device_form(blob.data_ptr())
     eng2 = S.Engine(params)

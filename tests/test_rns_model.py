@@ -30,7 +30,7 @@ def test_ntt_model(logm, loge):
     m = 1 << logm
     C = RM.Consts(m // 8, m, (1 << 50) + 1, 1 << 26, 12345)
     N = RM.NttModel(logm, loge)
-    P = C.pk[logm % RM.NPR]
+    P = C.pk[logm % C.npr]
     p = P["p"]
     poly = np.random.default_rng(logm).integers(0, p, size=m, dtype=np.uint64)
     x = N.forward(N.to_regs(poly), P["twf"], p, P["ninv"])
@@ -70,7 +70,7 @@ def test_pipeline_matches_oracle():
     bk = BO.bootstrap_key(p, sk, 6, noise=2)
     E = RM.EngineModel(n, m, Q, B, p.DQ_tilde)
     key = [[[E.key_transform(bk[k][rc // 2][rc % 2], pi) for rc in range(8)]
-            for pi in range(RM.NPR)] for k in range(n)]
+            for pi in range(E.C.npr)] for k in range(n)]
     g = BO.SplitMix64(7)
     l1 = BO.lwe_encrypt_bit(p, sk, 1, g)
     l2 = BO.lwe_encrypt_bit(p, sk, 0, g)
