@@ -27,7 +27,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_HBM_GBS = 8000.0     # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
-W_BYTES = {"params1024": 16, "params512": 16, "params64": 8, "synth64": 8}
+W_BYTES = {"params1024": 16, "params512": 16, "params2048": 16, "params64": 8, "synth64": 8}
 
 
 def make_params(S, name):
@@ -35,6 +35,8 @@ def make_params(S, name):
         return S.Params(1024)
     if name == "params512":
         return S.Params(512)
+    if name == "params2048":  # the largest parameter set the reference can build
+        return S.Params(2048)
     if name == "params64":
         return S.Params(64)
     if name == "synth64":   # BASELINE.json config 3: n = 1024 with a single-limb 64-bit prime

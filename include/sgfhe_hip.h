@@ -48,7 +48,7 @@ typedef enum {
 typedef struct {
     uint64_t n;           /* LWE dimension (polynomial length of the small ring) */
     uint64_t r;           /* LWE modulus, power of two, r = 2 m */
-    uint64_t m;           /* bootstrap polynomial length, power of two, 2^6 .. 2^13 */
+    uint64_t m;           /* bootstrap polynomial length, power of two, 2^6 .. 2^14 */
     uint64_t ell;         /* gadget decomposition length; must be 2 */
     uint64_t Q[2];        /* bootstrap modulus, Q < 2^94 */
     uint64_t B[2];        /* gadget base, B^2 >= Q, B < 2^46 */
@@ -70,7 +70,7 @@ int32_t sgfhe_ctx_destroy(sgfhe_ctx *ctx);
 const char *sgfhe_last_error_string(const sgfhe_ctx *ctx);
 
 /* Batch-scheduling knobs.  chunk: bootstraps that move through the k-loop in lock-step
- * (0 = default, at most 8192; rounded up to a multiple of 8).  lanes: 1 (default) runs the
+ * (0 = default; rounded up to a multiple of 8; a chunk's buffers must stay below 4 GiB).  lanes: 1 (default) runs the
  * chunks of a batch one after the other; 2 runs consecutive chunks on two HIP streams (measured
  * equal to one stream with twice the chunk).  Every setting gives bit-identical results. */
 int32_t sgfhe_set_chunk(sgfhe_ctx *ctx, uint32_t chunk);

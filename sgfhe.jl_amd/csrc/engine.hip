@@ -131,7 +131,7 @@ template <int LOGM> constexpr int threads_of() { return NttGeom<LOGM, LOGE>::T; 
 
 // ---- per-LOGM dispatch ------------------------------------------------------------------------
 
-#define SGFHE_FOR_LOGM(X) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13)
+#define SGFHE_FOR_LOGM(X) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14)
 
 template <int LOGM>
 int32_t launch_extprod_t(sgfhe_ctx *c, const sgfhe_ctx::Lane &L, const uint32_t *keyk,
@@ -630,8 +630,8 @@ int32_t sgfhe_ctx_create(const sgfhe_params *p, int device, sgfhe_ctx **out) {
     c->device = device;
     const uint64_t m = p->m;
     if (p->ell != 2) return fail(c, SGFHE_ERR_UNSUPPORTED, "ell must be 2 (fhe.jl:576)");
-    if (m < 64 || m > 8192 || (m & (m - 1)))
-        return fail(c, SGFHE_ERR_UNSUPPORTED, "m must be a power of two in [2^6, 2^13]");
+    if (m < 64 || m > 16384 || (m & (m - 1)))
+        return fail(c, SGFHE_ERR_UNSUPPORTED, "m must be a power of two in [2^6, 2^14]");
     if (p->r != 2 * m) return fail(c, SGFHE_ERR_INVALID_ARG, "r must equal 2 m (fhe.jl:62)");
     if (p->n == 0 || p->n > m / 4)
         return fail(c, SGFHE_ERR_INVALID_ARG, "n must be in [1, m / 4] (extract, fhe.jl:585-590)");
@@ -677,8 +677,12 @@ int32_t sgfhe_ctx_destroy(sgfhe_ctx *c) {
 
 int32_t sgfhe_set_chunk(sgfhe_ctx *c, uint32_t chunk) {
     if (!c) return SGFHE_ERR_INVALID_ARG;
-    if (chunk > 8192)  // the kernels index a chunk's planes with 32-bit element offsets
-        return fail(c, SGFHE_ERR_INVALID_ARG, "chunk must be at most 8192 bootstraps");
+    // the kernels index a chunk's planes with 32-bit byte offsets: residues [chunk][2][npr][m] x 4 B
+    // and digit records [chunk][2] x 16 m B must stay below 4 GiB
+    const uint64_t cap_y = 0xFFFFFFFFull / ((uint64_t)2 * c->npr * c->M * 4);
+    const uint64_t cap_d = 0xFFFFFFFFull / ((uint64_t)2 * 16 * c->M);
+    const uint64_t cap = (cap_y < cap_d ? cap_y : cap_d) & ~7ull;
+    if (chunk > cap) return fail(c, SGFHE_ERR_INVALID_ARG, "chunk too large for this ring size");
     c->chunk = chunk ? round_up8(chunk) : 0;
     return SGFHE_OK;
 }
@@ -1030,7 +1034,7 @@ int32_t sgfhe_debug_ntt(sgfhe_ctx *c, uint32_t prime_index, int inverse, const u
 int32_t sgfhe_debug_primes(const sgfhe_ctx *c, uint32_t *count, uint32_t *primes) {
     if (!c || !count || !primes) return SGFHE_ERR_INVALID_ARG;
     *count = c->npr;
-    for (int i = 0; i < c->npr; i++) primes[i] = c->primes[i];
+    for (uint32_t i = 0; i < c->npr; i++) primes[i] = c->primes[i];
     return SGFHE_OK;
 }
 

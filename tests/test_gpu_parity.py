@@ -24,7 +24,7 @@ def _inputs(oc_obj, sk, batch, seed):
     return bits, a[0::2], b[0::2], a[1::2], b[1::2]
 
 
-@pytest.mark.parametrize("logm", [6, 7, 8, 9, 10, 11, 12, 13])
+@pytest.mark.parametrize("logm", [6, 7, 8, 9, 10, 11, 12, 13, 14])
 def test_ntt_matches_model(S, logm):
     """sgfhe_debug_ntt: forward = evaluations in slot order, inverse(forward(x)) = x."""
     m = 1 << logm
@@ -202,6 +202,42 @@ def test_params1024_full_batch_4096(S, oc):
     y1, y2 = bits[0::2], bits[1::2]
     dec = o.lwe_decrypt_bits(sk, out[:4096:512, 2, :params.n], out[:4096:512, 2, params.n])
     assert np.array_equal(dec, (y1 ^ y2)[idx[:4096:512]])
+    eng.close()
+
+
+def test_params2048_largest_reference_ring(S, oc):
+    """Params(2048): the largest parameter set the reference can build (Q 92.25 bits < 2^128,
+    src/fhe.jl:74-77): m = 16384, six RNS primes, B just above 2^46.  The first two k-loop
+    iterations against the oracle (only key slices 0 and 1 are filled), then complete gate
+    bootstraps with a device-generated key, checked by decryption."""
+    import bench
+    params = S.Params(2048)
+    o = oc.Oracle.from_params(params)
+    eng = S.Engine(params)
+    assert len(eng.primes()) == 6
+    key = np.zeros((params.n, 4, 2, params.m, 2), dtype=np.uint64)
+    key[:2] = bench.random_key(params, 41)[:2]
+    eng.upload_key(key)
+    rng = np.random.default_rng(42)
+    a1 = rng.integers(0, params.r, size=(2, params.n), dtype=np.uint64)
+    a2 = rng.integers(0, params.r, size=(2, params.n), dtype=np.uint64)
+    b1 = rng.integers(0, params.r, size=2, dtype=np.uint64)
+    b2 = rng.integers(0, params.r, size=2, dtype=np.uint64)
+    for it in (1, 2):
+        _, acc_ref = o.bootstrap_batch(key, a1, b1, a2, b2, n_iters=it, want_acc=True, threads=2)
+        assert np.array_equal(eng.debug_accumulators(a1, b1, a2, b2, it), acc_ref)
+    del key
+    sk = o.private_key(43)
+    eng.generate_key(sk, 44)
+    bits = np.array([0, 0, 0, 1, 1, 0, 1, 1] * 2, dtype=np.uint8)
+    a, b = o.lwe_encrypt_bits(sk, bits, 45)
+    out = eng.bootstrap_batch(a[0::2], b[0::2], a[1::2], b[1::2])
+    y1, y2 = bits[0::2], bits[1::2]
+    for g, fn in enumerate((np.bitwise_and, np.bitwise_or, np.bitwise_xor)):
+        dec = o.lwe_decrypt_bits(sk, out[:, g, :params.n], out[:, g, params.n])
+        assert np.array_equal(dec, fn(y1, y2))
+    with pytest.raises(S.SgfheError):                      # digits of the randomised mode need B < 2^46
+        eng.set_random_flatten(True, 1)
     eng.close()
 
 
