@@ -74,6 +74,11 @@ const char *sgfhe_last_error_string(const sgfhe_ctx *ctx);
  * chunks of a batch one after the other; 2 runs consecutive chunks on two HIP streams (measured
  * equal to one stream with twice the chunk).  Every setting gives bit-identical results. */
 int32_t sgfhe_set_chunk(sgfhe_ctx *ctx, uint32_t chunk);
+/* Chunks of at most this many bootstraps (default 24, 0 = never, at most 256) run the k-loop in
+ * its small-batch form: 6 workgroups per (bootstrap, RNS prime) and three launches per iteration
+ * instead of 1 and two, which shortens the serial chain a single bootstrap() call waits for.
+ * Same results bit for bit. */
+int32_t sgfhe_set_small_batch_max(sgfhe_ctx *ctx, uint32_t max_bootstraps);
 int32_t sgfhe_set_lanes(sgfhe_ctx *ctx, uint32_t lanes);
 
 /*

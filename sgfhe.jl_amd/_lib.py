@@ -65,6 +65,7 @@ def lib():
         "sgfhe_last_error_string": (ctypes.c_char_p, [vp]),
         "sgfhe_set_chunk": (i32, [vp, u32]),
         "sgfhe_set_lanes": (i32, [vp, u32]),
+        "sgfhe_set_small_batch_max": (i32, [vp, u32]),
         "sgfhe_set_random_flatten": (i32, [vp, ctypes.c_int, u64]),
         "sgfhe_bkey_upload": (i32, [vp, vp, sz]),
         "sgfhe_bkey_upload_rns2": (i32, [vp, vp, sz, u64, u64]),
@@ -93,7 +94,7 @@ def lib():
 
 EXPORTED_SYMBOLS = (
     "sgfhe_version", "sgfhe_ctx_create", "sgfhe_ctx_destroy", "sgfhe_last_error_string",
-    "sgfhe_set_chunk", "sgfhe_set_lanes", "sgfhe_set_random_flatten", "sgfhe_bkey_upload", "sgfhe_bkey_upload_rns2", "sgfhe_bkey_generate",
+    "sgfhe_set_chunk", "sgfhe_set_lanes", "sgfhe_set_small_batch_max", "sgfhe_set_random_flatten", "sgfhe_bkey_upload", "sgfhe_bkey_upload_rns2", "sgfhe_bkey_generate",
     "sgfhe_bkey_device_form_bytes", "sgfhe_bkey_export_device_form",
     "sgfhe_bkey_import_device_form", "sgfhe_bootstrap_batch", "sgfhe_bootstrap_batch_device",
     "sgfhe_sync", "sgfhe_external_product", "sgfhe_pack_encrypted_bits", "sgfhe_debug_accumulators", "sgfhe_debug_ntt",

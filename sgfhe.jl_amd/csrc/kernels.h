@@ -477,6 +477,120 @@ k_crt_acc(const uint32_t *__restrict__ yres, uint64_t *__restrict__ dig,
     store_digits(dig, bc, i, M, (uint64_t)lo, hq);
 }
 
+// ---- small-batch ("latency") form of the external product --------------------------------------
+// A call with a handful of gates leaves most of the 256 CUs idle while one workgroup per
+// (bootstrap, prime) walks through 4 forward and 2 inverse transforms.  Here the same work is cut
+// into 4 + 2 independent workgroups per (bootstrap, prime), three launches per iteration:
+//   k_fwd_phase   (bootstrap, prime, key row ph)  digit plane -> forward NTT -> products with the
+//                 two key polynomials of that row, reduced to [0, 2p)      -> zpart
+//   k_inv_column  (bootstrap, prime, column c)    sum of the four partial products -> inverse NTT
+//                 -> (x^j - 1) rotation -> residues                         -> yres
+//   k_crt_acc     as before.
+//   zpart [chunk][npr][4][2][m]   slot order (E tid + e)
+template <int LOGM>
+__global__ void __launch_bounds__((NttGeom<LOGM, LOGE>::T), (NttGeom<LOGM, LOGE>::T >= 256 ? 4 : 1))
+k_fwd_phase(const uint64_t *__restrict__ dig, const uint32_t *__restrict__ keyk,
+            uint32_t *__restrict__ zpart, PrimeSet PS, uint32_t mode) {
+    using G = NttGeom<LOGM, LOGE>;
+    constexpr int M = G::M, T = G::T, E = G::E;
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const int tid = threadIdx.x;
+    const uint32_t npr = PS[0].npr;
+    const uint32_t ph = blockIdx.x & 3u;
+    const uint32_t pi = (blockIdx.x >> 2) % npr;
+    const uint32_t b = (blockIdx.x >> 2) / npr;
+    const PrimeK P = PS[pi];
+    const uint32_t p = P.p;
+    const Mod md = {P.p, P.ninv, 2 * P.p};
+    const uint32_t sRd = (mode & MODE_RANDOM) ? P.sRr : P.sR;
+
+    uint32_t x[1][E];
+    const uint32_t *dl = digit_lo_plane(dig, (size_t)b * 2 + (ph >> 1), M) + (ph & 1) * M;
+    const uint16_t *dh = digit_hi_plane(dig, (size_t)b * 2 + (ph >> 1), M) + (ph & 1) * M;
+#pragma unroll
+    for (int e = 0; e < E; e++)
+        x[0][e] = digit_reduce(dl[tid + T * e] | ((uint64_t)dh[tid + T * e] << 32), P, sRd);
+    ntt_forward<LOGM, 1, LOGE>(x, lds, P.twf, tid, md);
+
+    const uint32_t *kp = keyk + ((size_t)pi * 8 + ph * 2) * M + E * tid;
+    uint32_t *zp = zpart + ((((size_t)b * npr + pi) * 4 + ph) * 2) * M + E * tid;
+#pragma unroll
+    for (int h = 0; h < E / 4; h++) {
+        const uint4 a = reinterpret_cast<const uint4 *>(kp)[h];
+        const uint4 bq = reinterpret_cast<const uint4 *>(kp + M)[h];
+        const uint32_t ka[4] = {a.x, a.y, a.z, a.w};
+        const uint32_t kb[4] = {bq.x, bq.y, bq.z, bq.w};
+        uint32_t r0[4], r1[4];
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const uint32_t u = condsub(x[0][4 * h + t], md.p2);
+            r0[t] = redc_mad((uint64_t)u * ka[t], p, P.ninv);  // [0, 2p)
+            r1[t] = redc_mad((uint64_t)u * kb[t], p, P.ninv);
+        }
+        reinterpret_cast<uint4 *>(zp)[h] = make_uint4(r0[0], r0[1], r0[2], r0[3]);
+        reinterpret_cast<uint4 *>(zp + M)[h] = make_uint4(r1[0], r1[1], r1[2], r1[3]);
+    }
+}
+
+template <int LOGM>
+__global__ void __launch_bounds__((NttGeom<LOGM, LOGE>::T), (NttGeom<LOGM, LOGE>::T >= 256 ? 4 : 1))
+k_inv_column(const uint32_t *__restrict__ zpart, uint32_t *__restrict__ yres,
+             const uint32_t *__restrict__ ua, PrimeSet PS, uint32_t k, uint32_t n) {
+    using G = NttGeom<LOGM, LOGE>;
+    constexpr int M = G::M, T = G::T, E = G::E;
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const int tid = threadIdx.x;
+    const uint32_t npr = PS[0].npr;
+    const uint32_t c = blockIdx.x & 1u;
+    const uint32_t pi = (blockIdx.x >> 1) % npr;
+    const uint32_t b = (blockIdx.x >> 1) / npr;
+    const PrimeK P = PS[pi];
+    const uint32_t p = P.p;
+    const Mod md = {P.p, P.ninv, 2 * P.p};
+
+    uint32_t z[1][E];
+    const uint32_t *zp = zpart + ((((size_t)b * npr + pi) * 4) * 2 + c) * M + E * tid;
+#pragma unroll
+    for (int h = 0; h < E / 4; h++) {
+        uint32_t acc[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int ph = 0; ph < 4; ph++) {
+            const uint4 v = reinterpret_cast<const uint4 *>(zp + (size_t)ph * 2 * M)[h];
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int t = 0; t < 4; t++) acc[t] = condsub(acc[t] + w[t], md.p2);  // stays in [0, 2p)
+        }
+#pragma unroll
+        for (int t = 0; t < 4; t++) z[0][4 * h + t] = acc[t];
+    }
+    ntt_inverse<LOGM, 1, LOGE>(z, lds, P.twi, tid, md);
+#pragma unroll
+    for (int e = 0; e < E; e++) z[0][e] = csub(z[0][e], p);
+
+    // y = x^j P - P  (as in k_extprod)
+    uint32_t *yb = yres + (((size_t)b * 2 + c) * npr + pi) * M;
+    const uint32_t j = ua[(size_t)b * n + k];
+    lds_store<LOGM, 1, LOGE, G::STOP>(z, lds, tid);  // own addresses: the thread's last loads
+    SGFHE_SYNC();
+    constexpr uint32_t LOWMASK = (1u << G::STOP) - 1u;
+    const uint32_t s0 = ((uint32_t)tid - j) & (2 * M - 1);
+    const uint32_t lowswz = swz<LOGE>(s0 & LOWMASK);
+    const uint32_t h0 = s0 >> G::STOP;
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+        const uint32_t he = h0 + e;
+        const uint32_t hipart = (he & (E - 1)) << G::STOP;
+        const uint32_t addr = hipart ^ lowswz ^ (G::STOP >= 9 ? 0u : swz_bits<LOGE>(hipart));
+        const uint32_t v = lds[addr];
+        const uint32_t vs = (he & E) ? p - v : v;  // x^m = -1
+        uint32_t d;
+        const bool borrow = __builtin_usub_overflow(vs, z[0][e], &d);
+        uint32_t y = borrow ? d + p : d;           // [0, p]
+        if (P.hoff) y = condsub(y + P.hoff, p);
+        yb[tid + T * e] = y;
+    }
+}
+
 // ---- k_init -------------------------------------------------------------------------------------
 // u = lwe1 + lwe2 (fhe.jl:566); a = 0 (fhe.jl:570); b = x^(-u.b) t DQ_tilde (fhe.jl:572-573) with
 // t = initial_poly (fhe.jl:535-548): +1 on [0, Dr), 0 at Dr, -1 on (Dr, m).  Every coefficient of

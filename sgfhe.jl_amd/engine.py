@@ -101,6 +101,10 @@ class Engine:
     def set_lanes(self, lanes):
         self._chk(self._L.sgfhe_set_lanes(self._h, lanes))
 
+    def set_small_batch_max(self, max_bootstraps):
+        """Chunks of at most this many bootstraps use the small-batch form of the k-loop (0: never)."""
+        self._chk(self._L.sgfhe_set_small_batch_max(self._h, max_bootstraps))
+
     def set_random_flatten(self, enable, seed=0):
         """rng != nothing branch of flatten (utils.jl:198-241): Philox stream of `seed`."""
         self._chk(self._L.sgfhe_set_random_flatten(self._h, int(bool(enable)),

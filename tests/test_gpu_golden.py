@@ -118,6 +118,12 @@ def test_chunk_size_independence_and_determinism(S, p64):
     assert np.array_equal(eng.bootstrap_batch(a1, b1, a2, b2), base)
     eng.set_lanes(1)
     eng.set_chunk(0)
+    for small in (0, 8, 40, 32):                       # large form only / mixed by chunk / small only
+        eng.set_small_batch_max(small)
+        for chunk in (0, 8, 24):
+            eng.set_chunk(chunk)
+            assert np.array_equal(eng.bootstrap_batch(a1, b1, a2, b2), base)
+    eng.set_chunk(0)
     assert np.array_equal(base, o.bootstrap_batch(bkey, a1, b1, a2, b2))
 
 

@@ -6,6 +6,8 @@ import sgfhe_jl_amd as S
 
 p = S.Params(1024)
 eng = S.Engine(p)
+if os.environ.get("SGFHE_SMALL_MAX"):
+    eng.set_small_batch_max(int(os.environ["SGFHE_SMALL_MAX"]))
 eng.generate_key(np.random.default_rng(11).integers(0, 2, size=p.n, dtype=np.uint64), 1)
 g = torch.Generator(device="cuda"); g.manual_seed(1)
 for B in [int(x) for x in sys.argv[1:]] or [1, 8, 64, 256, 512]:
