@@ -100,7 +100,7 @@ struct sgfhe_ctx {
         uint32_t *zpart = nullptr;  // small-batch form only: [cap_small][npr][4][2][m]
     } lane[2];
     uint32_t small_max = 24;  // chunks of at most this many bootstraps take the small-batch form
-                              // (measured crossover at Params(1024): 24 -> 38.9 vs 40.9 ms, 32 -> 51.0 vs 42.3 ms)
+                              // (measured crossover at Params(1024): 24 -> 32.3 vs 40.9 ms, 32 -> 44.0 vs 42.3 ms)
     // timing
     bool timing = false;
     struct EvTriple { hipEvent_t e0, e1, e2; };  // ext = e0 -> e1, crt = e1 -> e2
@@ -164,19 +164,22 @@ int32_t launch_extprod(sgfhe_ctx *c, const sgfhe_ctx::Lane &L, const uint32_t *k
 template <int LOGM>
 int32_t launch_small_t(sgfhe_ctx *c, const sgfhe_ctx::Lane &L, const uint32_t *keyk, uint32_t cpad,
                        uint32_t k, uint32_t mode, hipStream_t st) {
+    // 8 points per thread while m / 8 threads fit a workgroup, else the engine's 16
+    constexpr int LE = (LOGM - 3 <= 10 && LOGM >= 9) ? 3 : LOGE;
+    constexpr int TH = NttGeom<LOGM, LE>::T;
     const size_t lds = lds_bytes(LOGM, 1);
     static bool attr_done[16] = {};
     if (!attr_done[c->device & 15]) {
-        HIPCHK(c, hipFuncSetAttribute((const void *)k_fwd_phase<LOGM>,
+        HIPCHK(c, hipFuncSetAttribute((const void *)k_fwd_phase<LOGM, LE>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        HIPCHK(c, hipFuncSetAttribute((const void *)k_inv_column<LOGM>,
+        HIPCHK(c, hipFuncSetAttribute((const void *)k_inv_column<LOGM, LE>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_done[c->device & 15] = true;
     }
-    hipLaunchKernelGGL(k_fwd_phase<LOGM>, dim3(cpad * c->npr * 4), dim3(threads_of<LOGM>()), lds, st,
-                       L.dig, keyk, L.zpart, c->d_primes, mode);
-    hipLaunchKernelGGL(k_inv_column<LOGM>, dim3(cpad * c->npr * 2), dim3(threads_of<LOGM>()), lds, st,
-                       L.zpart, L.yres, L.ua, c->d_primes, k, c->n);
+    hipLaunchKernelGGL((k_fwd_phase<LOGM, LE>), dim3(cpad * c->npr * 4), dim3(TH), lds, st, L.dig,
+                       keyk, L.zpart, c->d_primes, mode);
+    hipLaunchKernelGGL((k_inv_column<LOGM, LE>), dim3(cpad * c->npr * 2), dim3(TH), lds, st, L.zpart,
+                       L.yres, L.ua, c->d_primes, k, c->n);
     HIPCHK(c, hipGetLastError());
     return SGFHE_OK;
 }

@@ -486,12 +486,14 @@ k_crt_acc(const uint32_t *__restrict__ yres, uint64_t *__restrict__ dig,
 //   k_inv_column  (bootstrap, prime, column c)    sum of the four partial products -> inverse NTT
 //                 -> (x^j - 1) rotation -> residues                         -> yres
 //   k_crt_acc     as before.
-//   zpart [chunk][npr][4][2][m]   slot order (E tid + e)
-template <int LOGM>
-__global__ void __launch_bounds__((NttGeom<LOGM, LOGE>::T), (NttGeom<LOGM, LOGE>::T >= 256 ? 4 : 1))
+//   zpart [chunk][npr][4][2][m]   slot order (the order of the key slices)
+// Both run with 8 points per thread where that fits a workgroup (LE = 3: twice the threads on
+// each transform); the slot order of a transform does not depend on the points per thread.
+template <int LOGM, int LE>
+__global__ void __launch_bounds__((NttGeom<LOGM, LE>::T), (NttGeom<LOGM, LE>::T >= 256 ? 4 : 1))
 k_fwd_phase(const uint64_t *__restrict__ dig, const uint32_t *__restrict__ keyk,
             uint32_t *__restrict__ zpart, PrimeSet PS, uint32_t mode) {
-    using G = NttGeom<LOGM, LOGE>;
+    using G = NttGeom<LOGM, LE>;
     constexpr int M = G::M, T = G::T, E = G::E;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const int tid = threadIdx.x;
@@ -510,7 +512,7 @@ k_fwd_phase(const uint64_t *__restrict__ dig, const uint32_t *__restrict__ keyk,
 #pragma unroll
     for (int e = 0; e < E; e++)
         x[0][e] = digit_reduce(dl[tid + T * e] | ((uint64_t)dh[tid + T * e] << 32), P, sRd);
-    ntt_forward<LOGM, 1, LOGE>(x, lds, P.twf, tid, md);
+    ntt_forward<LOGM, 1, LE>(x, lds, P.twf, tid, md);
 
     const uint32_t *kp = keyk + ((size_t)pi * 8 + ph * 2) * M + E * tid;
     uint32_t *zp = zpart + ((((size_t)b * npr + pi) * 4 + ph) * 2) * M + E * tid;
@@ -532,11 +534,11 @@ k_fwd_phase(const uint64_t *__restrict__ dig, const uint32_t *__restrict__ keyk,
     }
 }
 
-template <int LOGM>
-__global__ void __launch_bounds__((NttGeom<LOGM, LOGE>::T), (NttGeom<LOGM, LOGE>::T >= 256 ? 4 : 1))
+template <int LOGM, int LE>
+__global__ void __launch_bounds__((NttGeom<LOGM, LE>::T), (NttGeom<LOGM, LE>::T >= 256 ? 4 : 1))
 k_inv_column(const uint32_t *__restrict__ zpart, uint32_t *__restrict__ yres,
              const uint32_t *__restrict__ ua, PrimeSet PS, uint32_t k, uint32_t n) {
-    using G = NttGeom<LOGM, LOGE>;
+    using G = NttGeom<LOGM, LE>;
     constexpr int M = G::M, T = G::T, E = G::E;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const int tid = threadIdx.x;
@@ -563,24 +565,24 @@ k_inv_column(const uint32_t *__restrict__ zpart, uint32_t *__restrict__ yres,
 #pragma unroll
         for (int t = 0; t < 4; t++) z[0][4 * h + t] = acc[t];
     }
-    ntt_inverse<LOGM, 1, LOGE>(z, lds, P.twi, tid, md);
+    ntt_inverse<LOGM, 1, LE>(z, lds, P.twi, tid, md);
 #pragma unroll
     for (int e = 0; e < E; e++) z[0][e] = csub(z[0][e], p);
 
     // y = x^j P - P  (as in k_extprod)
     uint32_t *yb = yres + (((size_t)b * 2 + c) * npr + pi) * M;
     const uint32_t j = ua[(size_t)b * n + k];
-    lds_store<LOGM, 1, LOGE, G::STOP>(z, lds, tid);  // own addresses: the thread's last loads
+    lds_store<LOGM, 1, LE, G::STOP>(z, lds, tid);  // own addresses: the thread's last loads
     SGFHE_SYNC();
     constexpr uint32_t LOWMASK = (1u << G::STOP) - 1u;
     const uint32_t s0 = ((uint32_t)tid - j) & (2 * M - 1);
-    const uint32_t lowswz = swz<LOGE>(s0 & LOWMASK);
+    const uint32_t lowswz = swz<LE>(s0 & LOWMASK);
     const uint32_t h0 = s0 >> G::STOP;
 #pragma unroll
     for (int e = 0; e < E; e++) {
         const uint32_t he = h0 + e;
         const uint32_t hipart = (he & (E - 1)) << G::STOP;
-        const uint32_t addr = hipart ^ lowswz ^ (G::STOP >= 9 ? 0u : swz_bits<LOGE>(hipart));
+        const uint32_t addr = hipart ^ lowswz ^ (G::STOP >= 9 ? 0u : swz_bits<LE>(hipart));
         const uint32_t v = lds[addr];
         const uint32_t vs = (he & E) ? p - v : v;  // x^m = -1
         uint32_t d;
