@@ -66,6 +66,14 @@ const char *sgfhe_version(void);
  * Replaces: the type-level set-up Julia does when `Params(n)` fixes MgModUInt{LargeType, Q}
  * (src/fhe.jl:71-85,102-104) -- here: RNS primes, twiddle tables, CRT and flatten constants. */
 int32_t sgfhe_ctx_create(const sgfhe_params *p, int device, sgfhe_ctx **out);
+/* The same with creation flags.  SGFHE_CTX_RANDOM_FLATTEN sizes the RNS basis for the randomised
+ * flatten (`rng::AbstractRNG` of bootstrap / pack_encrypted_bits, src/utils.jl:198-241), whose
+ * digits are four times larger: Params(1024) then runs on six 29-bit primes instead of five
+ * (about 20 % more work per bootstrap); the other Params(n) have the head-room anyway.  Without
+ * the flag sgfhe_set_random_flatten(enable = 1) fails with SGFHE_ERR_UNSUPPORTED on a ctx whose
+ * primes do not cover it. */
+#define SGFHE_CTX_RANDOM_FLATTEN 1u
+int32_t sgfhe_ctx_create_ex(const sgfhe_params *p, int device, uint32_t flags, sgfhe_ctx **out);
 int32_t sgfhe_ctx_destroy(sgfhe_ctx *ctx);
 const char *sgfhe_last_error_string(const sgfhe_ctx *ctx);
 

@@ -61,6 +61,7 @@ def lib():
     sig = {
         "sgfhe_version": (ctypes.c_char_p, []),
         "sgfhe_ctx_create": (i32, [ctypes.POINTER(SgfheParams), ctypes.c_int, ctypes.POINTER(vp)]),
+        "sgfhe_ctx_create_ex": (i32, [ctypes.POINTER(SgfheParams), ctypes.c_int, u32, ctypes.POINTER(vp)]),
         "sgfhe_ctx_destroy": (i32, [vp]),
         "sgfhe_last_error_string": (ctypes.c_char_p, [vp]),
         "sgfhe_set_chunk": (i32, [vp, u32]),
@@ -93,7 +94,7 @@ def lib():
 
 
 EXPORTED_SYMBOLS = (
-    "sgfhe_version", "sgfhe_ctx_create", "sgfhe_ctx_destroy", "sgfhe_last_error_string",
+    "sgfhe_version", "sgfhe_ctx_create", "sgfhe_ctx_create_ex", "sgfhe_ctx_destroy", "sgfhe_last_error_string",
     "sgfhe_set_chunk", "sgfhe_set_lanes", "sgfhe_set_small_batch_max", "sgfhe_set_random_flatten", "sgfhe_bkey_upload", "sgfhe_bkey_upload_rns2", "sgfhe_bkey_generate",
     "sgfhe_bkey_device_form_bytes", "sgfhe_bkey_export_device_form",
     "sgfhe_bkey_import_device_form", "sgfhe_bootstrap_batch", "sgfhe_bootstrap_batch_device",

@@ -56,6 +56,7 @@ uint32_t bitrev(uint32_t x, int bits) {
     return r;
 }
 inline u128 ld128(const uint64_t *w) { return ((u128)w[1] << 64) | w[0]; }
+inline int32_t centre32(uint32_t x, uint32_t p) { return x > (p - 1) / 2 ? (int32_t)x - (int32_t)p : (int32_t)x; }
 double u128_log2(u128 x) { return log2((double)(uint64_t)(x >> 64) * 18446744073709551616.0 + (double)(uint64_t)x); }
 double u128_dbl(u128 x) { return (double)(uint64_t)(x >> 64) * 18446744073709551616.0 + (double)(uint64_t)x; }
 
@@ -80,11 +81,12 @@ struct sgfhe_ctx {
     PrimeK *d_primes = nullptr;
     CrtConst *d_crt = nullptr;
     uint32_t *d_bad = nullptr;  // set by k_key_transform when a key residue is >= Q
-    uint32_t *d_tw = nullptr;  // npr * 2 * M entries
+    int32_t *d_tw = nullptr;  // npr * 2 * M entries
     CrtConst h_crt;
-    uint32_t pack_G = 1;  // key slices per exact-accumulation group of the packing path
+    uint32_t pack_G = 1, pack_G_rnd = 0;  // key slices per exact-accumulation group of the packing path
+                                          // (deterministic / randomised flatten; 0 = not available)
     // key
-    uint32_t *d_key = nullptr;
+    int32_t *d_key = nullptr;
     size_t key_bytes = 0;
     bool have_key = false;
     // work buffers: two lanes, each sized for `cap` bootstraps
@@ -92,12 +94,13 @@ struct sgfhe_ctx {
     // randomised flatten (rng != nothing, utils.jl:198-241)
     bool rnd = false, rnd_ok = false;
     uint64_t rnd_seed = 0;
-    uint32_t rnd_call = 0;
+    uint32_t rnd_call = 0, last_call = 0;
+    uint32_t create_flags = 0;
     struct Lane {
         uint64_t *dig = nullptr;
         uint32_t *yres = nullptr;
         uint32_t *ua = nullptr;
-        uint32_t *zpart = nullptr;  // small-batch form only: [cap_small][npr][4][2][m]
+        int32_t *zpart = nullptr;  // small-batch form only: [cap_small][npr][4][2][m]
     } lane[2];
     uint32_t small_max = 24;  // chunks of at most this many bootstraps take the small-batch form
                               // (measured crossover at Params(1024): 24 -> 32.3 vs 40.9 ms, 32 -> 44.0 vs 42.3 ms)
@@ -108,7 +111,11 @@ struct sgfhe_ctx {
     double t_ext = 0, t_crt = 0;
     uint64_t n_ext = 0, n_crt = 0;
     uint32_t last_chunk = 0;
+    // kernels whose dynamic-LDS limit has been raised on this ctx's device (hipFuncSetAttribute is
+    // per device; a ctx is bound to one device and used by one host thread)
+    uint32_t attr_done = 0;
 };
+enum : uint32_t { ATTR_EXTPROD = 1u, ATTR_SMALL = 2u, ATTR_SHORTPROD = 4u };
 
 namespace {
 
@@ -137,21 +144,20 @@ template <int LOGM> constexpr int threads_of() { return NttGeom<LOGM, LOGE>::T; 
 #define SGFHE_FOR_LOGM(X) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14)
 
 template <int LOGM>
-int32_t launch_extprod_t(sgfhe_ctx *c, const sgfhe_ctx::Lane &L, const uint32_t *keyk,
+int32_t launch_extprod_t(sgfhe_ctx *c, const sgfhe_ctx::Lane &L, const int32_t *keyk,
                          uint32_t cpad, uint32_t k, uint32_t mode, hipStream_t st) {
     const size_t lds = lds_bytes(LOGM, 2);  // exchange buffer + z1 accumulator
-    static bool attr_done[16] = {};
-    if (!attr_done[c->device & 15]) {
+    if (!(c->attr_done & ATTR_EXTPROD)) {
         HIPCHK(c, hipFuncSetAttribute((const void *)k_extprod<LOGM>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_done[c->device & 15] = true;
+        c->attr_done |= ATTR_EXTPROD;
     }
     hipLaunchKernelGGL(k_extprod<LOGM>, dim3(cpad * c->npr), dim3(threads_of<LOGM>()), lds, st, L.dig,
                        keyk, L.yres, L.ua, c->d_primes, k, c->n, mode);
     HIPCHK(c, hipGetLastError());
     return SGFHE_OK;
 }
-int32_t launch_extprod(sgfhe_ctx *c, const sgfhe_ctx::Lane &L, const uint32_t *keyk, uint32_t cpad,
+int32_t launch_extprod(sgfhe_ctx *c, const sgfhe_ctx::Lane &L, const int32_t *keyk, uint32_t cpad,
                        uint32_t k, uint32_t mode, hipStream_t st) {
     switch (c->logm) {
 #define X(LM) case LM: return launch_extprod_t<LM>(c, L, keyk, cpad, k, mode, st);
@@ -162,19 +168,18 @@ int32_t launch_extprod(sgfhe_ctx *c, const sgfhe_ctx::Lane &L, const uint32_t *k
 }
 
 template <int LOGM>
-int32_t launch_small_t(sgfhe_ctx *c, const sgfhe_ctx::Lane &L, const uint32_t *keyk, uint32_t cpad,
+int32_t launch_small_t(sgfhe_ctx *c, const sgfhe_ctx::Lane &L, const int32_t *keyk, uint32_t cpad,
                        uint32_t k, uint32_t mode, hipStream_t st) {
     // 8 points per thread while m / 8 threads fit a workgroup, else the engine's 16
     constexpr int LE = (LOGM - 3 <= 10 && LOGM >= 9) ? 3 : LOGE;
     constexpr int TH = NttGeom<LOGM, LE>::T;
     const size_t lds = lds_bytes(LOGM, 1);
-    static bool attr_done[16] = {};
-    if (!attr_done[c->device & 15]) {
+    if (!(c->attr_done & ATTR_SMALL)) {
         HIPCHK(c, hipFuncSetAttribute((const void *)k_fwd_phase<LOGM, LE>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIPCHK(c, hipFuncSetAttribute((const void *)k_inv_column<LOGM, LE>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_done[c->device & 15] = true;
+        c->attr_done |= ATTR_SMALL;
     }
     hipLaunchKernelGGL((k_fwd_phase<LOGM, LE>), dim3(cpad * c->npr * 4), dim3(TH), lds, st, L.dig,
                        keyk, L.zpart, c->d_primes, mode);
@@ -183,7 +188,7 @@ int32_t launch_small_t(sgfhe_ctx *c, const sgfhe_ctx::Lane &L, const uint32_t *k
     HIPCHK(c, hipGetLastError());
     return SGFHE_OK;
 }
-int32_t launch_small(sgfhe_ctx *c, const sgfhe_ctx::Lane &L, const uint32_t *keyk, uint32_t cpad,
+int32_t launch_small(sgfhe_ctx *c, const sgfhe_ctx::Lane &L, const int32_t *keyk, uint32_t cpad,
                      uint32_t k, uint32_t mode, hipStream_t st) {
     switch (c->logm) {
 #define X(LM) case LM: return launch_small_t<LM>(c, L, keyk, cpad, k, mode, st);
@@ -195,23 +200,22 @@ int32_t launch_small(sgfhe_ctx *c, const sgfhe_ctx::Lane &L, const uint32_t *key
 
 template <int LOGM>
 int32_t launch_shortprod_t(sgfhe_ctx *c, const uint64_t *pdig, uint32_t *yg, uint32_t count,
-                           uint32_t G, uint32_t groups, hipStream_t st) {
+                           uint32_t G, uint32_t groups, uint32_t mode, hipStream_t st) {
     const size_t lds = lds_bytes(LOGM, 2);
-    static bool attr_done[16] = {};
-    if (!attr_done[c->device & 15]) {
+    if (!(c->attr_done & ATTR_SHORTPROD)) {
         HIPCHK(c, hipFuncSetAttribute((const void *)k_shortprod<LOGM>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_done[c->device & 15] = true;
+        c->attr_done |= ATTR_SHORTPROD;
     }
     hipLaunchKernelGGL(k_shortprod<LOGM>, dim3(count * groups * c->npr), dim3(threads_of<LOGM>()), lds,
-                       st, pdig, c->d_key, yg, c->d_primes, c->d_crt, c->n, G, groups);
+                       st, pdig, c->d_key, yg, c->d_primes, c->d_crt, c->n, G, groups, mode);
     HIPCHK(c, hipGetLastError());
     return SGFHE_OK;
 }
 int32_t launch_shortprod(sgfhe_ctx *c, const uint64_t *pdig, uint32_t *yg, uint32_t count,
-                         uint32_t G, uint32_t groups, hipStream_t st) {
+                         uint32_t G, uint32_t groups, uint32_t mode, hipStream_t st) {
     switch (c->logm) {
-#define X(LM) case LM: return launch_shortprod_t<LM>(c, pdig, yg, count, G, groups, st);
+#define X(LM) case LM: return launch_shortprod_t<LM>(c, pdig, yg, count, G, groups, mode, st);
         SGFHE_FOR_LOGM(X)
 #undef X
     }
@@ -219,7 +223,7 @@ int32_t launch_shortprod(sgfhe_ctx *c, const uint64_t *pdig, uint32_t *yg, uint3
 }
 
 template <int LOGM>
-int32_t launch_keygen_ntt_t(sgfhe_ctx *c, const uint64_t *d_sk, uint32_t *d_shat,
+int32_t launch_keygen_ntt_t(sgfhe_ctx *c, const uint64_t *d_sk, int32_t *d_shat,
                             const ulonglong2 *d_acan, uint32_t *d_y, uint32_t R, bool shat_pass,
                             hipStream_t st) {
     if (shat_pass)
@@ -231,7 +235,7 @@ int32_t launch_keygen_ntt_t(sgfhe_ctx *c, const uint64_t *d_sk, uint32_t *d_shat
     HIPCHK(c, hipGetLastError());
     return SGFHE_OK;
 }
-int32_t launch_keygen_ntt(sgfhe_ctx *c, const uint64_t *d_sk, uint32_t *d_shat,
+int32_t launch_keygen_ntt(sgfhe_ctx *c, const uint64_t *d_sk, int32_t *d_shat,
                           const ulonglong2 *d_acan, uint32_t *d_y, uint32_t R, bool shat_pass,
                           hipStream_t st) {
     switch (c->logm) {
@@ -243,7 +247,7 @@ int32_t launch_keygen_ntt(sgfhe_ctx *c, const uint64_t *d_sk, uint32_t *d_shat,
 }
 
 template <int LOGM>
-int32_t launch_keytr_t(sgfhe_ctx *c, const ulonglong2 *canon, uint32_t *keyhat, uint32_t poly0,
+int32_t launch_keytr_t(sgfhe_ctx *c, const ulonglong2 *canon, int32_t *keyhat, uint32_t poly0,
                        uint32_t npolys, hipStream_t st) {
     hipLaunchKernelGGL(k_key_transform<LOGM>, dim3(npolys * c->npr), dim3(threads_of<LOGM>()),
                        lds_bytes(LOGM, 1), st, canon, keyhat, c->d_primes, c->d_crt, poly0,
@@ -251,7 +255,7 @@ int32_t launch_keytr_t(sgfhe_ctx *c, const ulonglong2 *canon, uint32_t *keyhat, 
     HIPCHK(c, hipGetLastError());
     return SGFHE_OK;
 }
-int32_t launch_keytr(sgfhe_ctx *c, const ulonglong2 *canon, uint32_t *keyhat, uint32_t poly0,
+int32_t launch_keytr(sgfhe_ctx *c, const ulonglong2 *canon, int32_t *keyhat, uint32_t poly0,
                      uint32_t npolys, hipStream_t st) {
     switch (c->logm) {
 #define X(L) case L: return launch_keytr_t<L>(c, canon, keyhat, poly0, npolys, st);
@@ -280,7 +284,7 @@ int32_t launch_dbgntt(sgfhe_ctx *c, const uint32_t *in, uint32_t *out, uint32_t 
 }
 
 // k_crt_acc is compiled once per prime count (its residue loops are unrolled)
-#define SGFHE_FOR_NPR(X) X(2) X(3) X(4) X(5) X(6)
+#define SGFHE_FOR_NPR(X) X(2) X(3) X(4) X(5) X(6) X(7)
 int32_t launch_crt_raw(sgfhe_ctx *c, const uint32_t *yres, uint64_t *dig, uint32_t total,
                        uint32_t mode, hipStream_t st, RndArgs ra, uint32_t iter) {
     switch (c->npr) {
@@ -403,6 +407,7 @@ int32_t bootstrap_device(sgfhe_ctx *c, const uint64_t *a1, const uint64_t *b1, c
     const bool two_lanes = c->lanes == 2 && batch > chunk;
     const uint32_t mode = c->rnd ? MODE_RANDOM : 0u;
     const uint32_t call = c->rnd ? c->rnd_call++ : 0u;
+    c->last_call = call;
     if (two_lanes) {  // fork: the second lane starts after everything already queued on st
         HIPCHK(c, hipEventRecord(c->ev_fork, st));
         HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
@@ -454,48 +459,52 @@ int32_t build_constants(sgfhe_ctx *c) {
     const int logm = c->logm;
     const u128 Q = c->Q, B = c->B;
 
-    // RNS primes: the largest primes below 2^30 with p = 1 mod 2^15 (2 m | p - 1 for every
-    // supported m), as many as the exactness bound needs: |D| <= 2 m B Q must stay below
-    // M_rns / 4 (see k_crt_acc), i.e. 8 m B Q <= M_rns; one more factor 4 if that still fits
-    // the same number of primes or NPR_MAX allows it (randomised flatten, digits up to 2 B).
+    // RNS primes: the largest primes below 2^29 with p = 1 mod 2^15 (2 m | p - 1 for every
+    // supported m), as many as the exactness bound needs.  The exact integer the CRT has to
+    // recover is D = (x^j - 1) sum_row u_row (*) C_row with |u| <= B / 2 (deterministic flatten,
+    // utils.jl:155-189) and the key lifted to |C| <= Q / 2, so |D| <= 2 m B Q; k_crt_acc needs
+    // |D| <= 0.4 M_rns, i.e. 5 m B Q <= M_rns.  The randomised flatten (|u| <= 2 B,
+    // utils.jl:198-241) needs a factor 4 more: it is available when that fits the same number of
+    // primes, or when the ctx was created with SGFHE_CTX_RANDOM_FLATTEN (then one more prime is
+    // taken where necessary: Params(1024) runs on 5 primes deterministic-only, on 6 with the flag).
     uint32_t cand_primes[NPR_MAX];
     {
         int found = 0;
-        for (uint64_t kk = ((1ull << 30) - 1) >> 15; kk > 0 && found < NPR_MAX; kk--) {
+        for (uint64_t kk = ((1ull << 29) - 1) >> 15; kk > 0 && found < NPR_MAX; kk--) {
             uint32_t cand = (uint32_t)((kk << 15) + 1);
-            if (cand < (1u << 30) && is_prime32(cand)) cand_primes[found++] = cand;
+            if (cand < (1u << 29) && is_prime32(cand)) cand_primes[found++] = cand;
         }
         if (found < NPR_MAX) return fail(c, SGFHE_ERR_UNSUPPORTED, "could not find RNS primes");
     }
-    const double log_need = 3.0 + logm + u128_log2(B) + u128_log2(Q) + 0.01;
+    const double log_mbq = logm + u128_log2(B) + u128_log2(Q);
+    const double log_need = log2(5.0) + log_mbq + 0.001;
+    const bool want_rnd = (c->create_flags & SGFHE_CTX_RANDOM_FLATTEN) != 0;
+    const double log_target = log_need + (want_rnd ? 2.0 : 0.0);
     double log_have = 0;
     uint32_t npr = 0;
-    while (npr < NPR_MAX && (npr < 2 || log_have < log_need + 2.0)) {
+    while (npr < NPR_MAX && (npr < 2 || log_have < log_target)) {
         log_have += log2((double)cand_primes[npr]);
         npr++;
     }
-    if (log_have < log_need + 2.0) {  // the randomised mode does not fit: deterministic only
-        npr = 0;
-        log_have = 0;
-        while (npr < NPR_MAX && (npr < 2 || log_have < log_need)) {
-            log_have += log2((double)cand_primes[npr]);
-            npr++;
-        }
-    }
-    if (log_need > log_have)
+    if (log_have < log_target)
         return fail(c, SGFHE_ERR_UNSUPPORTED,
-                    "8 m B Q exceeds the product of the RNS primes (need more primes)");
+                    "5 m B Q (20 m B Q with SGFHE_CTX_RANDOM_FLATTEN) exceeds the product of the RNS primes");
     c->npr = npr;
     for (uint32_t i = 0; i < npr; i++) c->primes[i] = cand_primes[i];
     const int NPR = (int)npr;  // the loops below run over the primes in use
 
     // Packing (fhe.jl:683-687): G slices of two digit polynomials each are summed exactly before a
-    // CRT: |sum| <= G m B Q / 2 must stay below M_rns / 8.
+    // CRT: |sum| <= G m B Q / 2 (four times that with the randomised flatten) must stay below
+    // 0.4 M_rns.
     {
-        const double lg = log_have - (2.0 + logm + u128_log2(B) + u128_log2(Q) + 0.01);
-        uint32_t G = 1;
-        while (G < c->n && (double)(31 - __builtin_clz(2 * G)) <= lg) G *= 2;
-        c->pack_G = G;
+        auto group = [&](double lg) {
+            uint32_t G = 0;
+            if (lg >= 0) { G = 1; while (G < c->n && (double)(31 - __builtin_clz(2 * G)) <= lg) G *= 2; }
+            return G;
+        };
+        const double lg = log_have + log2(0.8) - log_mbq - 0.001;
+        c->pack_G = group(lg);
+        c->pack_G_rnd = group(lg - 2.0);
     }
 
     // flatten constants (utils.jl:162-169)
@@ -548,11 +557,11 @@ int32_t build_constants(sgfhe_ctx *c) {
     limbs(Q, cc.Q32, 3);
     cc.Bd = u128_dbl(B);
 
-    // twiddle tables and per-prime constants
-    std::vector<uint32_t> tw((size_t)NPR * 2 * M);
+    // twiddle tables and per-prime constants (all residues centred: |.| <= (p - 1) / 2)
+    std::vector<int32_t> tw((size_t)NPR * 2 * M);
     std::vector<PrimeK> pk(NPR);
     cc.npr = npr;
-    HIPCHK(c, hipMalloc(&c->d_tw, tw.size() * sizeof(uint32_t)));
+    HIPCHK(c, hipMalloc(&c->d_tw, tw.size() * sizeof(int32_t)));
     for (int i = 0; i < NPR; i++) {
         const uint32_t p = c->primes[i];
         uint32_t psi = 0;
@@ -562,48 +571,49 @@ int32_t build_constants(sgfhe_ctx *c) {
         }
         if (!psi) return fail(c, SGFHE_ERR_UNSUPPORTED, "no primitive 2m-th root of unity");
         const uint32_t ipsi = powmod32(psi, p - 2, p);
-        uint32_t *f = tw.data() + (size_t)(2 * i) * M, *v = f + M;
+        int32_t *f = tw.data() + (size_t)(2 * i) * M, *v = f + M;
         const uint32_t R1m = (uint32_t)((1ull << 32) % p);
         uint32_t pw = 1, ipw = 1;
         for (uint32_t t = 0; t < M; t++) {
             const uint32_t br = bitrev(t, logm);
-            f[br] = mulmod32(pw, R1m, p);   // Montgomery form
-            v[br] = mulmod32(ipw, R1m, p);
+            f[br] = centre32(mulmod32(pw, R1m, p), p);   // Montgomery form
+            v[br] = centre32(mulmod32(ipw, R1m, p), p);
             pw = mulmod32(pw, psi, p);
             ipw = mulmod32(ipw, ipsi, p);
         }
         PrimeK &P = pk[i];
         memset(&P, 0, sizeof P);
-        P.p = p;
+        P.p = (int32_t)p;
         uint32_t inv = p;  // Newton: p^-1 mod 2^32
         for (int it = 0; it < 5; it++) inv *= 2u - p * inv;
-        P.ninv = 0u - inv;
+        P.pinv = inv;
         const uint32_t R1 = (uint32_t)((1ull << 32) % p);
         const uint32_t Rinv = powmod32(R1, p - 2, p);
-        P.r1 = R1;
-        P.r2 = mulmod32(R1, R1, p);
-        P.r3 = mulmod32(P.r2, R1, p);
-        P.sR = p - mulmod32((uint32_t)(s % p), Rinv, p);  // in [1, p]
+        const uint32_t R2 = mulmod32(R1, R1, p);
+        P.r1 = centre32(R1, p);
+        P.r2 = centre32(R2, p);
+        P.r3 = centre32(mulmod32(R2, R1, p), p);
+        P.sR = centre32((p - mulmod32((uint32_t)(s % p), Rinv, p)) % p, p);
         {
             const u128 xmax = (B & 1) ? (B - 1) / 2 * 3 : B / 2 * 3;
-            P.sRr = p - mulmod32((uint32_t)((s + xmax) % p), Rinv, p);
+            P.sRr = centre32((p - mulmod32((uint32_t)((s + xmax) % p), Rinv, p)) % p, p);
         }
         P.hoff = (i == NPR - 1) ? (p - 1) / 2 : 0;
-        P.qmodp = (uint32_t)(Q % p);
+        P.qmodp = centre32((uint32_t)(Q % p), p);
         uint32_t Mi = 1;  // (M_rns / p_i) mod p_i
         for (int j = 0; j < NPR; j++)
             if (j != i) Mi = mulmod32(Mi, c->primes[j] % p, p);
         const uint32_t ei = powmod32(Mi, p - 2, p);
         const uint32_t minv = powmod32(M % p, p - 2, p);
-        const uint32_t kappa = mulmod32(mulmod32(P.r2, minv, p), ei, p);
-        P.kappaR = mulmod32(kappa, R1, p);
-        P.minvR = mulmod32(minv, R1, p);
+        const uint32_t kappa = mulmod32(mulmod32(R2, minv, p), ei, p);
+        P.kappaR = centre32(mulmod32(kappa, R1, p), p);
+        P.minvR = centre32(mulmod32(minv, R1, p), p);
         P.invp = 1.0f / (float)p;
         P.twf = c->d_tw + (size_t)(2 * i) * M;
         P.twi = c->d_tw + (size_t)(2 * i + 1) * M;
         P.npr = npr;
     }
-    HIPCHK(c, hipMemcpy(c->d_tw, tw.data(), tw.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->d_tw, tw.data(), tw.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     HIPCHK(c, hipMalloc(&c->d_primes, NPR * sizeof(PrimeK)));
     HIPCHK(c, hipMemcpy(c->d_primes, pk.data(), NPR * sizeof(PrimeK), hipMemcpyHostToDevice));
     HIPCHK(c, hipMalloc(&c->d_bad, sizeof(uint32_t)));
@@ -611,6 +621,40 @@ int32_t build_constants(sgfhe_ctx *c) {
     HIPCHK(c, hipMalloc(&c->d_crt, sizeof(CrtConst)));
     HIPCHK(c, hipMemcpy(c->d_crt, &cc, sizeof(CrtConst), hipMemcpyHostToDevice));
     return SGFHE_OK;
+}
+
+// Device-form key blob = 64-byte header + payload keyhat[k][prime][row * 2 + col][slot].  The
+// header pins everything the payload's meaning depends on, so a blob made for another parameter
+// set (or by another arithmetic revision of this library) is refused by the import.
+struct KeyBlobHeader {
+    char magic[8];         // "SGFHEKEY"
+    uint32_t version;      // SGFHE_KEY_BLOB_VERSION: layout + residue form of the payload
+    uint32_t n, m, npr;
+    uint64_t Q[2];
+    uint64_t B;
+    uint64_t prime_hash;   // FNV-1a over the RNS primes in use
+    uint64_t payload_bytes;
+};
+static_assert(sizeof(KeyBlobHeader) == 64, "key blob header is 64 bytes");
+constexpr uint32_t SGFHE_KEY_BLOB_VERSION = 2;
+
+KeyBlobHeader blob_header(const sgfhe_ctx *c) {
+    KeyBlobHeader h;
+    memset(&h, 0, sizeof h);
+    memcpy(h.magic, "SGFHEKEY", 8);
+    h.version = SGFHE_KEY_BLOB_VERSION;
+    h.n = c->n;
+    h.m = c->M;
+    h.npr = c->npr;
+    h.Q[0] = (uint64_t)c->Q;
+    h.Q[1] = (uint64_t)(c->Q >> 64);
+    h.B = (uint64_t)c->B;
+    uint64_t f = 0xcbf29ce484222325ull;
+    for (uint32_t i = 0; i < c->npr; i++)
+        for (int b = 0; b < 4; b++) { f ^= (c->primes[i] >> (8 * b)) & 0xffu; f *= 0x100000001b3ull; }
+    h.prime_hash = f;
+    h.payload_bytes = (uint64_t)c->n * c->npr * 8 * c->M * 4;
+    return h;
 }
 
 int32_t key_alloc(sgfhe_ctx *c) {
@@ -621,7 +665,7 @@ int32_t key_alloc(sgfhe_ctx *c) {
 }
 
 // canonical [npolys][m][2 words] in host memory -> NTT-domain key polys poly0.. in keyhat
-int32_t key_transform_host(sgfhe_ctx *c, const uint64_t *canon, uint32_t npolys, uint32_t *keyhat) {
+int32_t key_transform_host(sgfhe_ctx *c, const uint64_t *canon, uint32_t npolys, int32_t *keyhat) {
     const size_t poly_bytes = (size_t)c->M * 16;
     uint32_t stage_polys = (uint32_t)(((size_t)64 << 20) / poly_bytes);
     if (stage_polys < 8) stage_polys = 8;
@@ -658,8 +702,13 @@ const char *sgfhe_last_error_string(const sgfhe_ctx *ctx) {
 }
 
 int32_t sgfhe_ctx_create(const sgfhe_params *p, int device, sgfhe_ctx **out) {
+    return sgfhe_ctx_create_ex(p, device, 0u, out);
+}
+
+int32_t sgfhe_ctx_create_ex(const sgfhe_params *p, int device, uint32_t flags, sgfhe_ctx **out) {
     if (!p || !out) return SGFHE_ERR_INVALID_ARG;
     *out = nullptr;
+    if (flags & ~(uint32_t)SGFHE_CTX_RANDOM_FLATTEN) return SGFHE_ERR_INVALID_ARG;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev)
         return SGFHE_ERR_NO_DEVICE;
@@ -669,13 +718,15 @@ int32_t sgfhe_ctx_create(const sgfhe_params *p, int device, sgfhe_ctx **out) {
     *out = c;  // returned even on failure so that the caller can read the error string
     c->par = *p;
     c->device = device;
+    c->create_flags = flags;
     const uint64_t m = p->m;
     if (p->ell != 2) return fail(c, SGFHE_ERR_UNSUPPORTED, "ell must be 2 (fhe.jl:576)");
     if (m < 64 || m > 16384 || (m & (m - 1)))
         return fail(c, SGFHE_ERR_UNSUPPORTED, "m must be a power of two in [2^6, 2^14]");
     if (p->r != 2 * m) return fail(c, SGFHE_ERR_INVALID_ARG, "r must equal 2 m (fhe.jl:62)");
-    if (p->n == 0 || p->n > m / 4)
-        return fail(c, SGFHE_ERR_INVALID_ARG, "n must be in [1, m / 4] (extract, fhe.jl:585-590)");
+    if (p->n == 0 || p->n > m / 4 || (p->n & (p->n - 1)))
+        return fail(c, SGFHE_ERR_INVALID_ARG,
+                    "n must be a power of two in [1, m / 4] (fhe.jl:45-46; extract, fhe.jl:585-590)");
     c->M = (uint32_t)m;
     c->n = (uint32_t)p->n;
     while ((1u << c->logm) < c->M) c->logm++;
@@ -732,7 +783,8 @@ int32_t sgfhe_set_random_flatten(sgfhe_ctx *c, int enable, uint64_t seed) {
     if (!c) return SGFHE_ERR_INVALID_ARG;
     if (enable && !c->rnd_ok)
         return fail(c, SGFHE_ERR_UNSUPPORTED,
-                    "randomised flatten: 32 m B Q exceeds the product of the RNS primes");
+                    "randomised flatten: 20 m B Q exceeds the product of this ctx's RNS primes (or B >= 2^46); "
+                    "create the ctx with sgfhe_ctx_create_ex(..., SGFHE_CTX_RANDOM_FLATTEN, ...)");
     c->rnd = enable != 0;
     c->rnd_seed = seed;
     c->rnd_call = 0;
@@ -789,7 +841,8 @@ int32_t sgfhe_bkey_generate(sgfhe_ctx *c, const uint64_t *sk, size_t n_sk, uint6
     uint32_t R = 64;  // rows per batch (16 key slices)
     if (R > rows) R = rows;
     uint64_t *d_sk = nullptr;
-    uint32_t *d_shat = nullptr, *d_y = nullptr;
+    int32_t *d_shat = nullptr;
+    uint32_t *d_y = nullptr;
     ulonglong2 *d_acan = nullptr, *d_prod = nullptr, *d_canon = nullptr;
     int32_t *d_e = nullptr;
     hipError_t e = hipSuccess;
@@ -868,7 +921,7 @@ int32_t sgfhe_bkey_upload_rns2(sgfhe_ctx *c, const uint64_t *pairs, size_t n_wor
 
 int32_t sgfhe_bkey_device_form_bytes(const sgfhe_ctx *c, size_t *bytes) {
     if (!c || !bytes) return SGFHE_ERR_INVALID_ARG;
-    *bytes = (size_t)c->n * c->npr * 8 * c->M * 4;
+    *bytes = sizeof(KeyBlobHeader) + (size_t)c->n * c->npr * 8 * c->M * 4;
     return SGFHE_OK;
 }
 
@@ -876,7 +929,10 @@ int32_t sgfhe_bkey_export_device_form(sgfhe_ctx *c, void *dst) {
     if (!c || !dst) return SGFHE_ERR_INVALID_ARG;
     if (!c->have_key) return fail(c, SGFHE_ERR_NO_KEY, "no bootstrap key uploaded");
     (void)hipSetDevice(c->device);
-    HIPCHK(c, hipMemcpyAsync(dst, c->d_key, c->key_bytes, hipMemcpyDeviceToDevice, c->stream));
+    const KeyBlobHeader h = blob_header(c);
+    HIPCHK(c, hipMemcpy(dst, &h, sizeof h, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpyAsync(static_cast<char *>(dst) + sizeof h, c->d_key, c->key_bytes,
+                             hipMemcpyDeviceToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return SGFHE_OK;
 }
@@ -884,9 +940,20 @@ int32_t sgfhe_bkey_export_device_form(sgfhe_ctx *c, void *dst) {
 int32_t sgfhe_bkey_import_device_form(sgfhe_ctx *c, const void *src) {
     if (!c || !src) return SGFHE_ERR_INVALID_ARG;
     (void)hipSetDevice(c->device);
+    KeyBlobHeader got;
+    HIPCHK(c, hipMemcpy(&got, src, sizeof got, hipMemcpyDeviceToHost));
+    const KeyBlobHeader want = blob_header(c);
+    if (memcmp(got.magic, want.magic, sizeof want.magic) != 0)
+        return fail(c, SGFHE_ERR_INVALID_ARG, "bkey_import: not a device-form key blob (bad magic)");
+    if (got.version != want.version)
+        return fail(c, SGFHE_ERR_INVALID_ARG, "bkey_import: blob format version differs from this library");
+    if (memcmp(&got, &want, sizeof want) != 0)
+        return fail(c, SGFHE_ERR_INVALID_ARG,
+                    "bkey_import: the blob belongs to another parameter set (n, m, Q, B or RNS primes differ)");
     int32_t rc = key_alloc(c);
     if (rc) return rc;
-    HIPCHK(c, hipMemcpyAsync(c->d_key, src, c->key_bytes, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_key, static_cast<const char *>(src) + sizeof got, c->key_bytes,
+                             hipMemcpyDeviceToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->have_key = true;
     return SGFHE_OK;
@@ -973,7 +1040,7 @@ int32_t sgfhe_external_product(sgfhe_ctx *c, const uint64_t *a, const uint64_t *
     int32_t rc = ensure_work(c, cpad);
     if (rc) return rc;
     const sgfhe_ctx::Lane &L = c->lane[0];
-    uint32_t *d_A = nullptr;
+    int32_t *d_A = nullptr;
     ulonglong2 *d_ab = nullptr;
     HIPCHK(c, hipMalloc(&d_A, (size_t)c->npr * 8 * M * 4));
     hipError_t e = hipMalloc(&d_ab, (size_t)2 * M * 16);
@@ -1009,7 +1076,13 @@ int32_t sgfhe_pack_encrypted_bits(sgfhe_ctx *c, const uint64_t *a, const uint64_
     (void)hipSetDevice(c->device);
     const size_t n = c->n, M = c->M;
     const size_t nb = count * n;  // bootstraps
-    const uint32_t G = c->pack_G, groups = (uint32_t)(n / G);
+    // rng != nothing: the n bootstraps and the flatten of every as_i (all m coefficients of the
+    // resized polynomial, utils.jl:253-264) draw from the ctx's Philox stream (fhe.jl:673,683-684)
+    const uint32_t mode = c->rnd ? MODE_RANDOM : 0u;
+    const uint32_t G = c->rnd ? c->pack_G_rnd : c->pack_G;
+    if (!G) return fail(c, SGFHE_ERR_UNSUPPORTED, "pack_encrypted_bits: exactness bound of the RNS primes");
+    const uint32_t groups = (uint32_t)(n / G);
+    const size_t len = c->rnd ? M : n;  // stored coefficients per digit polynomial
     uint64_t *d_lwe = nullptr, *d_pdig = nullptr, *d_wv = nullptr;
     ulonglong2 *d_raw = nullptr;
     uint32_t *d_yg = nullptr;
@@ -1020,7 +1093,7 @@ int32_t sgfhe_pack_encrypted_bits(sgfhe_ctx *c, const uint64_t *a, const uint64_
         if ((e = hipMalloc(&d_lwe, (2 * nb * n + 2 * nb) * 8))) break;
         uint64_t *d_a1 = d_lwe, *d_a2 = d_lwe + nb * n, *d_b1 = d_a2 + nb * n, *d_b2 = d_b1 + nb;
         if ((e = hipMalloc(&d_raw, nb * 3 * (n + 1) * 16))) break;
-        if ((e = hipMalloc(&d_pdig, count * n * 2 * n * 8))) break;
+        if ((e = hipMalloc(&d_pdig, count * n * 2 * len * 8))) break;
         if ((e = hipMalloc(&d_yg, count * groups * 2 * c->npr * M * 4))) break;
         if ((e = hipMalloc(&d_wv, 2 * count * M * 8))) break;
         if ((e = hipMemsetAsync(d_a1, 0, nb * n * 8, c->stream))) break;
@@ -1028,16 +1101,15 @@ int32_t sgfhe_pack_encrypted_bits(sgfhe_ctx *c, const uint64_t *a, const uint64_
         if ((e = hipMemcpyAsync(d_b1, ones.data(), nb * 8, hipMemcpyHostToDevice, c->stream))) break;
         if ((e = hipMemcpyAsync(d_a2, a, nb * n * 8, hipMemcpyHostToDevice, c->stream))) break;
         if ((e = hipMemcpyAsync(d_b2, b, nb * 8, hipMemcpyHostToDevice, c->stream))) break;
-        const bool rnd_saved = c->rnd;  // packing is deterministic whatever the bootstrap mode
-        c->rnd = false;
         rc = bootstrap_device(c, d_a1, d_b1, d_a2, d_b2, nb, (uint64_t *)d_raw, SGFHE_FLAG_RAW_MODQ,
                               c->n, nullptr, c->stream);
-        c->rnd = rnd_saved;
         if (rc) break;
-        const size_t tf = count * n * n;
+        const RndArgs ra = {(uint32_t)c->rnd_seed, (uint32_t)(c->rnd_seed >> 32), c->last_call, 0u};
+        const size_t tf = count * n * len;
         hipLaunchKernelGGL(k_pack_flatten, dim3((unsigned)((tf + 255) / 256)), dim3(256), 0, c->stream,
-                           d_raw, d_pdig, c->d_crt, (uint32_t)count, (uint32_t)n);
-        rc = launch_shortprod(c, d_pdig, d_yg, (uint32_t)count, G, groups, c->stream);
+                           d_raw, d_pdig, c->d_crt, (uint32_t)count, (uint32_t)n, (uint32_t)c->logm,
+                           mode, ra);
+        rc = launch_shortprod(c, d_pdig, d_yg, (uint32_t)count, G, groups, mode, c->stream);
         if (rc) break;
         const size_t tw = count * M;
         switch (c->npr) {

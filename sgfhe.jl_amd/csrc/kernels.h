@@ -20,28 +20,29 @@ namespace sgfhe {
 
 typedef unsigned __int128 u128;
 
-constexpr int NPR_MAX = 6;  // at most this many RNS primes (p_i < 2^30); a ctx uses the fewest whose
-                            // product covers 8 m B Q (4 at Params(64), 5 at Params(512/1024))
+constexpr int NPR_MAX = 7;  // at most this many RNS primes (p_i < 2^29); a ctx uses the fewest whose
+                            // product covers 5 m B Q (4 at Params(64), 5 at Params(512/1024))
 #ifndef SGFHE_LOGE
 #define SGFHE_LOGE 4
 #endif
 constexpr int LOGE = SGFHE_LOGE;  // points per thread (2^LOGE) in every NTT of the engine
 
 struct PrimeK {
-    uint32_t p;       // prime
-    uint32_t ninv;    // -p^-1 mod 2^32
-    uint32_t sR;      // p - (s * R^-1 mod p) (digit offset s of utils.jl:162-166, R = 2^32)
-    uint32_t sRr;     // the same for the randomised flatten: offset s + xmax (utils.jl:198-241)
+    int32_t p;        // prime, < 2^29
+    uint32_t pinv;    // p^-1 mod 2^32
+    int32_t sR;       // -(s R^-1) mod p, centred (digit offset s of utils.jl:162-166, R = 2^32)
+    int32_t sRr;      // the same for the randomised flatten: offset s + xmax (utils.jl:198-241)
     uint32_t hoff;    // offset added to the output residue: (p-1)/2 for the last prime, else 0
-    uint32_t r1, r2, r3;  // R, R^2, R^3 mod p
-    uint32_t qmodp;   // Q mod p
-    uint32_t kappaR;  // key scale kappa * R mod p, kappa = R^2 m^-1 (M/p)^-1 mod p
-    uint32_t minvR;   // m^-1 * R mod p (debug inverse NTT scaling)
+    int32_t r1, r2, r3;  // R, R^2, R^3 mod p, centred
+    int32_t qmodp;    // Q mod p, centred
+    int32_t kappaR;   // key scale kappa * R mod p (centred), kappa = R^2 m^-1 (M/p)^-1 mod p
+    int32_t minvR;    // m^-1 * R mod p, centred (debug inverse NTT scaling)
     float invp;       // 1 / p
-    const uint32_t *twf;  // forward twiddles psi^bitrev(i) * R mod p (Montgomery form)
-    const uint32_t *twi;  // inverse twiddles psi^-bitrev(i) * R mod p
+    const int32_t *twf;  // forward twiddles psi^bitrev(i) * R mod p (Montgomery form, centred)
+    const int32_t *twi;  // inverse twiddles psi^-bitrev(i) * R mod p
     uint32_t npr;     // number of primes of the ctx (the same in every record)
 };
+__device__ __forceinline__ Mod mod_of(const PrimeK &P) { return Mod{P.p, -P.p, P.pinv}; }
 
 // The npr PrimeK records live in device memory and are indexed by the (wave-uniform) prime
 // index of the workgroup.
@@ -145,9 +146,18 @@ __device__ __forceinline__ void store_digits(uint64_t *__restrict__ dig, size_t 
 // ---- randomised flatten (utils.jl:198-241) ----------------------------------------------------------
 // Philox4x32-10 counter-based generator: (counter, key) -> 128 random bits.  Functional parity
 // only: the reference draws from Julia's MersenneTwister, which is not reproducible here.
+// The draw for a digit pair is addressed by a counter that does not depend on how a batch is cut
+// into chunks or scheduled:
+//   counter = (x: coefficient index (c << log2 m) + i of the accumulator pair (c = 0: a, 1: b),
+//              y: 0 for the initial accumulators, k + 1 after k-loop iteration k
+//                 (pack_encrypted_bits' flatten of as_i: 2^31 | i),
+//              z: index of the bootstrap within the call (of the ciphertext, for packing),
+//              w: number of the call since sgfhe_set_random_flatten),   key = seed.
+// oracle/bigint_oracle.py restates the same stream, so the randomised mode is bit-comparable with
+// the oracle (not with Julia's MersenneTwister, which cannot be reproduced here).
 struct RndArgs {
     uint32_t key0, key1;   // seed
-    uint32_t call, chunk;  // per-call counter, first bootstrap of the chunk
+    uint32_t call, chunk;  // per-call counter, index of the chunk's first bootstrap in the call
 };
 __device__ __forceinline__ uint4 philox4x32(uint4 c, uint32_t k0, uint32_t k1) {
 #pragma unroll
@@ -164,8 +174,8 @@ __device__ __forceinline__ uint4 philox4x32(uint4 c, uint32_t k0, uint32_t k1) {
 //   r_i = v_i + xmax uniform in [0, 2 xmax];  x2 = (xn - r_0 - r_1 B) mod Q = a' of utils.jl:179
 //   for the shifted value;  (lo, hi) = divmod(x2, B);  e_i = (lo, hi) + r_i  ( = u_i + s + xmax ).
 __device__ __forceinline__ ulonglong2 random_digits(u128 xn, const CrtConst *CC, const RndArgs &ra,
-                                                    uint32_t t, uint32_t iter) {
-    const uint4 rv = philox4x32(make_uint4(t, iter, ra.chunk, ra.call), ra.key0, ra.key1);
+                                                    uint4 ctr) {
+    const uint4 rv = philox4x32(ctr, ra.key0, ra.key1);
     const uint64_t span = 2 * CC->xmax + 1;
     const uint64_t r0 = (uint64_t)(((u128)(((uint64_t)rv.y << 32) | rv.x) * span) >> 64);
     const uint64_t r1 = (uint64_t)(((u128)(((uint64_t)rv.w << 32) | rv.z) * span) >> 64);
@@ -178,13 +188,10 @@ __device__ __forceinline__ ulonglong2 random_digits(u128 xn, const CrtConst *CC,
 }
 
 // ---- digit -> residue ------------------------------------------------------------------------
-// (e - s) * R^-1 mod p, lazily in [0, 4p), for a stored digit e < 2^48:
-// REDC(e) < e / 2^32 + p < 2^16 + p, plus the constant p - s R^-1.
-__device__ __forceinline__ uint32_t digit_reduce(uint64_t e, const PrimeK &P, uint32_t sR) {
-    return redc_mad(e, P.p, P.ninv) + sR;
-}
-__device__ __forceinline__ uint32_t digit_reduce(uint64_t e, const PrimeK &P) {
-    return digit_reduce(e, P, P.sR);
+// (e - s) * R^-1 mod p for a stored digit e < 2^48: |REDC(e)| <= 2^16 + p / 2, plus the centred
+// constant -(s R^-1): |result| <= p + 2^16.
+__device__ __forceinline__ int32_t digit_reduce(uint64_t e, const Mod &md, int32_t sR) {
+    return sredc((int64_t)e, md) + sR;
 }
 
 // ---- k_extprod ----------------------------------------------------------------------------------
@@ -196,21 +203,22 @@ __device__ __forceinline__ uint32_t digit_reduce(uint64_t e, const PrimeK &P) {
 // product polynomial): two workgroups share a CU, so one computes butterflies while the other
 // sits in an LDS exchange, a barrier or a load.
 //   dig    [chunk][2][2][m]     digit planes (see above)
-//   keyk   [NPR][4][2][m]       NTT-domain key slice of iteration k (slot order, scaled by kappa)
-//   yres   [chunk][2][NPR][m]   output residues y_i = (M/p_i)^-1 * D mod p_i (+ hoff)
+//   keyk   [NPR][4][2][m]       NTT-domain key slice of iteration k (slot order, scaled by kappa,
+//                               centred residues as int32)
+//   yres   [chunk][2][NPR][m]   output residues y_i = (M/p_i)^-1 * D mod p_i (+ hoff), in [0, p_i)
 //   ua     [chunk][n]           j = u.a[k] of every bootstrap (fhe.jl:566,580)
 // The four digit polynomials u = [a_lo, a_hi, b_lo, b_hi] (fhe.jl:524-526) go through the forward
 // NTT one at a time (phase = key row); the two product polynomials through the inverse NTT one at
 // a time.  The running NTT-domain sum z_0 lives in registers, z_1 in LDS.
 template <int LOGM>
 __global__ void __launch_bounds__((NttGeom<LOGM, LOGE>::T), (NttGeom<LOGM, LOGE>::T >= 256 ? 4 : 1))
-k_extprod(const uint64_t *__restrict__ dig, const uint32_t *__restrict__ keyk,
+k_extprod(const uint64_t *__restrict__ dig, const int32_t *__restrict__ keyk,
           uint32_t *__restrict__ yres, const uint32_t *__restrict__ ua, PrimeSet PS, uint32_t k,
           uint32_t n, uint32_t mode) {
     using G = NttGeom<LOGM, LOGE>;
     constexpr int M = G::M, T = G::T, E = G::E;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-    uint32_t *const z1 = lds + M + threadIdx.x;  // z1[e * T]: private to the thread, conflict-free
+    int32_t *const z1 = reinterpret_cast<int32_t *>(lds) + M + threadIdx.x;  // z1[e * T]: private to the thread, conflict-free
 
     const int tid = threadIdx.x;
     const uint32_t g = blockIdx.x;
@@ -219,11 +227,10 @@ k_extprod(const uint64_t *__restrict__ dig, const uint32_t *__restrict__ keyk,
     const uint32_t b = (slot / npr) * 8 + (g & 7);
     const uint32_t pi = slot % npr;
     const PrimeK P = PS[pi];
-    const uint32_t p = P.p;
-    const Mod md = {P.p, P.ninv, 2 * P.p};
+    const Mod md = mod_of(P);
 
-    const uint32_t sRd = (mode & MODE_RANDOM) ? P.sRr : P.sR;  // digit offset of the flatten mode
-    uint64_t acc0[E];  // 64-bit NTT-domain sum of column 0 over the four phases (< 8 p^2 < 2^63)
+    const int32_t sRd = (mode & MODE_RANDOM) ? P.sRr : P.sR;  // digit offset of the flatten mode
+    int64_t acc0[E];  // 64-bit NTT-domain sum of column 0 over the four phases (|.| < 2^61)
 #pragma unroll
     for (int e = 0; e < E; e++) { acc0[e] = 0; z1[e * T] = 0; }
     // A real loop (not unrolled): one copy of the forward NTT in the instruction stream, and the
@@ -238,15 +245,15 @@ k_extprod(const uint64_t *__restrict__ dig, const uint32_t *__restrict__ keyk,
         // twiddle addresses derived from it are hoisted out of the loop and spilled.
         const int tid = (int)threadIdx.x + (int)opaque_zero();
         // 1. digits -> residues (flatten_poly, utils.jl:253-264, lifted to signed integers)
-        uint32_t x[1][E];
+        int32_t x[1][E];
         const uint32_t *dl = digit_lo_plane(dig, (size_t)b * 2 + (ph >> 1), M) + (ph & 1) * M;
         const uint16_t *dh = digit_hi_plane(dig, (size_t)b * 2 + (ph >> 1), M) + (ph & 1) * M;
 #pragma unroll
         for (int e = 0; e < E; e++)
 #ifdef SGFHE_ABL_NO_DIG
-            x[0][e] = digit_reduce((uint64_t)(tid + e) * 0x9E3779B97F4Aull, P);  // timing-only build
+            x[0][e] = digit_reduce((uint64_t)(tid + e) * 0x9E3779B97F4Aull, md, sRd);  // timing-only build
 #else
-            x[0][e] = digit_reduce(dl[tid + T * e] | ((uint64_t)dh[tid + T * e] << 32), P, sRd);
+            x[0][e] = digit_reduce(dl[tid + T * e] | ((uint64_t)dh[tid + T * e] << 32), md, sRd);
 #endif
         // the exchange buffer is reused: every wave must have finished the previous phase's loads
         SGFHE_SYNC();
@@ -255,16 +262,16 @@ k_extprod(const uint64_t *__restrict__ dig, const uint32_t *__restrict__ keyk,
         //    before the last pass of the transform, so they have arrived (from L2) when the
         //    products start; at smaller m the extra live registers cost more than the wait.
         constexpr bool KEY_EARLY = LOGM >= 13;
-        const uint32_t *kp = keyk + ((size_t)pi * 8 + ph * 2) * M + E * tid;
-        uint4 ka4[E / 4], kb4[E / 4];
+        const int32_t *kp = keyk + ((size_t)pi * 8 + ph * 2) * M + E * tid;
+        int4 ka4[E / 4], kb4[E / 4];
         auto load_key = [&]() {
 #pragma unroll
             for (int h = 0; h < E / 4; h++) {
 #ifdef SGFHE_ABL_NO_KEY
-                ka4[h] = make_uint4(tid, h, ph, 7u), kb4[h] = make_uint4(h, tid, 5u, ph);  // timing-only
+                ka4[h] = make_int4(tid, h, ph, 7), kb4[h] = make_int4(h, tid, 5, ph);  // timing-only
 #else
-                ka4[h] = reinterpret_cast<const uint4 *>(kp)[h];
-                kb4[h] = reinterpret_cast<const uint4 *>(kp + M)[h];
+                ka4[h] = reinterpret_cast<const int4 *>(kp)[h];
+                kb4[h] = reinterpret_cast<const int4 *>(kp + M)[h];
 #endif
             }
         };
@@ -275,42 +282,36 @@ k_extprod(const uint64_t *__restrict__ dig, const uint32_t *__restrict__ keyk,
             load_key();
         }
 
-        // 3. pointwise: z_c += U * K[ph][c]   (fhe.jl:527-528 in the NTT domain), U in [0, 2p)
-        //    column 0: 64-bit multiply-accumulate, reduced once after the loop
-        //    column 1: Montgomery-reduced and added lazily (mod 2p) to the LDS accumulator
+        // 3. pointwise: z_c += U * K[ph][c]   (fhe.jl:527-528 in the NTT domain), |U| < 3.5 * 2^29,
+        //    |K| <= p / 2
+        //    column 0: 64-bit multiply-accumulate (v_mad_i64_i32), reduced once after the loop
+        //    column 1: Montgomery-reduced (|.| < 0.72 * 2^29) and added to the LDS accumulator
 #pragma unroll
         for (int h = 0; h < E / 4; h++) {
-            const uint4 a = ka4[h], bq = kb4[h];
-            const uint32_t ka[4] = {a.x, a.y, a.z, a.w};
-            const uint32_t kb[4] = {bq.x, bq.y, bq.z, bq.w};
+            const int4 a = ka4[h], bq = kb4[h];
+            const int32_t ka[4] = {a.x, a.y, a.z, a.w};
+            const int32_t kb[4] = {bq.x, bq.y, bq.z, bq.w};
 #pragma unroll
             for (int t = 0; t < 4; t++) {
                 const int e = 4 * h + t;
-                const uint32_t u = condsub(x[0][e], md.p2);
-                acc0[e] += (uint64_t)u * ka[t];
-                const uint32_t r1 = redc_mad((uint64_t)u * kb[t], p, P.ninv);  // [0, 2p)
-                uint32_t *zp = lds + M + e * T + tid;
-                const uint32_t s1 = *zp + r1;
-                *zp = condsub(s1, md.p2);
+                const int32_t u = x[0][e];
+                acc0[e] += (int64_t)u * ka[t];
+                int32_t *zp = reinterpret_cast<int32_t *>(lds) + M + e * T + tid;
+                *zp += smont(u, kb[t], md);
             }
         }
     }
     // 4. inverse NTT of both columns at once (same twiddles, one set of exchanges; the second
     //    exchange buffer is the LDS area that held z_1):
     //    P_c = (M/p)^-1 * sum_row u_row (*) C_row[c]  mod p
-    uint32_t z[2][E];
+    int32_t z[2][E];
 #pragma unroll
     for (int e = 0; e < E; e++) {
-        const uint32_t r = redc_mad(acc0[e], p, P.ninv);  // [0, 3p)
-        z[0][e] = condsub(r, md.p2);                      // [0, 2p)
-        z[1][e] = z1[e * T];
+        z[0][e] = sred(sredc(acc0[e], md), md);  // |REDC| < 1.4 * 2^29
+        z[1][e] = sred(z1[e * T], md);           // four phases: < 2.9 * 2^29
     }
     SGFHE_SYNC();  // every thread has taken its z_1 out of the buffer the exchanges now reuse
-    ntt_inverse<LOGM, 2, LOGE>(z, lds, P.twi, tid, md);
-#pragma unroll
-    for (int c = 0; c < 2; c++)
-#pragma unroll
-        for (int e = 0; e < E; e++) z[c][e] = csub(z[c][e], p);
+    ntt_inverse<LOGM, 2, LOGE>(z, lds, P.twi, tid, md);  // |z| < 1.4 * 2^29
 
     uint32_t *yb = yres + ((size_t)b * 2 * npr + pi) * M;
     // 5. y = x^j P - P  (mul_by_xj_minus_one, fhe.jl:554-556, applied to the product)
@@ -319,15 +320,14 @@ k_extprod(const uint64_t *__restrict__ dig, const uint32_t *__restrict__ keyk,
         for (int c = 0; c < 2; c++)
 #pragma unroll
             for (int e = 0; e < E; e++)
-                yb[(size_t)c * npr * M + tid + T * e] = csub(z[c][e] + P.hoff, p);
+                yb[(size_t)c * npr * M + tid + T * e] = condsub(sfull(z[c][e], md) + P.hoff, (uint32_t)P.p);
         return;
     }
     const uint32_t j = ua[(size_t)b * n + k];
     lds_store<LOGM, 2, LOGE, G::STOP>(z, lds, tid);
     SGFHE_SYNC();
     // Source index of output coefficient i = tid + T e is s_e = (i - j) mod 2m = s_0 + T e:
-    // the swizzled low part is computed once per thread.  Residues leave in [0, p]
-    // (p == 0 mod p: k_crt_acc's alpha estimate absorbs it exactly).
+    // the swizzled low part is computed once per thread.  Residues leave in [0, p).
     {
         constexpr uint32_t LOWMASK = (1u << G::STOP) - 1u;
         const uint32_t s0 = ((uint32_t)tid - j) & (2 * M - 1);
@@ -341,12 +341,10 @@ k_extprod(const uint64_t *__restrict__ dig, const uint32_t *__restrict__ keyk,
             const uint32_t addr = hipart ^ lowswz ^ (G::STOP >= 9 ? 0u : swz_bits<LOGE>(hipart));
 #pragma unroll
             for (int c = 0; c < 2; c++) {
-                const uint32_t v = lds[c * M + addr];
-                const uint32_t vs = (he & E) ? p - v : v;  // x^m = -1
-                uint32_t d;
-                const bool borrow = __builtin_usub_overflow(vs, z[c][e], &d);
-                uint32_t y = borrow ? d + p : d;           // [0, p]
-                if (P.hoff) y = condsub(y + P.hoff, p);    // wave-uniform: only the last prime
+                const int32_t v = (int32_t)lds[c * M + addr];
+                const int32_t vs = (he & E) ? -v : v;  // x^m = -1
+                uint32_t y = sfull(vs - z[c][e], md);  // |vs - z| < 2.8 * 2^29 -> [0, p)
+                if (P.hoff) y = condsub(y + P.hoff, (uint32_t)P.p);  // wave-uniform: only the last prime
                 // streamed out: the residues are not read again by this launch, so they should
                 // not displace the digit planes the other prime-workgroups still want from L2
                 __builtin_nontemporal_store(y, &yb[(size_t)c * npr * M + tid + T * e]);
@@ -358,9 +356,8 @@ k_extprod(const uint64_t *__restrict__ dig, const uint32_t *__restrict__ keyk,
 // ---- k_crt_acc --------------------------------------------------------------------------------
 // One thread per (bootstrap, c, coefficient).  With y'_i = (D + H') (M/p_i)^-1 mod p_i:
 //   D + H' = sum_i y'_i (M/p_i) - alpha M,  alpha = floor(sum_i y'_i / p_i)
-// and |D| <= M / 8 (checked at ctx creation) puts the fractional part of the sum within
-// 0.5 +- 0.125, so alpha is exact in float (residues may be p_i instead of 0: the identity holds
-// for any non-negative representatives).  Then x'_new = (x'_old + D) mod Q and the new digits are
+// and |D| <= 0.4 M (5 m B Q <= M is checked at ctx creation) puts the fractional part of the sum
+// within 0.5 +- 0.4, so alpha is exact in float (the estimate is off by < 10^-6).  Then x'_new = (x'_old + D) mod Q and the new digits are
 // (x'_new mod B, x'_new / B)  (flatten, utils.jl:155-189).
 //
 // Arithmetic: S = sum_i y'_i c_i + T[alpha] + x'_old < 2^33 Q.  Its quotient by Q is estimated in
@@ -463,7 +460,8 @@ k_crt_acc(const uint32_t *__restrict__ yres, uint64_t *__restrict__ dig,
         return;
     }
     if (mode & MODE_RANDOM) {
-        const ulonglong2 e = random_digits(((u128)a.w2 << 64) | xlo, CC, ra, t, iter);
+        const uint4 ctr = make_uint4(((bc & 1u) << logm) + i, iter, ra.chunk + (bc >> 1), ra.call);
+        const ulonglong2 e = random_digits(((u128)a.w2 << 64) | xlo, CC, ra, ctr);
         store_digits(dig, bc, i, M, e.x, e.y);
         return;
     }
@@ -491,8 +489,8 @@ k_crt_acc(const uint32_t *__restrict__ yres, uint64_t *__restrict__ dig,
 // each transform); the slot order of a transform does not depend on the points per thread.
 template <int LOGM, int LE>
 __global__ void __launch_bounds__((NttGeom<LOGM, LE>::T), (NttGeom<LOGM, LE>::T >= 256 ? 4 : 1))
-k_fwd_phase(const uint64_t *__restrict__ dig, const uint32_t *__restrict__ keyk,
-            uint32_t *__restrict__ zpart, PrimeSet PS, uint32_t mode) {
+k_fwd_phase(const uint64_t *__restrict__ dig, const int32_t *__restrict__ keyk,
+            int32_t *__restrict__ zpart, PrimeSet PS, uint32_t mode) {
     using G = NttGeom<LOGM, LE>;
     constexpr int M = G::M, T = G::T, E = G::E;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
@@ -502,41 +500,40 @@ k_fwd_phase(const uint64_t *__restrict__ dig, const uint32_t *__restrict__ keyk,
     const uint32_t pi = (blockIdx.x >> 2) % npr;
     const uint32_t b = (blockIdx.x >> 2) / npr;
     const PrimeK P = PS[pi];
-    const uint32_t p = P.p;
-    const Mod md = {P.p, P.ninv, 2 * P.p};
-    const uint32_t sRd = (mode & MODE_RANDOM) ? P.sRr : P.sR;
+    const Mod md = mod_of(P);
+    const int32_t sRd = (mode & MODE_RANDOM) ? P.sRr : P.sR;
 
-    uint32_t x[1][E];
+    int32_t x[1][E];
     const uint32_t *dl = digit_lo_plane(dig, (size_t)b * 2 + (ph >> 1), M) + (ph & 1) * M;
     const uint16_t *dh = digit_hi_plane(dig, (size_t)b * 2 + (ph >> 1), M) + (ph & 1) * M;
 #pragma unroll
     for (int e = 0; e < E; e++)
-        x[0][e] = digit_reduce(dl[tid + T * e] | ((uint64_t)dh[tid + T * e] << 32), P, sRd);
+        x[0][e] = digit_reduce(dl[tid + T * e] | ((uint64_t)dh[tid + T * e] << 32), md, sRd);
     ntt_forward<LOGM, 1, LE>(x, lds, P.twf, tid, md);
 
-    const uint32_t *kp = keyk + ((size_t)pi * 8 + ph * 2) * M + E * tid;
-    uint32_t *zp = zpart + ((((size_t)b * npr + pi) * 4 + ph) * 2) * M + E * tid;
+    const int32_t *kp = keyk + ((size_t)pi * 8 + ph * 2) * M + E * tid;
+    int32_t *zp = zpart + ((((size_t)b * npr + pi) * 4 + ph) * 2) * M + E * tid;
 #pragma unroll
     for (int h = 0; h < E / 4; h++) {
-        const uint4 a = reinterpret_cast<const uint4 *>(kp)[h];
-        const uint4 bq = reinterpret_cast<const uint4 *>(kp + M)[h];
-        const uint32_t ka[4] = {a.x, a.y, a.z, a.w};
-        const uint32_t kb[4] = {bq.x, bq.y, bq.z, bq.w};
-        uint32_t r0[4], r1[4];
+        const int4 a = reinterpret_cast<const int4 *>(kp)[h];
+        const int4 bq = reinterpret_cast<const int4 *>(kp + M)[h];
+        const int32_t ka[4] = {a.x, a.y, a.z, a.w};
+        const int32_t kb[4] = {bq.x, bq.y, bq.z, bq.w};
+        int32_t r0[4], r1[4];
 #pragma unroll
         for (int t = 0; t < 4; t++) {
-            const uint32_t u = condsub(x[0][4 * h + t], md.p2);
-            r0[t] = redc_mad((uint64_t)u * ka[t], p, P.ninv);  // [0, 2p)
-            r1[t] = redc_mad((uint64_t)u * kb[t], p, P.ninv);
+            const int32_t u = x[0][4 * h + t];
+            r0[t] = smont(u, ka[t], md);  // |.| < 0.72 * 2^29
+            r1[t] = smont(u, kb[t], md);
         }
-        reinterpret_cast<uint4 *>(zp)[h] = make_uint4(r0[0], r0[1], r0[2], r0[3]);
-        reinterpret_cast<uint4 *>(zp + M)[h] = make_uint4(r1[0], r1[1], r1[2], r1[3]);
+        reinterpret_cast<int4 *>(zp)[h] = make_int4(r0[0], r0[1], r0[2], r0[3]);
+        reinterpret_cast<int4 *>(zp + M)[h] = make_int4(r1[0], r1[1], r1[2], r1[3]);
     }
 }
 
 template <int LOGM, int LE>
 __global__ void __launch_bounds__((NttGeom<LOGM, LE>::T), (NttGeom<LOGM, LE>::T >= 256 ? 4 : 1))
-k_inv_column(const uint32_t *__restrict__ zpart, uint32_t *__restrict__ yres,
+k_inv_column(const int32_t *__restrict__ zpart, uint32_t *__restrict__ yres,
              const uint32_t *__restrict__ ua, PrimeSet PS, uint32_t k, uint32_t n) {
     using G = NttGeom<LOGM, LE>;
     constexpr int M = G::M, T = G::T, E = G::E;
@@ -547,27 +544,22 @@ k_inv_column(const uint32_t *__restrict__ zpart, uint32_t *__restrict__ yres,
     const uint32_t pi = (blockIdx.x >> 1) % npr;
     const uint32_t b = (blockIdx.x >> 1) / npr;
     const PrimeK P = PS[pi];
-    const uint32_t p = P.p;
-    const Mod md = {P.p, P.ninv, 2 * P.p};
+    const Mod md = mod_of(P);
 
-    uint32_t z[1][E];
-    const uint32_t *zp = zpart + ((((size_t)b * npr + pi) * 4) * 2 + c) * M + E * tid;
+    int32_t z[1][E];
+    const int32_t *zp = zpart + ((((size_t)b * npr + pi) * 4) * 2 + c) * M + E * tid;
 #pragma unroll
     for (int h = 0; h < E / 4; h++) {
-        uint32_t acc[4] = {0, 0, 0, 0};
+        int32_t acc[4] = {0, 0, 0, 0};
 #pragma unroll
         for (int ph = 0; ph < 4; ph++) {
-            const uint4 v = reinterpret_cast<const uint4 *>(zp + (size_t)ph * 2 * M)[h];
-            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-            for (int t = 0; t < 4; t++) acc[t] = condsub(acc[t] + w[t], md.p2);  // stays in [0, 2p)
+            const int4 v = reinterpret_cast<const int4 *>(zp + (size_t)ph * 2 * M)[h];
+            acc[0] += v.x; acc[1] += v.y; acc[2] += v.z; acc[3] += v.w;  // < 2.9 * 2^29
         }
 #pragma unroll
-        for (int t = 0; t < 4; t++) z[0][4 * h + t] = acc[t];
+        for (int t = 0; t < 4; t++) z[0][4 * h + t] = sred(acc[t], md);
     }
     ntt_inverse<LOGM, 1, LE>(z, lds, P.twi, tid, md);
-#pragma unroll
-    for (int e = 0; e < E; e++) z[0][e] = csub(z[0][e], p);
 
     // y = x^j P - P  (as in k_extprod)
     uint32_t *yb = yres + (((size_t)b * 2 + c) * npr + pi) * M;
@@ -583,12 +575,10 @@ k_inv_column(const uint32_t *__restrict__ zpart, uint32_t *__restrict__ yres,
         const uint32_t he = h0 + e;
         const uint32_t hipart = (he & (E - 1)) << G::STOP;
         const uint32_t addr = hipart ^ lowswz ^ (G::STOP >= 9 ? 0u : swz_bits<LE>(hipart));
-        const uint32_t v = lds[addr];
-        const uint32_t vs = (he & E) ? p - v : v;  // x^m = -1
-        uint32_t d;
-        const bool borrow = __builtin_usub_overflow(vs, z[0][e], &d);
-        uint32_t y = borrow ? d + p : d;           // [0, p]
-        if (P.hoff) y = condsub(y + P.hoff, p);
+        const int32_t v = (int32_t)lds[addr];
+        const int32_t vs = (he & E) ? -v : v;  // x^m = -1
+        uint32_t y = sfull(vs - z[0][e], md);
+        if (P.hoff) y = condsub(y + P.hoff, (uint32_t)P.p);
         yb[tid + T * e] = y;
     }
 }
@@ -626,8 +616,8 @@ k_init(const uint64_t *__restrict__ a1, const uint64_t *__restrict__ b1,
         const u128 offr = CC->offneg_rnd ? Q - CC->offneg_rnd : 0;
         u128 xb = offr + (tv > 0 ? CC->DQ : (tv < 0 ? Q - CC->DQ : 0));
         if (xb >= Q) xb -= Q;
-        const ulonglong2 ea = random_digits(offr, CC, ra, ((b * 2 + 0) << logm) + i, 0u);
-        const ulonglong2 eb = random_digits(xb, CC, ra, ((b * 2 + 1) << logm) + i, 0u);
+        const ulonglong2 ea = random_digits(offr, CC, ra, make_uint4(i, 0u, ra.chunk + b, ra.call));
+        const ulonglong2 eb = random_digits(xb, CC, ra, make_uint4(M + i, 0u, ra.chunk + b, ra.call));
         store_digits(dig, (size_t)b * 2 + 0, i, M, ea.x, ea.y);
         store_digits(dig, (size_t)b * 2 + 1, i, M, eb.x, eb.y);
         return;
@@ -733,23 +723,41 @@ k_flatten_canon(const ulonglong2 *__restrict__ in, uint64_t *__restrict__ dig,
 // ==================================================================================================
 
 // raw: [count * n][3][n + 1] 16-byte residues (RAW_MODQ bootstrap output); only gate 0 (AND) is
-// read.  pdig: [count][n slices][2 digits][n coefficients] uint64.
+// read.  pdig: [count][n slices][2 digits][len] uint64 with len = n coefficients for the
+// deterministic flatten (the zero padding of as_i, fhe.jl:675-677, has the constant digits of 0)
+// and len = m for the randomised one (flatten_poly draws for every coefficient of the resized
+// polynomial, utils.jl:253-264).
 __global__ void __launch_bounds__(256)
 k_pack_flatten(const ulonglong2 *__restrict__ raw, uint64_t *__restrict__ pdig,
-               const CrtConst *__restrict__ CC, uint32_t count, uint32_t n) {
+               const CrtConst *__restrict__ CC, uint32_t count, uint32_t n, uint32_t logm,
+               uint32_t mode, RndArgs ra) {
     const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (t >= (size_t)count * n * n) return;
-    const uint32_t j = (uint32_t)(t % n);           // bit index = coefficient index of as_i
-    const uint32_t i = (uint32_t)((t / n) % n);     // LWE coefficient index = slice
-    const uint32_t ci = (uint32_t)(t / ((size_t)n * n));
-    const ulonglong2 v = raw[(((size_t)ci * n + j) * 3 + 0) * (n + 1) + i];
-    u128 x = (((u128)v.y << 64) | v.x) + (CC->Q - CC->offneg);   // + off
-    if (x >= CC->Q) x -= CC->Q;
+    const uint32_t len = (mode & MODE_RANDOM) ? (1u << logm) : n;
+    if (t >= (size_t)count * n * len) return;
+    const uint32_t j = (uint32_t)(t % len);         // bit index = coefficient index of as_i
+    const uint32_t i = (uint32_t)((t / len) % n);   // LWE coefficient index = slice
+    const uint32_t ci = (uint32_t)(t / ((size_t)n * len));
+    const u128 Q = CC->Q;
+    u128 x = 0;
+    if (j < n) {
+        const ulonglong2 v = raw[(((size_t)ci * n + j) * 3 + 0) * (n + 1) + i];
+        x = ((u128)v.y << 64) | v.x;
+    }
+    uint64_t *d = pdig + (((size_t)ci * n + i) * 2) * len + j;
+    if (mode & MODE_RANDOM) {
+        x += CC->offneg_rnd ? Q - CC->offneg_rnd : 0;   // + (s + xmax)(1 + B)
+        if (x >= Q) x -= Q;
+        const ulonglong2 e = random_digits(x, CC, ra, make_uint4(j, 0x80000000u | i, ci, ra.call));
+        d[0] = e.x;
+        d[len] = e.y;
+        return;
+    }
+    x += Q - CC->offneg;   // + off
+    if (x >= Q) x -= Q;
     uint64_t hi;
     const u128 lo = mod_wide(x, CC->B, CC->invB, &hi);
-    uint64_t *d = pdig + (((size_t)ci * n + i) * 2) * n + j;
     d[0] = (uint64_t)lo;
-    d[n] = hi;
+    d[len] = hi;
 }
 
 // grid = count * groups * NPR workgroups of T threads.  Workgroup (ci, g, pi) runs the 2 G phases
@@ -758,53 +766,57 @@ k_pack_flatten(const ulonglong2 *__restrict__ raw, uint64_t *__restrict__ pdig,
 //   yg [count][groups][2][NPR][m] residues (+ hoff), in [0, p]
 template <int LOGM>
 __global__ void __launch_bounds__((NttGeom<LOGM, LOGE>::T), (NttGeom<LOGM, LOGE>::T >= 256 ? 4 : 1))
-k_shortprod(const uint64_t *__restrict__ pdig, const uint32_t *__restrict__ keyhat,
+k_shortprod(const uint64_t *__restrict__ pdig, const int32_t *__restrict__ keyhat,
             uint32_t *__restrict__ yg, PrimeSet PS, const CrtConst *__restrict__ CC, uint32_t n,
-            uint32_t G, uint32_t groups) {
+            uint32_t G, uint32_t groups, uint32_t mode) {
     using GE = NttGeom<LOGM, LOGE>;
     constexpr int M = GE::M, T = GE::T, E = GE::E;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    int32_t *const ldsi = reinterpret_cast<int32_t *>(lds);
     const uint32_t npr = PS[0].npr;
     const uint32_t pi = blockIdx.x % npr;
     const uint32_t g = (blockIdx.x / npr) % groups;
     const uint32_t ci = blockIdx.x / (npr * groups);
     const PrimeK P = PS[pi];
-    const uint32_t p = P.p;
-    const Mod md = {P.p, P.ninv, 2 * P.p};
+    const Mod md = mod_of(P);
+    const int32_t sRd = (mode & MODE_RANDOM) ? P.sRr : P.sR;
     // residues of the digits of a zero coefficient (x' = off): the zero padding of as_i
-    const uint32_t zlo = digit_reduce(CC->dig0.x, P), zhi = digit_reduce(CC->dig0.y, P);
+    // (deterministic flatten of 0; the randomised mode draws for the padding too: k_pack_flatten
+    // writes all m coefficients there)
+    const int32_t zlo = digit_reduce(CC->dig0.x, md, P.sR), zhi = digit_reduce(CC->dig0.y, md, P.sR);
+    const uint32_t len = (mode & MODE_RANDOM) ? (uint32_t)M : n;  // stored coefficients per digit polynomial
 
-    uint32_t z0[1][E];
+    int32_t z0[1][E];
 #pragma unroll
-    for (int e = 0; e < E; e++) { z0[0][e] = 0; lds[M + e * T + threadIdx.x] = 0; }
+    for (int e = 0; e < E; e++) { z0[0][e] = 0; ldsi[M + e * T + threadIdx.x] = 0; }
 #pragma unroll 1
     for (uint32_t ph = 0; ph < 2 * G; ph++) {
         const int tid = (int)threadIdx.x + (int)opaque_zero();
         const uint32_t i = g * G + (ph >> 1), digit = ph & 1;
-        uint32_t x[1][E];
-        const uint64_t *d = pdig + (((size_t)ci * n + i) * 2 + digit) * n;
+        int32_t x[1][E];
+        const uint64_t *d = pdig + (((size_t)ci * n + i) * 2 + digit) * len;
 #pragma unroll
         for (int e = 0; e < E; e++) {
             const uint32_t idx = tid + T * e;
-            x[0][e] = idx < n ? digit_reduce(d[idx], P) : (digit ? zhi : zlo);
+            x[0][e] = idx < len ? digit_reduce(d[idx], md, sRd) : (digit ? zhi : zlo);
         }
         SGFHE_SYNC();
         ntt_forward<LOGM, 1, LOGE>(x, lds, P.twf, tid, md);
         // key rows l + 1 .. 2 l of slice i (fhe.jl:638-639): polynomials (2 + digit) * 2 + c
-        const uint32_t *kp = keyhat + (((size_t)i * npr + pi) * 8 + (2 + digit) * 2) * M + E * tid;
+        const int32_t *kp = keyhat + (((size_t)i * npr + pi) * 8 + (2 + digit) * 2) * M + E * tid;
 #pragma unroll
         for (int h = 0; h < E / 4; h++) {
-            const uint4 a = reinterpret_cast<const uint4 *>(kp)[h];
-            const uint4 bq = reinterpret_cast<const uint4 *>(kp + M)[h];
-            const uint32_t ka[4] = {a.x, a.y, a.z, a.w};
-            const uint32_t kb[4] = {bq.x, bq.y, bq.z, bq.w};
+            const int4 a = reinterpret_cast<const int4 *>(kp)[h];
+            const int4 bq = reinterpret_cast<const int4 *>(kp + M)[h];
+            const int32_t ka[4] = {a.x, a.y, a.z, a.w};
+            const int32_t kb[4] = {bq.x, bq.y, bq.z, bq.w};
 #pragma unroll
             for (int t = 0; t < 4; t++) {
                 const int e = 4 * h + t;
-                const uint32_t u = x[0][e];  // [0, 4p): u K < p 2^32
-                z0[0][e] = condsub(z0[0][e] + redc_mad((uint64_t)u * ka[t], p, P.ninv), md.p2);
-                uint32_t *zp = lds + M + e * T + tid;
-                *zp = condsub(*zp + redc_mad((uint64_t)u * kb[t], p, P.ninv), md.p2);
+                const int32_t u = x[0][e];
+                z0[0][e] = sred(z0[0][e] + smont(u, ka[t], md), md);  // stays below 0.52 * 2^29
+                int32_t *zp = ldsi + M + e * T + tid;
+                *zp = sred(*zp + smont(u, kb[t], md), md);
             }
         }
     }
@@ -814,13 +826,13 @@ k_shortprod(const uint64_t *__restrict__ pdig, const uint32_t *__restrict__ keyh
     for (int c = 0; c < 2; c++) {
         if (c > 0) {
 #pragma unroll
-            for (int e = 0; e < E; e++) z0[0][e] = lds[M + e * T + tid];
+            for (int e = 0; e < E; e++) z0[0][e] = ldsi[M + e * T + tid];
             SGFHE_SYNC();
         }
         ntt_inverse<LOGM, 1, LOGE>(z0, lds, P.twi, tid, md);
 #pragma unroll
         for (int e = 0; e < E; e++)
-            yb[(size_t)c * npr * M + tid + T * e] = condsub(condsub(z0[0][e], p) + P.hoff, p);
+            yb[(size_t)c * npr * M + tid + T * e] = condsub(sfull(z0[0][e], md) + P.hoff, (uint32_t)P.p);
     }
 }
 
@@ -905,39 +917,47 @@ k_keygen_draw(ulonglong2 *__restrict__ acan, int32_t *__restrict__ e,
     e[t] = (int32_t)d - (int32_t)noise;
 }
 
-// shat[pi][slot] = NTT(s)[slot] * m^-1 * (M/p)^-1 * R mod p  (s = the secret key, zero padded)
+// Residue mod p of a canonical value C < 2^96 given as three 32-bit limbs, lifted to the centred
+// representative of C mod Q first when `lift` (C > Q / 2 -> C - Q): |result| < 3.5 * 2^29.
+__device__ __forceinline__ int32_t limbs_mod_p(ulonglong2 v, bool lift, const PrimeK &P, const Mod &md) {
+    const uint32_t c0 = (uint32_t)v.x, c1 = (uint32_t)(v.x >> 32), c2 = (uint32_t)v.y;
+    int32_t r = smontu(c0, P.r1, md) + smontu(c1, P.r2, md) + smontu(c2, P.r3, md);  // each |.| < p
+    if (lift) r -= P.qmodp;
+    return r;
+}
+
+// shat[pi][slot] = NTT(s)[slot] * m^-1 * (M/p)^-1 * R mod p, centred  (s = the secret key, zero padded)
 template <int LOGM>
 __global__ void __launch_bounds__((NttGeom<LOGM, LOGE>::T))
-k_shat(const uint64_t *__restrict__ sk, uint32_t *__restrict__ shat, PrimeSet PS, uint32_t n) {
+k_shat(const uint64_t *__restrict__ sk, int32_t *__restrict__ shat, PrimeSet PS, uint32_t n) {
     using G = NttGeom<LOGM, LOGE>;
     constexpr int M = G::M, T = G::T, E = G::E;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const int tid = threadIdx.x;
     const uint32_t pi = blockIdx.x;
     const PrimeK P = PS[pi];
-    const Mod md = {P.p, P.ninv, 2 * P.p};
-    uint32_t x[1][E];
+    const Mod md = mod_of(P);
+    int32_t x[1][E];
 #pragma unroll
     for (int e = 0; e < E; e++) {
         const uint32_t idx = tid + T * e;
-        x[0][e] = idx < n ? (uint32_t)(sk[idx] & 1) : 0u;
+        x[0][e] = idx < n ? (int32_t)(sk[idx] & 1) : 0;
     }
     ntt_forward<LOGM, 1, LOGE>(x, lds, P.twf, tid, md);
-    // kappaR = R^2 m^-1 (M/p)^-1 * R: mont_mul(mont_mul(x, kappaR), 1) = x R^2 m^-1 e ... we need
-    // x m^-1 e R = mont_mul(x, kappaR) * R^-1: two Montgomery steps with 1 bring R^3 down to R
+    // kappaR = R^2 m^-1 (M/p)^-1 * R: smont(x, kappaR) = x R^2 m^-1 e; one more Montgomery step
+    // with 1 brings it down to x R m^-1 e
 #pragma unroll
     for (int e = 0; e < E; e++) {
-        uint32_t u = condsub(condsub(x[0][e], md.p2), P.p);
-        u = mont_mul(u, P.kappaR, P.p, P.ninv);   // x R^2 m^-1 e
-        u = mont_mul(u, 1u, P.p, P.ninv);         // x R   m^-1 e
-        shat[(size_t)pi * M + E * tid + e] = u;
+        int32_t u = smont(x[0][e], P.kappaR, md);
+        u = smont(u, 1, md);
+        shat[(size_t)pi * M + E * tid + e] = scentre(u, md);
     }
 }
 
 // y[r][pi][m] = (M/p)^-1 * (a_r (*) s) mod p (+ hoff), a lifted to (-Q/2, Q/2]
 template <int LOGM>
 __global__ void __launch_bounds__((NttGeom<LOGM, LOGE>::T))
-k_polymul_s(const ulonglong2 *__restrict__ acan, const uint32_t *__restrict__ shat,
+k_polymul_s(const ulonglong2 *__restrict__ acan, const int32_t *__restrict__ shat,
             uint32_t *__restrict__ y, PrimeSet PS, const CrtConst *__restrict__ CC) {
     using G = NttGeom<LOGM, LOGE>;
     constexpr int M = G::M, T = G::T, E = G::E;
@@ -946,29 +966,24 @@ k_polymul_s(const ulonglong2 *__restrict__ acan, const uint32_t *__restrict__ sh
     const uint32_t npr = PS[0].npr;
     const uint32_t r = blockIdx.x / npr, pi = blockIdx.x % npr;
     const PrimeK P = PS[pi];
-    const uint32_t p = P.p;
-    const Mod md = {P.p, P.ninv, 2 * P.p};
+    const Mod md = mod_of(P);
     const u128 halfQ = CC->halfQ;
-    uint32_t x[1][E];
+    int32_t x[1][E];
 #pragma unroll
     for (int e = 0; e < E; e++) {
         const ulonglong2 v = acan[(size_t)r * M + tid + T * e];
-        const uint32_t c0 = (uint32_t)v.x, c1 = (uint32_t)(v.x >> 32), c2 = (uint32_t)v.y;
-        uint32_t u = csub(mont_mul(c0, P.r1, p, P.ninv) + mont_mul(c1, P.r2, p, P.ninv), p);
-        u = csub(u + mont_mul(c2, P.r3, p, P.ninv), p);
         const u128 C = ((u128)v.y << 64) | v.x;
-        if (C > halfQ) { u = u - P.qmodp; u = min(u, u + p); }
-        x[0][e] = u;
+        x[0][e] = sred(limbs_mod_p(v, C > halfQ, P, md), md);
     }
     ntt_forward<LOGM, 1, LOGE>(x, lds, P.twf, tid, md);
 #pragma unroll
-    for (int e = 0; e < E; e++)  // x in [0, 4p), shat < p: product < p 2^32
-        x[0][e] = redc_mad((uint64_t)x[0][e] * shat[(size_t)pi * M + E * tid + e], p, P.ninv);
+    for (int e = 0; e < E; e++)  // |x| < 3.5 * 2^29, |shat| <= p / 2: |product R^-1| < 0.72 * 2^29
+        x[0][e] = smont(x[0][e], shat[(size_t)pi * M + E * tid + e], md);
     __syncthreads();
     ntt_inverse<LOGM, 1, LOGE>(x, lds, P.twi, tid, md);
 #pragma unroll
     for (int e = 0; e < E; e++)
-        y[((size_t)r * npr + pi) * M + tid + T * e] = condsub(condsub(x[0][e], p) + P.hoff, p);
+        y[((size_t)r * npr + pi) * M + tid + T * e] = condsub(sfull(x[0][e], md) + P.hoff, (uint32_t)P.p);
 }
 
 // canon[(r * 2 + col)][m]: col 0 = a_r + s_k G[row][0], col 1 = a_r (*) s + e_r + s_k G[row][1]
@@ -1005,7 +1020,7 @@ k_keygen_finish(const ulonglong2 *__restrict__ acan, const ulonglong2 *__restric
 //   keyhat [k][NPR][row*2+col][m]
 template <int LOGM>
 __global__ void __launch_bounds__((NttGeom<LOGM, LOGE>::T))
-k_key_transform(const ulonglong2 *__restrict__ canon, uint32_t *__restrict__ keyhat, PrimeSet PS,
+k_key_transform(const ulonglong2 *__restrict__ canon, int32_t *__restrict__ keyhat, PrimeSet PS,
                 const CrtConst *__restrict__ CC, uint32_t poly0, uint32_t *__restrict__ bad) {
     using G = NttGeom<LOGM, LOGE>;
     constexpr int M = G::M, T = G::T, E = G::E;
@@ -1015,33 +1030,25 @@ k_key_transform(const ulonglong2 *__restrict__ canon, uint32_t *__restrict__ key
     const uint32_t pl = blockIdx.x / npr;  // polynomial within this staging batch
     const uint32_t pi = blockIdx.x % npr;
     const PrimeK P = PS[pi];
-    const uint32_t p = P.p;
-    const Mod md = {P.p, P.ninv, 2 * P.p};
+    const Mod md = mod_of(P);
     const u128 halfQ = CC->halfQ;
-    uint32_t x[1][E];
+    int32_t x[1][E];
 #pragma unroll
     for (int e = 0; e < E; e++) {
         const ulonglong2 v = canon[(size_t)pl * M + tid + T * e];
-        const uint32_t c0 = (uint32_t)v.x, c1 = (uint32_t)(v.x >> 32), c2 = (uint32_t)v.y;
-        uint32_t r = csub(mont_mul(c0, P.r1, p, P.ninv) + mont_mul(c1, P.r2, p, P.ninv), p);
-        r = csub(r + mont_mul(c2, P.r3, p, P.ninv), p);
         const u128 C = ((u128)v.y << 64) | v.x;
         if (C >= CC->Q) *bad = 1u;  // not a canonical residue: reported by the upload call
-        if (C > halfQ) { r = r - P.qmodp; r = min(r, r + p); }
-        x[0][e] = mont_mul(r, P.kappaR, p, P.ninv);
+        x[0][e] = smont(limbs_mod_p(v, C > halfQ, P, md), P.kappaR, md);  // |.| < 0.72 * 2^29
     }
     ntt_forward<LOGM, 1, LOGE>(x, lds, P.twf, tid, md);
     const uint32_t pg = poly0 + pl;  // global polynomial index = k * 8 + row * 2 + col
-    uint32_t *dst = keyhat + (((size_t)(pg >> 3) * npr + pi) * 8 + (pg & 7)) * M + E * tid;
+    int32_t *dst = keyhat + (((size_t)(pg >> 3) * npr + pi) * 8 + (pg & 7)) * M + E * tid;
 #pragma unroll
     for (int h = 0; h < E / 4; h++) {
-        uint32_t o[4];
+        int32_t o[4];
 #pragma unroll
-        for (int t = 0; t < 4; t++) {
-            const uint32_t u = min(x[0][4 * h + t], x[0][4 * h + t] - md.p2);
-            o[t] = csub(u, p);
-        }
-        reinterpret_cast<uint4 *>(dst)[h] = make_uint4(o[0], o[1], o[2], o[3]);
+        for (int t = 0; t < 4; t++) o[t] = scentre(sred(x[0][4 * h + t], md), md);  // [-(p-1)/2, (p-1)/2]
+        reinterpret_cast<int4 *>(dst)[h] = make_int4(o[0], o[1], o[2], o[3]);
     }
 }
 
@@ -1055,25 +1062,20 @@ k_debug_ntt(const uint32_t *__restrict__ in, uint32_t *__restrict__ out, PrimeSe
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const int tid = threadIdx.x;
     const PrimeK P = PS[pi];
-    const uint32_t p = P.p;
-    const Mod md = {P.p, P.ninv, 2 * P.p};
-    uint32_t x[1][E];
+    const Mod md = mod_of(P);
+    int32_t x[1][E];
     if (!inverse) {
 #pragma unroll
-        for (int e = 0; e < E; e++) x[0][e] = in[tid + T * e];
+        for (int e = 0; e < E; e++) x[0][e] = (int32_t)in[tid + T * e];  // [0, p)
         ntt_forward<LOGM, 1, LOGE>(x, lds, P.twf, tid, md);
 #pragma unroll
-        for (int e = 0; e < E; e++) {
-            const uint32_t u = condsub(x[0][e], md.p2);
-            out[E * tid + e] = csub(u, p);
-        }
+        for (int e = 0; e < E; e++) out[E * tid + e] = sfull(x[0][e], md);
     } else {
 #pragma unroll
-        for (int e = 0; e < E; e++) x[0][e] = in[E * tid + e];
+        for (int e = 0; e < E; e++) x[0][e] = sred((int32_t)in[E * tid + e], md);
         ntt_inverse<LOGM, 1, LOGE>(x, lds, P.twi, tid, md);
 #pragma unroll
-        for (int e = 0; e < E; e++)
-            out[tid + T * e] = mont_mul(csub(x[0][e], p), P.minvR, p, P.ninv);
+        for (int e = 0; e < E; e++) out[tid + T * e] = scanon(smont(x[0][e], P.minvR, md), md);
     }
 }
 

@@ -1,5 +1,7 @@
-// LDS-staged negacyclic NTT of length m = 2^LOGM over one 30-bit RNS prime, NP polynomials at
-// once (same twiddles, NP-fold instruction-level parallelism).
+// LDS-staged negacyclic NTT of length m = 2^LOGM over one 29-bit RNS prime, NP polynomials at
+// once (same twiddles, NP-fold instruction-level parallelism).  Values are signed lazy residues
+// (rns_arith.h): the forward transform range-reduces the X inputs of the first stage of every LDS
+// pass, the inverse transform the sums of every second stage and of the last stage of a pass.
 //
 // Geometry: a workgroup of T = m / E threads, E = 2^LOGE (8 or 16); every thread keeps E points
 // of each polynomial in registers and performs radix-E passes (LOGE butterfly stages per pass)
@@ -15,7 +17,7 @@
 // Inverse: Gentleman-Sande, slot order in (same ownership), natural order out in the
 // idx(e) = tid + T * e layout, not scaled by 1/m (the scale is folded into the key).
 //
-// Twiddles: tw[i] = psi^(+-bitrev(i)) * 2^32 mod p (Montgomery form), i in [1, m).  Stage
+// Twiddles: tw[i] = psi^(+-bitrev(i)) * 2^32 mod p (Montgomery form, centred: |tw| <= p/2), i in [1, m).  Stage
 // "local bit b" of a pass over [S, S+LOGE) uses the 2^(LOGE-1-b) consecutive entries starting at
 // 2^(LOGM-1-S-b) + (hi << (LOGE-1-b)).
 //
@@ -73,7 +75,7 @@ __device__ __forceinline__ uint32_t opaque_zero_s() {
     return z;
 }
 
-typedef __attribute__((address_space(4))) uint32_t gmem_u32;  // a word of read-only global memory ("constant")
+typedef __attribute__((address_space(4))) int32_t gmem_i32;  // a word of read-only global memory ("constant")
 
 // ---- twiddles of one pass ---------------------------------------------------------------------
 // The E - 1 twiddles of a radix-E pass sit in registers in heap order: stage "local bit B" owns
@@ -84,21 +86,21 @@ typedef __attribute__((address_space(4))) uint32_t gmem_u32;  // a word of read-
 // every lane of a wavefront, so the loads are scalar (s_load into SGPRs: no VGPRs, no VMEM
 // traffic, no address arithmetic on the vector ALU).
 template <int LOGM, int LOGE, int S, int BHI, int BLO>
-__device__ __forceinline__ void load_twiddles_at(uint32_t (&t)[(1 << LOGE) - 1], const gmem_u32 *tw,
+__device__ __forceinline__ void load_twiddles_at(int32_t (&t)[(1 << LOGE) - 1], const gmem_i32 *tw,
                                                  uint32_t hi) {
     constexpr int NG = 1 << (LOGE - 1 - BHI);
-    const gmem_u32 *w = tw + (1u << (LOGM - 1 - S - BHI)) + (hi << (LOGE - 1 - BHI));
+    const gmem_i32 *w = tw + (1u << (LOGM - 1 - S - BHI)) + (hi << (LOGE - 1 - BHI));
 #pragma unroll
     for (int g = 0; g < NG; g++)
 #ifdef SGFHE_ABL_NO_TW
-        t[NG - 1 + g] = hi + g + 12345u;  // timing-only build: no twiddle loads (wrong results)
+        t[NG - 1 + g] = (int32_t)(hi + g + 12345u);  // timing-only build: no twiddle loads (wrong results)
 #else
         t[NG - 1 + g] = w[g];
 #endif
     if constexpr (BHI > BLO) load_twiddles_at<LOGM, LOGE, S, BHI - 1, BLO>(t, tw, hi);
 }
 template <int LOGM, int LOGE, int S, int BHI, int BLO>
-__device__ __forceinline__ void load_twiddles(uint32_t (&t)[(1 << LOGE) - 1], const uint32_t *tw,
+__device__ __forceinline__ void load_twiddles(int32_t (&t)[(1 << LOGE) - 1], const int32_t *tw,
                                               uint32_t hi) {
     // The table pointer comes out of a PrimeK record in memory, so the compiler only knows it as
     // a generic pointer and would emit flat_load, which counts on lgkmcnt as well as vmcnt: every
@@ -106,17 +108,17 @@ __device__ __forceinline__ void load_twiddles(uint32_t (&t)[(1 << LOGE) - 1], co
     // The opaque zero keeps the loads one pass ahead of their use and no further.
     if constexpr ((1 << S) >= 64) {
         const uint32_t hu = __builtin_amdgcn_readfirstlane(hi);
-        load_twiddles_at<LOGM, LOGE, S, BHI, BLO>(t, (const gmem_u32 *)tw + opaque_zero_s(), hu);
+        load_twiddles_at<LOGM, LOGE, S, BHI, BLO>(t, (const gmem_i32 *)tw + opaque_zero_s(), hu);
     } else {
-        load_twiddles_at<LOGM, LOGE, S, BHI, BLO>(t, (const gmem_u32 *)tw, hi);
+        load_twiddles_at<LOGM, LOGE, S, BHI, BLO>(t, (const gmem_i32 *)tw, hi);
     }
 }
 
 // ---- one butterfly stage on local bit B of the register index e -----------------------------
 
 template <int NP, int LOGE, int B>
-__device__ __forceinline__ void fwd_stage(uint32_t (&x)[NP][1 << LOGE],
-                                          const uint32_t (&t)[(1 << LOGE) - 1], const Mod &md) {
+__device__ __forceinline__ void fwd_stage(int32_t (&x)[NP][1 << LOGE],
+                                          const int32_t (&t)[(1 << LOGE) - 1], const Mod &md) {
     constexpr int NG = 1 << (LOGE - 1 - B);
 #pragma unroll
     for (int q = 0; q < NP; q++)
@@ -128,9 +130,9 @@ __device__ __forceinline__ void fwd_stage(uint32_t (&x)[NP][1 << LOGE],
                 bfly_fwd(x[q][e0], x[q][e0 | (1 << B)], t[NG - 1 + g], md);
             }
 }
-template <int NP, int LOGE, int B>
-__device__ __forceinline__ void inv_stage(uint32_t (&x)[NP][1 << LOGE],
-                                          const uint32_t (&t)[(1 << LOGE) - 1], const Mod &md) {
+template <int NP, int LOGE, int B, bool RED>
+__device__ __forceinline__ void inv_stage(int32_t (&x)[NP][1 << LOGE],
+                                          const int32_t (&t)[(1 << LOGE) - 1], const Mod &md) {
     constexpr int NG = 1 << (LOGE - 1 - B);
 #pragma unroll
     for (int q = 0; q < NP; q++)
@@ -139,23 +141,36 @@ __device__ __forceinline__ void inv_stage(uint32_t (&x)[NP][1 << LOGE],
 #pragma unroll
             for (int l = 0; l < (1 << B); l++) {
                 const int e0 = (g << (B + 1)) | l;
-                bfly_inv(x[q][e0], x[q][e0 | (1 << B)], t[NG - 1 + g], md);
+                bfly_inv<RED>(x[q][e0], x[q][e0 | (1 << B)], t[NG - 1 + g], md);
             }
 }
 
 // stages B = BHI, BHI-1, ..., BLO (forward order)
 template <int NP, int LOGE, int BHI, int BLO>
-__device__ __forceinline__ void fwd_stages(uint32_t (&x)[NP][1 << LOGE],
-                                           const uint32_t (&t)[(1 << LOGE) - 1], const Mod &md) {
+__device__ __forceinline__ void fwd_stages(int32_t (&x)[NP][1 << LOGE],
+                                           const int32_t (&t)[(1 << LOGE) - 1], const Mod &md) {
     fwd_stage<NP, LOGE, BHI>(x, t, md);
     if constexpr (BHI > BLO) fwd_stages<NP, LOGE, BHI - 1, BLO>(x, t, md);
 }
-// stages B = BLO, BLO+1, ..., BHI (inverse order)
-template <int NP, int LOGE, int BLO, int BHI>
-__device__ __forceinline__ void inv_stages(uint32_t (&x)[NP][1 << LOGE],
-                                           const uint32_t (&t)[(1 << LOGE) - 1], const Mod &md) {
-    inv_stage<NP, LOGE, BLO>(x, t, md);
-    if constexpr (BLO < BHI) inv_stages<NP, LOGE, BLO + 1, BHI>(x, t, md);
+// The X inputs of the first stage of a full pass (register index bit LOGE-1 clear) are pulled back
+// to about (-p/2, p/2); the stages of the pass then add at most 0.72 * 2^29 each.
+template <int NP, int LOGE>
+__device__ __forceinline__ void fwd_reduce_x(int32_t (&x)[NP][1 << LOGE], const Mod &md) {
+#pragma unroll
+    for (int q = 0; q < NP; q++)
+#pragma unroll
+        for (int e = 0; e < (1 << (LOGE - 1)); e++) x[q][e] = sred(x[q][e], md);
+}
+// stages B = BLO, BLO+1, ..., BHI (inverse order).  The sums of a Gentleman-Sande stage double in
+// size, so they are range-reduced in every second stage of a pass (counted from its first stage
+// BFIRST) and, when LASTRED, in its last stage: a full pass then hands at most 0.67 * 2^29 to the
+// next one (see the range model in tests/rns_model.py).
+template <int NP, int LOGE, int BLO, int BHI, int BFIRST, bool LASTRED>
+__device__ __forceinline__ void inv_stages(int32_t (&x)[NP][1 << LOGE],
+                                           const int32_t (&t)[(1 << LOGE) - 1], const Mod &md) {
+    constexpr bool RED = (((BLO - BFIRST) & 1) != 0) || (LASTRED && BLO == BHI);
+    inv_stage<NP, LOGE, BLO, RED>(x, t, md);
+    if constexpr (BLO < BHI) inv_stages<NP, LOGE, BLO + 1, BHI, BFIRST, LASTRED>(x, t, md);
 }
 
 // ---- LDS exchange ------------------------------------------------------------------------
@@ -169,7 +184,7 @@ __device__ __forceinline__ uint32_t lds_base(int tid) {
 // Addresses are formed in bytes: the thread's swizzled base is shifted once and every element
 // costs one XOR with a compile-time constant (an index-then-scale form costs a shift per element).
 template <int LOGM, int NP, int LOGE, int S>
-__device__ __forceinline__ void lds_store(const uint32_t (&x)[NP][1 << LOGE], uint32_t *lds, int tid) {
+__device__ __forceinline__ void lds_store(const int32_t (&x)[NP][1 << LOGE], uint32_t *lds, int tid) {
 #ifdef SGFHE_ABL_NO_LDS
     return;  // timing-only build: no LDS exchange (wrong results)
 #endif
@@ -180,11 +195,11 @@ __device__ __forceinline__ void lds_store(const uint32_t (&x)[NP][1 << LOGE], ui
     for (int e = 0; e < (1 << LOGE); e++) {
         const uint32_t a = pb ^ (swz<LOGE>((uint32_t)e << S) << 2);
 #pragma unroll
-        for (int q = 0; q < NP; q++) *reinterpret_cast<uint32_t *>(base + q * M * 4 + a) = x[q][e];
+        for (int q = 0; q < NP; q++) *reinterpret_cast<int32_t *>(base + q * M * 4 + a) = x[q][e];
     }
 }
 template <int LOGM, int NP, int LOGE, int S>
-__device__ __forceinline__ void lds_load(uint32_t (&x)[NP][1 << LOGE], const uint32_t *lds, int tid) {
+__device__ __forceinline__ void lds_load(int32_t (&x)[NP][1 << LOGE], const uint32_t *lds, int tid) {
 #ifdef SGFHE_ABL_NO_LDS
     return;
 #endif
@@ -195,7 +210,7 @@ __device__ __forceinline__ void lds_load(uint32_t (&x)[NP][1 << LOGE], const uin
     for (int e = 0; e < (1 << LOGE); e++) {
         const uint32_t a = pb ^ (swz<LOGE>((uint32_t)e << S) << 2);
 #pragma unroll
-        for (int q = 0; q < NP; q++) x[q][e] = *reinterpret_cast<const uint32_t *>(base + q * M * 4 + a);
+        for (int q = 0; q < NP; q++) x[q][e] = *reinterpret_cast<const int32_t *>(base + q * M * 4 + a);
     }
 }
 
@@ -230,15 +245,16 @@ struct NoHook {
 template <int LOGM, int NP, int LOGE, int SPREV, int SCUR>
 struct FwdPasses {
     template <class F>
-    static __device__ __forceinline__ void run(uint32_t (&x)[NP][1 << LOGE], uint32_t *lds,
-                                               const uint32_t *tw, int tid, const Mod &md,
+    static __device__ __forceinline__ void run(int32_t (&x)[NP][1 << LOGE], uint32_t *lds,
+                                               const int32_t *tw, int tid, const Mod &md,
                                                const F &before_last) {
-        uint32_t t[(1 << LOGE) - 1];
+        int32_t t[(1 << LOGE) - 1];
         load_twiddles<LOGM, LOGE, SCUR, LOGE - 1, 0>(t, tw, (uint32_t)tid >> SCUR);
         if constexpr (SCUR < LOGE) before_last();
         lds_store<LOGM, NP, LOGE, SPREV>(x, lds, tid);
         exchange_sync<LOGE, SCUR>();
         lds_load<LOGM, NP, LOGE, SCUR>(x, lds, tid);
+        fwd_reduce_x<NP, LOGE>(x, md);
         fwd_stages<NP, LOGE, LOGE - 1, 0>(x, t, md);
         if constexpr (SCUR >= LOGE)
             FwdPasses<LOGM, NP, LOGE, SCUR, SCUR - LOGE>::run(x, lds, tw, tid, md, before_last);
@@ -248,12 +264,12 @@ struct FwdPasses {
 // the twiddles of pass SCUR in t
 template <int LOGM, int NP, int LOGE, int SCUR, int SLAST>
 struct InvPasses {
-    static __device__ __forceinline__ void run(uint32_t (&x)[NP][1 << LOGE], uint32_t *lds,
-                                               const uint32_t *tw, int tid, const Mod &md,
-                                               const uint32_t (&t)[(1 << LOGE) - 1]) {
-        inv_stages<NP, LOGE, 0, LOGE - 1>(x, t, md);
+    static __device__ __forceinline__ void run(int32_t (&x)[NP][1 << LOGE], uint32_t *lds,
+                                               const int32_t *tw, int tid, const Mod &md,
+                                               const int32_t (&t)[(1 << LOGE) - 1]) {
+        inv_stages<NP, LOGE, 0, LOGE - 1, 0, true>(x, t, md);
         if constexpr (SCUR < SLAST) {
-            uint32_t tn[(1 << LOGE) - 1];
+            int32_t tn[(1 << LOGE) - 1];
             load_twiddles<LOGM, LOGE, SCUR + LOGE, LOGE - 1, 0>(tn, tw,
                                                                 (uint32_t)tid >> (SCUR + LOGE));
             lds_store<LOGM, NP, LOGE, SCUR>(x, lds, tid);
@@ -264,15 +280,15 @@ struct InvPasses {
     }
 };
 
-// Forward transform.  In: x[q][e] = coefficient tid + T e of polynomial q, in [0, 4p).
-// Out: x[q][e] = slot E tid + e, in [0, 4p).  `lds` must hold NP * m words.
+// Forward transform.  In: x[q][e] = coefficient tid + T e of polynomial q, |x| <= 1.01 * 2^29.
+// Out: x[q][e] = slot E tid + e, |x| < 3.5 * 2^29.  `lds` must hold NP * m words.
 template <int LOGM, int NP, int LOGE, class F = NoHook>
-__device__ __forceinline__ void ntt_forward(uint32_t (&x)[NP][1 << LOGE], uint32_t *lds,
-                                            const uint32_t *tw, int tid, const Mod &md,
+__device__ __forceinline__ void ntt_forward(int32_t (&x)[NP][1 << LOGE], uint32_t *lds,
+                                            const int32_t *tw, int tid, const Mod &md,
                                             const F &before_last = F()) {
     using G = NttGeom<LOGM, LOGE>;
     constexpr int BLO = G::RHO == 0 ? 0 : LOGE - G::RHO;
-    uint32_t t[(1 << LOGE) - 1];
+    int32_t t[(1 << LOGE) - 1];
     load_twiddles<LOGM, LOGE, G::STOP, LOGE - 1, BLO>(t, tw, 0u);
     fwd_stages<NP, LOGE, LOGE - 1, BLO>(x, t, md);
     if constexpr (G::SFIRST >= 0)
@@ -281,20 +297,21 @@ __device__ __forceinline__ void ntt_forward(uint32_t (&x)[NP][1 << LOGE], uint32
         before_last();
 }
 
-// Inverse transform (unscaled).  In: slots E tid + e in [0, 2p).  Out: coefficient tid + T e in
-// [0, 2p), in registers; the last LDS accesses of every thread were loads in layout STOP.
+// Inverse transform (unscaled).  In: slots E tid + e, |x| <= 0.75 * 2^29.  Out: coefficient
+// tid + T e, |x| < 1.4 * 2^29, in registers; the last LDS accesses of every thread were loads in
+// layout STOP.
 template <int LOGM, int NP, int LOGE>
-__device__ __forceinline__ void ntt_inverse(uint32_t (&x)[NP][1 << LOGE], uint32_t *lds,
-                                            const uint32_t *tw, int tid, const Mod &md) {
+__device__ __forceinline__ void ntt_inverse(int32_t (&x)[NP][1 << LOGE], uint32_t *lds,
+                                            const int32_t *tw, int tid, const Mod &md) {
     using G = NttGeom<LOGM, LOGE>;
     if constexpr (G::RHO == 0) {
-        uint32_t t[(1 << LOGE) - 1];
+        int32_t t[(1 << LOGE) - 1];
         load_twiddles<LOGM, LOGE, 0, LOGE - 1, 0>(t, tw, (uint32_t)tid);
         InvPasses<LOGM, NP, LOGE, 0, G::STOP>::run(x, lds, tw, tid, md, t);
     } else {
-        uint32_t tp[(1 << LOGE) - 1];
+        int32_t tp[(1 << LOGE) - 1];
         if constexpr (G::SLAST_INV >= 0) {
-            uint32_t t[(1 << LOGE) - 1];
+            int32_t t[(1 << LOGE) - 1];
             load_twiddles<LOGM, LOGE, 0, LOGE - 1, 0>(t, tw, (uint32_t)tid);
             InvPasses<LOGM, NP, LOGE, 0, G::SLAST_INV>::run(x, lds, tw, tid, md, t);
             load_twiddles<LOGM, LOGE, G::STOP, LOGE - 1, LOGE - G::RHO>(tp, tw, 0u);
@@ -304,7 +321,7 @@ __device__ __forceinline__ void ntt_inverse(uint32_t (&x)[NP][1 << LOGE], uint32
         } else {
             load_twiddles<LOGM, LOGE, G::STOP, LOGE - 1, LOGE - G::RHO>(tp, tw, 0u);
         }
-        inv_stages<NP, LOGE, LOGE - G::RHO, LOGE - 1>(x, tp, md);
+        inv_stages<NP, LOGE, LOGE - G::RHO, LOGE - 1, LOGE - G::RHO, false>(x, tp, md);
     }
 }
 

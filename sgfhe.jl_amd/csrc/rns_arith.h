@@ -1,10 +1,21 @@
-// Word-size modular arithmetic for the RNS primes (p < 2^30) on gfx950.
+// Word-size modular arithmetic for the RNS primes (p < 2^29) on gfx950.
 //
-// The native integer multiplier of a CDNA4 lane is 32 x 32 (v_mul_lo_u32 / v_mul_hi_u32 /
-// v_mad_u64_u32), so the wide ring Z_Q (Q up to 94 bits; DarkIntegers MgModUInt{UInt128, Q} in
-// the reference, src/fhe.jl:83-85,104) is replaced on the device by exact integer arithmetic in
-// a residue number system of 30-bit NTT primes.  Everything here is exact; laziness ranges are
-// stated per function.
+// The native integer multiplier of a CDNA4 lane is 32 x 32 (v_mul_lo_u32 / v_mul_hi / v_mad_64_32),
+// so the wide ring Z_Q (Q up to 94 bits; DarkIntegers MgModUInt{UInt128, Q} in the reference,
+// src/fhe.jl:83-85,104) is replaced on the device by exact integer arithmetic in a residue number
+// system of 29-bit NTT primes.  Everything here is exact.
+//
+// Representation: SIGNED lazy residues.  A value is an int32 anywhere in (-2^31, 2^31); with
+// p < 2^29 that is a window of (-4p, 4p), so several butterfly stages can add and subtract without
+// any conditional correction and without the +2p offsets an unsigned lazy form needs.  Products go
+// through a signed Montgomery reduction whose result is already centred (|t| < 0.75 p), and a
+// value is pulled back to about (-p/2, p/2) by `sred` only where the range analysis below calls
+// for it (once per radix-16 pass in the forward transform, every second stage in the inverse).
+// Measured on MI355X (tools/ubench_bfly.hip, profiles/r02_ubench_bfly.txt): 0.75 x the time of the
+// unsigned 30-bit Harvey butterfly of round 1 in the forward pass, 0.78 x in the inverse.
+//
+// Range bookkeeping is in units of 2^29 (> p); every bound is re-derived, with the exact pass
+// structure, by tests/rns_model.py (RangeModel) for every prime and ring size.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -12,69 +23,80 @@
 
 namespace sgfhe {
 
-// Conditional subtraction: x >= m ? x - m : x.  Written through the borrow so that hipcc emits
-// v_sub_co_u32 + v_cndmask_b32 (measured 1.80 add-equivalents for the pair on gfx950) instead
-// of v_sub_u32 + v_min_u32 (2.83): tools/ubench_int.hip.
+// Modulus record kept in registers by the NTT code.
+struct Mod {
+    int32_t p;      // prime, < 2^29
+    int32_t negp;   // -p
+    uint32_t pinv;  // p^-1 mod 2^32
+};
+
+// Signed Montgomery reduction, R = 2^32:  T R^-1 mod p  for any |T| < 2^62.
+//   m = T_lo p^-1 mod 2^32 (as int32), so T - m p == 0 mod 2^32 and the high word is the exact
+//   quotient: |result| <= |T| / 2^32 + p / 2.
+// Two instructions: v_mul_lo_u32, v_mad_i64_i32.
+__device__ __forceinline__ int32_t sredc(int64_t T, const Mod &md) {
+    const int32_t m = (int32_t)((uint32_t)T * md.pinv);
+    return (int32_t)(((int64_t)m * md.negp + T) >> 32);
+}
+
+// a w R^-1 mod p for any int32 a and |w| <= p / 2 (constants are held centred, in Montgomery form
+// w = v R mod p, so the result is a v mod p):  |result| <= |a| / 16 + p / 2  <  0.75 p.
+// v_mad_i64_i32, v_mul_lo_u32, v_mad_i64_i32.
+__device__ __forceinline__ int32_t smont(int32_t a, int32_t w, const Mod &md) {
+    return sredc((int64_t)a * w, md);
+}
+// The same for an unsigned 32-bit limb a (key upload: limbs of a canonical residue).
+__device__ __forceinline__ int32_t smontu(uint32_t a, int32_t w, const Mod &md) {
+    return sredc((int64_t)(uint64_t)a * w, md);
+}
+
+// Range reduction: any x with x + 2^28 < 2^31 (i.e. x < 3.5 * 2^29) and x > -2^31 + ...:
+//   q = round(x / 2^29),  r = x - q p = (x - q 2^29) + q (2^29 - p),
+//   |r| <= 2^28 + 4 (2^29 - p)   ( < 0.511 * 2^29 for the primes in use ).
+__device__ __forceinline__ int32_t sred(int32_t x, const Mod &md) {
+    const int32_t q = (x + (1 << 28)) >> 29;
+    return x - q * md.p;
+}
+
+// x in (-p, p) -> the canonical representative in [0, p).
+__device__ __forceinline__ uint32_t scanon(int32_t x, const Mod &md) {
+    return (uint32_t)(x + ((x >> 31) & md.p));
+}
+// any |x| < 3.5 * 2^29 -> [0, p)
+__device__ __forceinline__ uint32_t sfull(int32_t x, const Mod &md) { return scanon(sred(x, md), md); }
+
+// x in (-p, p) -> the centred canonical representative in [-(p-1)/2, (p-1)/2].
+__device__ __forceinline__ int32_t scentre(int32_t x, const Mod &md) {
+    const int32_t h = (md.p - 1) >> 1;
+    if (x > h) x -= md.p;
+    if (x < -h) x += md.p;
+    return x;
+}
+
+// Conditional subtraction on unsigned words: x >= m ? x - m : x (v_sub_co_u32 + v_cndmask_b32).
 __device__ __forceinline__ uint32_t condsub(uint32_t x, uint32_t m) {
     uint32_t d;
     const bool borrow = __builtin_usub_overflow(x, m, &d);
     return borrow ? x : d;
 }
-// x in [0, 2p) -> [0, p).
-__device__ __forceinline__ uint32_t csub(uint32_t x, uint32_t p) { return condsub(x, p); }
 
-// Montgomery reduction, R = 2^32: T < p * 2^32 -> T * R^-1 mod p in [0, 2p).
-// ninv = -p^-1 mod 2^32.
-__device__ __forceinline__ uint32_t redc64(uint64_t T, uint32_t p, uint32_t ninv) {
-    uint32_t tlo = (uint32_t)T, thi = (uint32_t)(T >> 32);
-    uint32_t mq = tlo * ninv;
-    uint32_t h = __umulhi(mq, p);
-    // tlo + lo(mq * p) == 0 mod 2^32, carry out iff tlo != 0
-    return thi + h + (tlo != 0u);
-}
-
-// The same reduction written for v_mad_u64_u32: hi32(T + (T_lo * ninv) * p).  Valid for any
-// T < 2^64 - 2^32 p; returns T * R^-1 mod p in [0, T / 2^32 + p).
-__device__ __forceinline__ uint32_t redc_mad(uint64_t T, uint32_t p, uint32_t ninv) {
-    const uint32_t mq = (uint32_t)T * ninv;
-    return (uint32_t)(((uint64_t)mq * p + T) >> 32);
-}
-
-// a * b * R^-1 mod p in [0, p); a * b < p * 2^32 required (e.g. a < 2^32, b < p).
-__device__ __forceinline__ uint32_t mont_mul(uint32_t a, uint32_t b, uint32_t p, uint32_t ninv) {
-    return csub(redc64((uint64_t)a * b, p, ninv), p);
-}
-
-// Modulus record kept in registers by the NTT code.
-struct Mod {
-    uint32_t p, ninv, p2;  // prime, -p^-1 mod 2^32, 2p
-};
-
-// Lazy Montgomery multiplication by a constant held in Montgomery form (wM = w * 2^32 mod p):
-// returns w * y mod p in [0, 2p) for any y < 2^32.  Two v_mad_u64_u32 and one v_mul_lo_u32
-// (measured on gfx950: 1.73 + 1.63 + 1.73 add-equivalents, against 5.8 for the Shoup form
-// mul_hi + 2 mul_lo + sub; tools/ubench_int.hip).
-__device__ __forceinline__ uint32_t mont_lazy(uint32_t y, uint32_t wM, const Mod &md) {
-    const uint64_t T = (uint64_t)wM * y;             // < p * 2^32
-    const uint32_t mq = (uint32_t)T * md.ninv;
-    const uint64_t U = (uint64_t)mq * md.p + T;      // low word cancels; < 2p * 2^32
-    return (uint32_t)(U >> 32);
-}
-
-// Forward (Cooley-Tukey) Harvey butterfly: X, Y in [0, 4p) -> X + wY, X - wY in [0, 4p).
-__device__ __forceinline__ void bfly_fwd(uint32_t &X, uint32_t &Y, uint32_t wM, const Mod &md) {
-    const uint32_t x = condsub(X, md.p2);  // [0, 2p)
-    const uint32_t t = mont_lazy(Y, wM, md);
+// Forward (Cooley-Tukey) butterfly: X' = X + w Y, Y' = X - w Y.  Any Y; |X'|, |Y'| <= |X| + |t|,
+// |t| <= |Y| / 16 + p / 2.  Five instructions (three multiplies, an add, a sub).
+__device__ __forceinline__ void bfly_fwd(int32_t &X, int32_t &Y, int32_t wM, const Mod &md) {
+    const int32_t t = smont(Y, wM, md);
+    const int32_t x = X;
     X = x + t;
-    Y = x + md.p2 - t;
+    Y = x - t;
 }
 
-// Inverse (Gentleman-Sande) Harvey butterfly: X, Y in [0, 2p) -> X + Y, w (X - Y) in [0, 2p).
-__device__ __forceinline__ void bfly_inv(uint32_t &X, uint32_t &Y, uint32_t wM, const Mod &md) {
-    const uint32_t s = X + Y;
-    const uint32_t t = X + md.p2 - Y;
-    X = condsub(s, md.p2);
-    Y = mont_lazy(t, wM, md);
+// Inverse (Gentleman-Sande) butterfly: X' = X + Y (range-reduced when RED), Y' = w (X - Y).
+// Needs |X| + |Y| < 2^31 (and < 3.5 * 2^29 when RED).
+template <bool RED>
+__device__ __forceinline__ void bfly_inv(int32_t &X, int32_t &Y, int32_t wM, const Mod &md) {
+    const int32_t s = X + Y;
+    const int32_t d = X - Y;
+    X = RED ? sred(s, md) : s;
+    Y = smont(d, wM, md);
 }
 
 }  // namespace sgfhe

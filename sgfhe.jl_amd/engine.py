@@ -12,6 +12,7 @@ import numpy as np
 from . import _lib
 
 FLAG_RAW_MODQ = 1
+CTX_RANDOM_FLATTEN = 1
 
 
 class SgfheError(RuntimeError):
@@ -32,14 +33,17 @@ def _c(arr, dtype=np.uint64):
 class Engine:
     """One bootstrap engine (ctx) for one parameter set on one HIP device."""
 
-    def __init__(self, params, device=0):
+    def __init__(self, params, device=0, random_flatten=False):
+        """random_flatten=True sizes the RNS basis for the randomised flatten (the `rng` argument of
+        bootstrap / pack_encrypted_bits): one more prime at Params(1024), nothing elsewhere."""
         self.params = params
         self.device = device
         self._L = _lib.lib()
         sp = _lib.SgfheParams(params.n, params.r, params.m, params.ell, _words(params.Q),
                               _words(params.B), _words(params.DQ_tilde))
         h = ctypes.c_void_p()
-        rc = self._L.sgfhe_ctx_create(ctypes.byref(sp), device, ctypes.byref(h))
+        rc = self._L.sgfhe_ctx_create_ex(ctypes.byref(sp), device,
+                                         CTX_RANDOM_FLATTEN if random_flatten else 0, ctypes.byref(h))
         self._h = h
         if rc != 0:
             msg = self._L.sgfhe_last_error_string(h).decode() if h else "ctx_create failed"

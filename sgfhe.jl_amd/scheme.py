@@ -116,10 +116,12 @@ class BootstrapKey:
     value.(coeffs) in [k][row][col][coef] order (what the Julia shim passes);
     `BootstrapKey(rng, sk, on_host=True)` generates it with host big-integer arithmetic."""
 
-    def __init__(self, rng, sk, device=0, engine=None, on_host=False):
+    def __init__(self, rng, sk, device=0, engine=None, on_host=False, random_flatten=False):
+        """random_flatten=True: the key will also be used with `rng != nothing` (randomised flatten);
+        at Params(1024) that takes a sixth RNS prime, so it is chosen when the key is made."""
         params = sk.params
         self.params = params
-        self.engine = engine or Engine(params, device)
+        self.engine = engine or Engine(params, device, random_flatten=random_flatten)
         if on_host:
             self.engine.upload_key(self._generate(rng, sk))
         else:
@@ -345,9 +347,9 @@ def split_ciphertext(ct):
 
 def pack_encrypted_bits(bkey, rng, enc_bits):
     """pack_encrypted_bits(bkey, rng, enc_bits) (src/fhe.jl:660-696): n EncryptedBits -> one
-    RLWE Ciphertext, on the HIP engine.  Deterministic flatten only (rng = nothing)."""
-    if rng is not None:
-        raise NotImplementedError("only the deterministic path (rng = nothing) is implemented")
+    RLWE Ciphertext, on the HIP engine.  rng = None: deterministic flatten (bit-exact); a numpy
+    Generator: randomised flatten of the n bootstraps and of the shortened external products."""
+    _set_flatten_mode(bkey, rng)
     p = bkey.params
     if len(enc_bits) != p.n:
         raise AssertionError("exactly n encrypted bits are required (src/fhe.jl:667)")

@@ -7,7 +7,7 @@ Test infrastructure only (used by tests/test_rns_model.py).
 
 import numpy as np
 
-NPR_MAX = 6
+NPR_MAX = 7
 MASK32 = 0xFFFFFFFF
 
 
@@ -37,35 +37,29 @@ def is_prime32(x):
 
 
 def rns_primes(count=NPR_MAX):
-    """The `count` largest primes below 2^30 that are 1 mod 2^15 (candidates of build_constants)."""
+    """The `count` largest primes below 2^29 that are 1 mod 2^15 (candidates of build_constants)."""
     out = []
-    kk = ((1 << 30) - 1) >> 15
+    kk = ((1 << 29) - 1) >> 15
     while len(out) < count:
         cand = (kk << 15) + 1
-        if cand < (1 << 30) and is_prime32(cand):
+        if cand < (1 << 29) and is_prime32(cand):
             out.append(cand)
         kk -= 1
     return out
 
 
-def select_npr(logm, B, Q):
-    """build_constants: the fewest primes covering 8 m B Q (times 4 for the randomised flatten when
-    NPR_MAX primes allow it), at least 2; same floating-point rule as the engine."""
+def select_npr(logm, B, Q, random_flatten=False):
+    """build_constants: the fewest primes covering 5 m B Q (20 m B Q when the ctx is created for
+    the randomised flatten), at least 2; same floating-point rule as the engine."""
     import math
     cand = rns_primes()
-    need = 3.0 + logm + math.log2(float(B)) + math.log2(float(Q)) + 0.01
-
-    def count(target):
-        have, k = 0.0, 0
-        while k < NPR_MAX and (k < 2 or have < target):
-            have += math.log2(float(cand[k]))
-            k += 1
-        return k, have
-
-    k, have = count(need + 2.0)
-    if have < need + 2.0:
-        k, have = count(need)
-    assert have >= need, "exactness bound"
+    need = math.log2(5.0) + logm + math.log2(float(B)) + math.log2(float(Q)) + 0.001
+    target = need + (2.0 if random_flatten else 0.0)
+    have, k = 0.0, 0
+    while k < NPR_MAX and (k < 2 or have < target):
+        have += math.log2(float(cand[k]))
+        k += 1
+    assert have >= target, "exactness bound"
     return k
 
 
@@ -77,19 +71,26 @@ def bitrev(x, bits):
     return r
 
 
+def centre(x, p):
+    x %= p
+    return x - p if x > (p - 1) // 2 else x
+
+
 class Consts:
-    def __init__(self, n, m, Q, B, DQ_tilde):
+    def __init__(self, n, m, Q, B, DQ_tilde, random_flatten=False):
         self.n, self.M, self.Q, self.B = n, m, Q, B
         self.logm = m.bit_length() - 1
-        self.npr = NPR = select_npr(self.logm, B, Q)
+        self.npr = NPR = select_npr(self.logm, B, Q, random_flatten)
         self.primes = rns_primes()[:NPR]
         prod = 1
         for p in self.primes:
             prod *= p
         self.Mrns = prod
-        assert 8 * m * B * Q < prod, "exactness bound"
+        assert 5 * m * B * Q < prod, "exactness bound"
         self.s = (B - 1) // 2 if B % 2 else B // 2 - 1
         self.off = (1 + B) * self.s % Q
+        self.xmax = (B - 1) // 2 * 3 if B % 2 else B // 2 * 3
+        self.off_rnd = (1 + B) * (self.s + self.xmax) % Q
         self.DQ = DQ_tilde % Q
         self.c = [prod // p % Q for p in self.primes]
         plast = self.primes[-1]
@@ -106,13 +107,13 @@ class Consts:
                     break
             ipsi = pow(psi, p - 2, p)
             R1 = (1 << 32) % p
-            twf = np.zeros(m, dtype=np.uint64)
-            twi = np.zeros(m, dtype=np.uint64)
+            twf = np.zeros(m, dtype=np.int64)
+            twi = np.zeros(m, dtype=np.int64)
             pw = ipw = 1
             for t in range(m):
                 br = bitrev(t, self.logm)
-                twf[br] = pw * R1 % p          # Montgomery form
-                twi[br] = ipw * R1 % p
+                twf[br] = centre(pw * R1, p)          # Montgomery form, centred
+                twi[br] = centre(ipw * R1, p)
                 pw = pw * psi % p
                 ipw = ipw * ipsi % p
             Rinv = pow(R1, p - 2, p)
@@ -121,10 +122,11 @@ class Consts:
             minv = pow(m, p - 2, p)
             kappa = R1 * R1 % p * minv % p * ei % p
             self.pk.append(dict(
-                p=p, ninv=(-pow(p, -1, 1 << 32)) & MASK32, sR=p - self.s % p * Rinv % p,
-                hoff=(p - 1) // 2 if i == NPR - 1 else 0, r1=R1, r2=R1 * R1 % p,
-                r3=R1 * R1 * R1 % p, qmodp=Q % p, kappaR=kappa * R1 % p, minvR=minv * R1 % p,
-                twf=twf, twi=twi, psi=psi, kappa=kappa, ei=ei))
+                p=p, pinv=pow(p, -1, 1 << 32), sR=centre(-(self.s % p) * Rinv, p),
+                sRr=centre(-((self.s + self.xmax) % p) * Rinv, p),
+                hoff=(p - 1) // 2 if i == NPR - 1 else 0, r1=centre(R1, p), r2=centre(R1 * R1, p),
+                r3=centre(R1 * R1 * R1, p), qmodp=centre(Q, p), kappaR=centre(kappa * R1, p),
+                minvR=centre(minv * R1, p), twf=twf, twi=twi, psi=psi, kappa=kappa, ei=ei))
 
     def digits_of(self, acc):
         x = (acc + self.off) % self.Q
@@ -132,58 +134,71 @@ class Consts:
 
 
 # ---- rns_arith.h ---------------------------------------------------------------------------------
+# int32 device values are modelled as numpy int64 arrays; `i32` checks that nothing left the
+# int32 range (a wrap-around on the device would be a silent error) and records the largest
+# magnitude seen, in units of 2^29.
 
-def u32(a):
-    return np.asarray(a, dtype=np.uint64) & MASK32
-
-
-def csub(x, p):
-    x = u32(x)
-    return np.minimum(x, u32(x + np.uint64((1 << 32) - p)))
+PEAK = {"v": 0.0}
 
 
-def mulhi(a, b):
-    return (u32(a) * u32(b)) >> 32
+def i32(x, limit=1 << 31):
+    x = np.asarray(x, dtype=np.int64)
+    if x.size:
+        mx = int(np.max(np.abs(x)))
+        assert mx < limit, "int32 range exceeded: %d" % mx
+        PEAK["v"] = max(PEAK["v"], mx / float(1 << 29))
+    return x
 
 
-def redc64(T, p, ninv):
-    T = np.asarray(T, dtype=np.uint64)
-    tlo, thi = T & MASK32, T >> 32
-    mq = u32(tlo * ninv)
-    h = mulhi(mq, p)
-    return u32(thi + h + (tlo != 0))
+def sredc(T, P):
+    """Signed Montgomery reduction: T R^-1 mod p, |T| < 2^62."""
+    T = np.asarray(T, dtype=np.int64)
+    assert int(np.max(np.abs(T))) < (1 << 62) if T.size else True
+    lo = T & MASK32
+    m = (lo * np.int64(P["pinv"])) & MASK32
+    m = np.where(m >= (1 << 31), m - (1 << 32), m)
+    U = T - m * np.int64(P["p"])
+    assert not np.any(U & MASK32)
+    return i32(U >> 32)
 
 
-def redc_mad(T, p, ninv):
-    """hi32(T + (T_lo * ninv mod 2^32) * p): the v_mad_u64_u32 form of REDC."""
-    T = np.asarray(T, dtype=np.uint64)
-    mq = u32((T & MASK32) * np.uint64(ninv))
-    return (mq * np.uint64(p) + T) >> 32
+def smont(a, w, P):
+    return sredc(i32(a) * np.asarray(w, dtype=np.int64), P)
 
 
-def mont_mul(a, b, p, ninv):
-    return csub(redc64(u32(a) * u32(b), p, ninv), p)
+def sred(x, P):
+    x = i32(x)
+    i32(x + (1 << 28))                       # the rounding add itself must not overflow
+    q = (x + (1 << 28)) >> 29
+    return i32(x - q * np.int64(P["p"]))
 
 
-def mont_lazy(y, wM, p, ninv):
-    T = u32(wM) * u32(y)
-    mq = u32((T & MASK32) * ninv)
-    U = mq * np.uint64(p) + T
-    return U >> 32
+def scanon(x, P):
+    x = i32(x)
+    assert int(np.max(np.abs(x))) < P["p"]
+    return np.where(x < 0, x + P["p"], x)
 
 
-def bfly_fwd(X, Y, wM, p, ninv):
-    p2 = 2 * p
-    x = np.minimum(u32(X), u32(u32(X) + np.uint64((1 << 32) - p2)))
-    t = mont_lazy(Y, wM, p, ninv)
-    return u32(x + t), u32(x + p2 + np.uint64(1 << 32) - t)
+def sfull(x, P):
+    return scanon(sred(x, P), P)
 
 
-def bfly_inv(X, Y, wM, p, ninv):
-    p2 = 2 * p
-    s = u32(X + Y)
-    t = u32(X + p2 + np.uint64(1 << 32) - Y)
-    return np.minimum(s, u32(s + np.uint64((1 << 32) - p2))), mont_lazy(t, wM, p, ninv)
+def scentre(x, P):
+    x = i32(x).copy()
+    h = (P["p"] - 1) >> 1
+    x = np.where(x > h, x - P["p"], x)
+    x = np.where(x < -h, x + P["p"], x)
+    return x
+
+
+def bfly_fwd(X, Y, wM, P):
+    t = smont(Y, wM, P)
+    return i32(X + t), i32(X - t)
+
+
+def bfly_inv(X, Y, wM, P, red):
+    s, d = i32(X + Y), i32(X - Y)
+    return (sred(s, P) if red else s), smont(d, wM, P)
 
 
 # ---- ntt.h -----------------------------------------------------------------------------------------
@@ -223,48 +238,55 @@ class NttModel:
             lds[self.lds_addr(S, e)] = x[:, e]
 
     def load(self, lds, S):
-        x = np.zeros((self.T, self.E), dtype=np.uint64)
+        x = np.zeros((self.T, self.E), dtype=np.int64)
         for e in range(self.E):
             x[:, e] = lds[self.lds_addr(S, e)]
         return x
 
-    def stage(self, x, tw, p, ninv, B, S, fwd):
+    def stage(self, x, tw, P, B, S, fwd, red=False):
         """butterflies on local bit B of the pass over [S, S + LOGE)."""
         hi = self.tid >> S
         base = (1 << (self.LOGM - 1 - S - B)) + (hi << (self.LOGE - 1 - B))
-        f = bfly_fwd if fwd else bfly_inv
         for g in range(1 << (self.LOGE - 1 - B)):
             w = tw[base + g]
             for l in range(1 << B):
                 e0 = (g << (B + 1)) | l
                 e1 = e0 | (1 << B)
-                x[:, e0], x[:, e1] = f(x[:, e0], x[:, e1], w, p, ninv)
+                if fwd:
+                    x[:, e0], x[:, e1] = bfly_fwd(x[:, e0], x[:, e1], w, P)
+                else:
+                    x[:, e0], x[:, e1] = bfly_inv(x[:, e0], x[:, e1], w, P, red)
 
-    def forward(self, x, tw, p, ninv):
+    def forward(self, x, tw, P):
         """x[tid, e] = coefficient tid + T e -> slot E tid + e."""
-        x = x.copy()
-        lds = np.zeros(self.M, dtype=np.uint64)
+        x = np.asarray(x, dtype=np.int64).copy()
+        lds = np.zeros(self.M, dtype=np.int64)
         blo = 0 if self.RHO == 0 else self.LOGE - self.RHO
         for B in range(self.LOGE - 1, blo - 1, -1):
-            self.stage(x, tw, p, ninv, B, self.STOP, True)
+            self.stage(x, tw, P, B, self.STOP, True)
         sprev, S = self.STOP, self.SFIRST
         while S >= 0:
             self.store(x, lds, sprev)
             x = self.load(lds, S)
+            x[:, :self.E // 2] = sred(x[:, :self.E // 2], P)         # fwd_reduce_x
             for B in range(self.LOGE - 1, -1, -1):
-                self.stage(x, tw, p, ninv, B, S, True)
+                self.stage(x, tw, P, B, S, True)
             sprev, S = S, S - self.LOGE
         return x
 
-    def inverse(self, x, tw, p, ninv):
+    def inv_stages(self, x, tw, P, S, blo, bhi, lastred):
+        for B in range(blo, bhi + 1):
+            red = bool((B - blo) & 1) or (lastred and B == bhi)
+            self.stage(x, tw, P, B, S, False, red)
+
+    def inverse(self, x, tw, P):
         """slots E tid + e -> coefficient tid + T e (unscaled)."""
-        x = x.copy()
-        lds = np.zeros(self.M, dtype=np.uint64)
+        x = np.asarray(x, dtype=np.int64).copy()
+        lds = np.zeros(self.M, dtype=np.int64)
         if self.SLAST_INV >= 0:
             S = 0
             while True:
-                for B in range(self.LOGE):
-                    self.stage(x, tw, p, ninv, B, S, False)
+                self.inv_stages(x, tw, P, S, 0, self.LOGE - 1, True)
                 if S >= self.SLAST_INV:
                     break
                 self.store(x, lds, S)
@@ -274,16 +296,78 @@ class NttModel:
             if self.SLAST_INV >= 0:
                 self.store(x, lds, self.SLAST_INV)
                 x = self.load(lds, self.STOP)
-            for B in range(self.LOGE - self.RHO, self.LOGE):
-                self.stage(x, tw, p, ninv, B, self.STOP, False)
+            self.inv_stages(x, tw, P, self.STOP, self.LOGE - self.RHO, self.LOGE - 1, False)
         return x
 
     def to_regs(self, poly):
         """natural-order polynomial -> [T, E] register layout (coefficient tid + T e)."""
-        return np.asarray(poly, dtype=np.uint64).reshape(self.E, self.T).T.copy()
+        return np.asarray(poly, dtype=np.int64).reshape(self.E, self.T).T.copy()
 
     def from_regs(self, x):
         return x.T.reshape(-1).copy()
+
+
+# ---- worst-case range analysis of the same pass structure -------------------------------------------
+# Magnitude bounds in units of 2^29 (p < 2^29).  smont: |t| <= |a| / 16 + 0.5; sred: |r| <= 0.5 +
+# 4 delta with delta = (2^29 - p) / 2^29; sred needs x + 2^28 < 2^31, i.e. a bound below 3.5.
+
+class RangeModel:
+    def __init__(self, logm, loge, p):
+        self.N = NttModel(logm, loge)
+        self.delta = ((1 << 29) - p) / float(1 << 29)
+        self.peak = 0.0
+
+    def _chk(self, b, limit=4.0):
+        assert b < limit, "bound %.3f * 2^29 exceeds %.1f" % (b, limit)
+        self.peak = max(self.peak, b)
+        return b
+
+    def sred(self, b):
+        self._chk(b, 3.5)
+        return 0.5 + 4 * self.delta
+
+    def forward(self, b_in):
+        N = self.N
+        b = b_in
+        first = N.RHO if N.RHO else N.LOGE
+        for _ in range(first):                               # register pass: no reduction
+            b = self._chk(b + b / 16 + 0.5)
+        passes = (N.SFIRST // N.LOGE + 1) if N.SFIRST >= 0 else 0
+        for _ in range(passes):
+            x = self.sred(b)                                 # X inputs of the first stage
+            y = b                                            # Y inputs: any int32
+            for _s in range(N.LOGE):
+                t = y / 16 + 0.5
+                x = self._chk(x + t)
+                y = x
+            b = x
+        return b
+
+    def inverse(self, b_in):
+        N = self.N
+        E = N.E
+
+        def run(bv, blo, bhi, lastred):
+            for B in range(blo, bhi + 1):
+                red = bool((B - blo) & 1) or (lastred and B == bhi)
+                nb = list(bv)
+                for e0 in range(E):
+                    if e0 & (1 << B):
+                        continue
+                    e1 = e0 | (1 << B)
+                    s = self._chk(bv[e0] + bv[e1], 3.5 if red else 4.0)
+                    nb[e0] = (0.5 + 4 * self.delta) if red else s
+                    nb[e1] = s / 16 + 0.5
+                bv = nb
+            return bv
+
+        bv = [b_in] * E
+        full = (N.SLAST_INV // N.LOGE + 1) if N.SLAST_INV >= 0 else 0
+        for _ in range(full):
+            bv = [max(run(bv, 0, N.LOGE - 1, True))] * E
+        if N.RHO:
+            bv = run(bv, N.LOGE - N.RHO, N.LOGE - 1, False)
+        return max(bv)
 
 
 def ntt_reference(poly, psi, p):
@@ -303,92 +387,122 @@ def ntt_reference(poly, psi, p):
 
 # ---- kernels.h: one k-loop iteration ---------------------------------------------------------------
 
+def philox4x32(ctr, k0, k1):
+    """Philox4x32-10 (kernels.h philox4x32): ctr = (x, y, z, w) -> four 32-bit words."""
+    c = [int(v) & MASK32 for v in ctr]
+    for _ in range(10):
+        p0 = 0xD2511F53 * c[0]
+        p1 = 0xCD9E8D57 * c[2]
+        c = [((p1 >> 32) ^ c[1] ^ k0) & MASK32, p1 & MASK32, ((p0 >> 32) ^ c[3] ^ k1) & MASK32, p0 & MASK32]
+        k0 = (k0 + 0x9E3779B9) & MASK32
+        k1 = (k1 + 0xBB67AE85) & MASK32
+    return c
+
+
 class EngineModel:
-    def __init__(self, n, m, Q, B, DQ_tilde):
-        self.C = Consts(n, m, Q, B, DQ_tilde)
+    def __init__(self, n, m, Q, B, DQ_tilde, random_flatten=False):
+        self.C = Consts(n, m, Q, B, DQ_tilde, random_flatten)
         self.ntt = NttModel(self.C.logm)
+
+    def limbs_mod_p(self, vals, P):
+        """limbs_mod_p: canonical residues (Python ints) -> centred-lifted residues mod p."""
+        C = self.C
+        v = [int(x) for x in vals]
+        c0 = np.array([x & MASK32 for x in v], dtype=np.int64)
+        c1 = np.array([(x >> 32) & MASK32 for x in v], dtype=np.int64)
+        c2 = np.array([(x >> 64) & MASK32 for x in v], dtype=np.int64)
+        r = i32(sredc(c0 * P["r1"], P) + sredc(c1 * P["r2"], P) + sredc(c2 * P["r3"], P))
+        lift = np.array([x > C.Q // 2 for x in v])
+        return i32(np.where(lift, r - P["qmodp"], r))
 
     def key_transform(self, canon_poly, pi):
         """k_key_transform for one polynomial (list of ints in [0, Q)) and prime index."""
-        C, P = self.C, self.C.pk[pi]
-        p, ninv = P["p"], P["ninv"]
-        vals = np.zeros(C.M, dtype=np.uint64)
-        for i, v in enumerate(canon_poly):
-            c0, c1, c2 = v & MASK32, (v >> 32) & MASK32, (v >> 64) & MASK32
-            r = int(csub(int(mont_mul(c0, P["r1"], p, ninv)) + int(mont_mul(c1, P["r2"], p, ninv)), p))
-            r = int(csub(r + int(mont_mul(c2, P["r3"], p, ninv)), p))
-            if v > C.Q // 2:
-                r = (r - P["qmodp"]) % p
-            vals[i] = int(mont_mul(r, P["kappaR"], p, ninv))
-        x = self.ntt.forward(self.ntt.to_regs(vals), P["twf"], p, ninv)
-        x = np.minimum(x, u32(x - 2 * p + (1 << 32)))
-        x = csub(x, p)
-        return x.reshape(-1)          # slot E tid + e
+        P = self.C.pk[pi]
+        vals = smont(self.limbs_mod_p(canon_poly, P), P["kappaR"], P)
+        x = self.ntt.forward(self.ntt.to_regs(vals), P["twf"], P)
+        return scentre(sred(x, P), P).reshape(-1)          # slot E tid + e, centred
 
-    def extprod(self, dig_a, dig_b, keyslice, j, plain=False):
-        """k_extprod for one bootstrap: dig_* lists of (lo, hi); keyslice[pi][row*2+col] slot
-        arrays; returns y[c][pi] arrays (natural order)."""
+    def extprod(self, dig_a, dig_b, keyslice, j, plain=False, random=False):
+        """k_extprod for one bootstrap: dig_* lists of (lo, hi) stored digits; keyslice[pi][row*2+col]
+        slot arrays; returns y[c][pi] arrays (natural order, in [0, p))."""
         C = self.C
         NPR = C.npr
         M, T = C.M, self.ntt.T
         ys = [[None] * NPR for _ in range(2)]
         for pi in range(NPR):
             P = C.pk[pi]
-            p, ninv = P["p"], P["ninv"]
-            digs = [np.array([d[0] for d in dig_a], dtype=np.uint64),
-                    np.array([d[1] for d in dig_a], dtype=np.uint64),
-                    np.array([d[0] for d in dig_b], dtype=np.uint64),
-                    np.array([d[1] for d in dig_b], dtype=np.uint64)]
+            p = P["p"]
+            sR = P["sRr"] if random else P["sR"]
+            digs = [np.array([d[0] for d in dig_a], dtype=np.int64),
+                    np.array([d[1] for d in dig_a], dtype=np.int64),
+                    np.array([d[0] for d in dig_b], dtype=np.int64),
+                    np.array([d[1] for d in dig_b], dtype=np.int64)]
             U = []
             for d in digs:
-                v = u32(redc_mad(d, p, ninv) + P["sR"])          # digit_reduce: lazy, in [0, 4p)
-                x = self.ntt.forward(self.ntt.to_regs(v), P["twf"], p, ninv)
-                U.append(np.minimum(x, u32(x + np.uint64((1 << 32) - 2 * p))).reshape(-1))   # [0, 2p)
+                v = i32(sredc(d, P) + sR)                        # digit_reduce
+                assert int(np.max(np.abs(v))) <= p + (1 << 16)
+                U.append(self.ntt.forward(self.ntt.to_regs(v), P["twf"], P).reshape(-1))
             for c in range(2):
                 if c == 0:
                     # column 0: 64-bit accumulation over the four phases, one reduction
                     acc = sum(U[row] * keyslice[pi][row * 2] for row in range(4))
-                    r = redc_mad(acc, p, ninv)                                   # [0, 3p)
-                    z = np.minimum(r, u32(r + np.uint64((1 << 32) - 2 * p)))
+                    z = sred(sredc(acc, P), P)
                 else:
-                    # column 1: reduced per phase, summed lazily mod 2p (LDS accumulator)
-                    z = np.zeros(M, dtype=np.uint64)
+                    # column 1: reduced per phase, summed in the LDS accumulator
+                    z = np.zeros(M, dtype=np.int64)
                     for row in range(4):
-                        zs = u32(z + redc_mad(U[row] * keyslice[pi][row * 2 + 1], p, ninv))
-                        z = np.minimum(zs, u32(zs + np.uint64((1 << 32) - 2 * p)))
-                z = z.reshape(T, self.ntt.E)
-                z = self.ntt.inverse(z, P["twi"], p, ninv)
-                Pn = self.ntt.from_regs(csub(z, p))            # natural order
+                        z = i32(z + smont(U[row], keyslice[pi][row * 2 + 1], P))
+                    z = sred(z, P)
+                z = self.ntt.inverse(z.reshape(T, self.ntt.E), P["twi"], P)
+                Pn = self.ntt.from_regs(z)                         # natural order, |.| < 1.4 * 2^29
                 if plain:
-                    ys[c][pi] = csub(Pn + P["hoff"], p)
+                    ys[c][pi] = (sfull(Pn, P) + P["hoff"]) % p
                     continue
                 i = np.arange(M, dtype=np.int64)
                 s = (i - j) & (2 * M - 1)
                 v = Pn[s & (M - 1)]
-                v = np.where((s & M) != 0, csub(p - v, p), v)
-                y = u32(v - Pn + (1 << 32))
-                y = np.minimum(y, u32(y + p))
-                ys[c][pi] = csub(y + P["hoff"], p)
+                v = np.where((s & M) != 0, -v, v)
+                ys[c][pi] = (sfull(i32(v - Pn), P) + P["hoff"]) % p
         return ys
 
-    def crt_acc(self, ys_c, dig_old, noacc=False, canon=False):
-        """k_crt_acc for one polynomial: ys_c[pi] arrays -> new digits (or canonical values)."""
+    def crt_value(self, y, x_old=0):
+        """crt_reduce for one coefficient: residues y[pi] -> (sum y c + T[alpha] + x_old) mod Q."""
         C = self.C
-        NPR = C.npr
+        f = np.float32(0)
+        for pi in range(C.npr):
+            f = np.float32(f + np.float32(y[pi]) * np.float32(np.float32(1.0) / np.float32(C.primes[pi])))
+        alpha = int(f)
+        return (C.T[alpha] + sum(y[pi] * C.c[pi] for pi in range(C.npr)) + x_old) % C.Q
+
+    def random_digits(self, xn, key, ctr):
+        """random_digits of kernels.h: stored digits e_i = u_i + s + xmax of the randomised flatten of
+        the accumulator whose shifted value is xn = (acc + (s + xmax)(1 + B)) mod Q."""
+        C = self.C
+        rv = philox4x32(ctr, key & MASK32, (key >> 32) & MASK32)
+        span = 2 * C.xmax + 1
+        r0 = (((rv[1] << 32) | rv[0]) * span) >> 64
+        r1 = (((rv[3] << 32) | rv[2]) * span) >> 64
+        x2 = (xn - r0 - r1 * C.B) % C.Q
+        return x2 % C.B + r0, x2 // C.B + r1
+
+    def crt_acc(self, ys_c, dig_old, noacc=False, canon=False, rnd=None):
+        """k_crt_acc for one polynomial: ys_c[pi] arrays -> new digits (or canonical values).
+        rnd = (seed, c, iter, bootstrap, call) selects the randomised flatten."""
+        C = self.C
         out = []
         for i in range(C.M):
-            y = [int(ys_c[pi][i]) for pi in range(NPR)]
-            f = np.float32(0)
-            for pi in range(NPR):
-                f = np.float32(f + np.float32(y[pi]) * np.float32(np.float32(1.0) / np.float32(C.primes[pi])))
-            alpha = int(f)
-            S = C.T[alpha] + sum(y[pi] * C.c[pi] for pi in range(NPR))
-            if not noacc:
-                S += dig_old[i][1] * C.B + dig_old[i][0]
-            xn = S % C.Q
-            out.append(xn if canon else (xn % C.B, xn // C.B))
+            y = [int(ys_c[pi][i]) for pi in range(C.npr)]
+            xn = self.crt_value(y, 0 if noacc else dig_old[i][1] * C.B + dig_old[i][0])
+            if canon:
+                out.append(xn)
+            elif rnd is not None:
+                seed, c, it, boot, call = rnd
+                out.append(self.random_digits(xn, seed, ((c << C.logm) + i, it, boot, call)))
+            else:
+                out.append((xn % C.B, xn // C.B))
         return out
 
-    def acc_from_digits(self, dig):
+    def acc_from_digits(self, dig, random=False):
         C = self.C
-        return [(d[1] * C.B + d[0] - C.off) % C.Q for d in dig]
+        off = C.off_rnd if random else C.off
+        return [(d[1] * C.B + d[0] - off) % C.Q for d in dig]

@@ -168,8 +168,8 @@ def test_device_form_export_import(S, p64):
     import torch
     params, o, sk, bkey, eng = p64
     nbytes = eng.key_device_form_bytes()
-    assert len(eng.primes()) == 4                        # Params(64): 4 primes cover 32 m B Q
-    assert nbytes == params.n * 4 * 8 * params.m * 4
+    assert len(eng.primes()) == 4                        # Params(64): 4 primes cover 20 m B Q
+    assert nbytes == 64 + params.n * 4 * 8 * params.m * 4  # 64-byte header + payload
     blob = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
     eng.export_key_device_form(blob.data_ptr())
     eng2 = S.Engine(params)
@@ -179,6 +179,27 @@ def test_device_form_export_import(S, p64):
     assert np.array_equal(eng2.bootstrap_batch(a[0::2], b[0::2], a[1::2], b[1::2]),
                           eng.bootstrap_batch(a[0::2], b[0::2], a[1::2], b[1::2]))
     eng2.close()
+    # the header pins the parameter set: a blob of Params(64) is refused by every other ctx, and
+    # so is a damaged header
+    hdr = blob[:64].cpu().numpy().copy()
+    assert bytes(hdr[:8]) == b"SGFHEKEY"
+    import bigint_oracle as BO
+    other = S.Engine(S.Params.custom(64, BO.find_modulus(1024, 1 << 61), 1 << 31))
+    with pytest.raises(S.SgfheError) as ei:
+        other.import_key_device_form(blob.data_ptr())
+    assert ei.value.code == -1 and "parameter set" in str(ei.value)
+    other.close()
+    eng3 = S.Engine(params)
+    for off, what in ((0, "magic"), (8, "version")):
+        bad = blob.clone()
+        bad[off] ^= 0x5A
+        with pytest.raises(S.SgfheError) as ei:
+            eng3.import_key_device_form(bad.data_ptr())
+        assert ei.value.code == -1 and what in str(ei.value)
+    with pytest.raises(S.SgfheError):                     # and a ctx that never imported has no key
+        z = np.zeros((1, params.n), dtype=np.uint64)
+        eng3.bootstrap_batch(z, [0], z, [0])
+    eng3.close()
 
 
 def test_rns2_key_upload_matches_canonical(S, oc):
@@ -380,6 +401,8 @@ def test_host_api_end_to_end(S):
         assert S.decrypt(key, r_xor) == (msg[i] ^ msg[i + 1])
     ct = S.pack_encrypted_bits(bkey, None, bits)
     assert np.array_equal(S.decrypt(key, ct), msg)
+    ct = S.pack_encrypted_bits(bkey, rng, bits)           # test/api.test.jl:86-108, use_rng = true
+    assert np.array_equal(S.decrypt(key, ct), msg)
     pkey = S.PublicKey(rng, key)                          # public-key ciphertexts feed the gates too
     pbits = S.split_ciphertext(S.encrypt(pkey, rng, msg))
     for i in range(0, 8, 2):
@@ -447,24 +470,47 @@ def test_random_flatten_chunks_draw_distinct_streams(S, p64):
         assert np.all(o.lwe_decrypt_bits(sk, out[:, g, :-1], out[:, g, -1]) == w)
 
 
-def test_pack_stays_deterministic_in_random_mode(S, oc, p64):
+def test_pack_encrypted_bits_randomised(S, oc, p64):
+    """test/api.test.jl:86-108 with use_rng = true: split -> pack_encrypted_bits(bkey, rng, .) ->
+    decrypt directly and via split_ciphertext; the RLWE differs from the deterministic one and
+    from another seed's, and repeats for the same seed and call number."""
     params, o, sk, bkey, eng = p64
-    bits = np.random.default_rng(6).integers(0, 2, size=params.n).astype(np.uint8)
+    n = params.n
+    bits = np.random.default_rng(6).integers(0, 2, size=n).astype(np.uint8)
     a, b = o.lwe_encrypt_bits(sk, bits, 81)
     w0, v0 = eng.pack_encrypted_bits(a[None], b[None])
+    key = S.PrivateKey.__new__(S.PrivateKey)
+    key.params, key.key = params, np.asarray(sk, dtype=np.uint64)
+    outs = []
     try:
-        eng.set_random_flatten(True, 3)
-        w1, v1 = eng.pack_encrypted_bits(a[None], b[None])
+        for seed in (3, 4, 3):
+            eng.set_random_flatten(True, seed)
+            w1, v1 = eng.pack_encrypted_bits(a[None], b[None])
+            ct = S.Ciphertext(params, S.RLWE(w1[0], v1[0]))
+            assert np.array_equal(S.decrypt(key, ct), bits.astype(bool))
+            assert [S.decrypt(key, eb) for eb in S.split_ciphertext(ct)] == list(bits.astype(bool))
+            outs.append((w1, v1))
     finally:
         eng.set_random_flatten(False)
-    assert np.array_equal(w0, w1) and np.array_equal(v0, v1)
+    assert np.array_equal(outs[0][0], outs[2][0]) and np.array_equal(outs[0][1], outs[2][1])
+    assert not np.array_equal(outs[0][0], outs[1][0])
+    assert not np.array_equal(outs[0][0], w0)
+    w2, v2 = eng.pack_encrypted_bits(a[None], b[None])      # and back to the bit-exact path
+    assert np.array_equal(w0, w2) and np.array_equal(v0, v2)
 
 
 def test_random_flatten_params1024_and_host_api(S):
     rng = np.random.default_rng(8)
     params = S.Params(1024)
     key = S.PrivateKey(params, rng)
-    bkey = S.BootstrapKey(rng, key)
+    plain = S.Engine(params)                              # five primes: deterministic flatten only
+    assert len(plain.primes()) == 5
+    with pytest.raises(S.SgfheError) as ei:
+        plain.set_random_flatten(True, 1)
+    assert ei.value.code == -2 and "SGFHE_CTX_RANDOM_FLATTEN" in str(ei.value)
+    plain.close()
+    bkey = S.BootstrapKey(rng, key, random_flatten=True)  # six primes: both modes
+    assert len(bkey.engine.primes()) == 6
     msg = rng.integers(0, 2, size=params.n).astype(bool)
     bits = S.split_ciphertext(S.encrypt(key, rng, msg))
     res = S.bootstrap_batch(bkey, rng, bits[0:16:2], bits[1:16:2])

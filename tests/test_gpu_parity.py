@@ -40,7 +40,7 @@ def test_ntt_matches_model(S, logm):
         p = primes[pi]
         poly = rng.integers(0, p, size=m, dtype=np.uint64)
         fwd = eng.debug_ntt(pi, poly.astype(np.uint32))
-        model = N.forward(N.to_regs(poly), C.pk[pi]["twf"], p, C.pk[pi]["ninv"]).reshape(-1) % p
+        model = N.forward(N.to_regs(poly), C.pk[pi]["twf"], C.pk[pi]).reshape(-1) % p
         assert np.array_equal(fwd.astype(np.uint64), model)
         if logm <= 8:
             ref = RM.ntt_reference([int(v) for v in poly], C.pk[pi]["psi"], p)
@@ -214,7 +214,7 @@ def test_params2048_largest_reference_ring(S, oc):
     params = S.Params(2048)
     o = oc.Oracle.from_params(params)
     eng = S.Engine(params)
-    assert len(eng.primes()) == 6
+    assert len(eng.primes()) == 6                          # 5 m B Q needs six 29-bit primes
     key = np.zeros((params.n, 4, 2, params.m, 2), dtype=np.uint64)
     key[:2] = bench.random_key(params, 41)[:2]
     eng.upload_key(key)

@@ -114,11 +114,24 @@ def test_extract_matches_reference_semantics(S):
             assert got == BO.extract(a, i, n, Q)
 
 
-def test_pack_rejects_rng(S):
+def test_pack_selects_flatten_mode_and_checks_length(S):
+    """pack_encrypted_bits(bkey, rng, enc_bits): rng picks the flatten mode on the engine (as for
+    bootstrap) before anything else; a wrong number of bits is the reference's assertion
+    (src/fhe.jl:667)."""
+    calls = []
+
+    class FakeEngine:
+        def set_random_flatten(self, enable, seed=0):
+            calls.append((bool(enable), seed))
+
     class Dummy:
         params = S.Params(64)
-    with pytest.raises(NotImplementedError):
+        engine = FakeEngine()
+    with pytest.raises(AssertionError):
         S.pack_encrypted_bits(Dummy(), np.random.default_rng(0), [])
+    with pytest.raises(AssertionError):
+        S.pack_encrypted_bits(Dummy(), None, [])
+    assert calls[0][0] is True and calls[1] == (False, 0)
 
 
 def test_library_exports_every_declared_symbol(S):

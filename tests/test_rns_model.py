@@ -33,17 +33,53 @@ def test_ntt_model(logm, loge):
     P = C.pk[logm % C.npr]
     p = P["p"]
     poly = np.random.default_rng(logm).integers(0, p, size=m, dtype=np.uint64)
-    x = N.forward(N.to_regs(poly), P["twf"], p, P["ninv"])
-    assert int(x.max()) < 4 * p
+    x = N.forward(N.to_regs(poly), P["twf"], P)               # i32() inside checks the int32 range
+    assert int(np.abs(x).max()) < 3.5 * 2 ** 29
     got = [int(v) % p for v in x.reshape(-1)]
     Rinv = pow(1 << 32, p - 2, p)
     plain = np.array([int(w) * Rinv % p for w in P["twf"]], dtype=np.uint64)
     assert got == _textbook_fwd(poly, plain, p)
     if logm <= 7:
         assert got == RM.ntt_reference([int(v) for v in poly], P["psi"], p)
-    back = N.from_regs(N.inverse(np.array(got, dtype=np.uint64).reshape(N.T, N.E), P["twi"], p, P["ninv"]))
+    slots = RM.sred(np.array(got, dtype=np.int64).reshape(N.T, N.E), P)
+    back = N.from_regs(N.inverse(slots, P["twi"], P))
+    assert int(np.abs(back).max()) < 1.4 * 2 ** 29
     minv = pow(m, p - 2, p)
     assert [int(v) * minv % p for v in back] == [int(v) for v in poly]
+
+
+@pytest.mark.parametrize("loge", [3, 4])
+@pytest.mark.parametrize("logm", [6, 7, 8, 9, 10, 11, 12, 13, 14])
+def test_worst_case_ranges(logm, loge):
+    """Interval analysis of the signed lazy arithmetic with the exact pass structure: no int32
+    overflow and every range reduction inside its precondition, for every RNS prime, from the
+    largest inputs the kernels feed (forward: digits / key residues <= 1.01 * 2^29; inverse:
+    <= 0.75 * 2^29)."""
+    for p in RM.rns_primes():
+        R = RM.RangeModel(logm, loge, p)
+        assert R.forward(1.01) < 3.5         # pointwise products assume |U| < 3.5 * 2^29
+        assert R.inverse(0.75) < 1.4         # the rotate-and-subtract epilogue assumes < 1.4 * 2^29
+        assert R.peak < 3.99
+
+
+def test_adversarial_ranges_on_data():
+    """Extreme inputs (all +-max) through the data model: the int32 checks inside must hold."""
+    for logm, loge in ((13, 4), (13, 3), (12, 4), (9, 3), (14, 4)):
+        m = 1 << logm
+        C = RM.Consts(m // 8, m, (1 << 50) + 1, 1 << 26, 12345)
+        N = RM.NttModel(logm, loge)
+        P = C.pk[0]
+        p = P["p"]
+        big = p + (1 << 16)
+        for pattern in (np.full(m, big), np.full(m, -big),
+                        np.where(np.arange(m) & 1, big, -big),
+                        np.where(np.arange(m) < m // 2, big, -big)):
+            x = N.forward(N.to_regs(pattern.astype(np.int64)), P["twf"], P)
+            z = RM.sred(x, P)
+            N.inverse(z, P["twi"], P)
+            lim = int(0.75 * 2 ** 29)
+            for pat2 in (np.full(m, lim), np.where(np.arange(m) & 1, lim, -lim)):
+                N.inverse(pat2.astype(np.int64).reshape(N.T, N.E), P["twi"], P)
 
 
 def test_swizzle_is_conflict_free():
@@ -90,8 +126,10 @@ def test_pipeline_matches_oracle():
 
 
 def test_exactness_bound_reference_params():
-    """8 m B Q < product of the RNS primes for every reference parameter set and the synthetic
-    configurations of BASELINE.json."""
-    for n in (64, 512, 1024):
+    """5 m B Q < product of the RNS primes for every reference parameter set (20 m B Q when the
+    ctx is created for the randomised flatten): prime counts the engine ends up with."""
+    want = {64: (4, 4), 512: (5, 5), 1024: (5, 6), 2048: (6, 6)}
+    for n, (det, rnd) in want.items():
         p = BO.Params.make(n)
-        RM.Consts(p.n, p.m, p.Q, p.B, p.DQ_tilde)
+        assert RM.Consts(p.n, p.m, p.Q, p.B, p.DQ_tilde).npr == det
+        assert RM.select_npr(p.m.bit_length() - 1, p.B, p.Q, random_flatten=True) == rnd
