@@ -4,20 +4,30 @@
 One "step" = one pass of the hot path (`bootstrap()` of nucypher/SGFHE.jl,
 /root/reference/src/fhe.jl:608-621) over one batch of independent gate bootstraps resident in
 HBM.  Default workload: the reference's own Params(1024) (Q = 92180593745615474572738561,
-86.25-bit prime; SURVEY.md config 4'), batch 4096 per GPU, synthetic uniformly random bootstrap
-LWE inputs and a bootstrap key generated on the device from a fixed seed (a valid key of a
-random secret; sgfhe_bkey_generate).
+86.25-bit prime; SURVEY.md config 4'), batch 4096 per GPU (8192 per GPU on 8 GPUs = config 5's
+65536), synthetic uniformly random bootstrap LWE inputs and a bootstrap key generated on the
+device from a fixed seed (a valid key of a random secret; sgfhe_bkey_generate).
 
-Multi-GPU (launched by torch.distributed.run, one rank per GPU): the batch shards across ranks,
-rank 0 builds the device-form key and broadcasts it once over RCCL; there is no collective in
-the timed region ("scaling": "weak").
+Other workloads (parity-test cases, `--config`): params512 (config 2, use --batch 1024), synth64
+(config 3: n = 1024 over a 64-bit prime), rns2 (config 4: n = 1024 over the composite
+Q = B * Bp of two 43-bit NTT primes, the RNS2Number ring of src/rns.jl / src/fhe2.jl:57-60),
+params64, params2048.
+
+Multi-GPU: `python bench.py --gpus N` starts N ranks itself (torch.distributed.run, one per GPU,
+rendezvous on 127.0.0.1) when it was not already started by a launcher; the batch shards across
+ranks, rank 0 builds the device-form key and broadcasts it once over RCCL; there is no
+collective in the timed region ("scaling": "weak").
 
 Prints ONE JSON line on rank 0.
 """
 
 import argparse
+import glob
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -27,7 +37,20 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_HBM_GBS = 8000.0     # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
-W_BYTES = {"params1024": 16, "params512": 16, "params2048": 16, "params64": 8, "synth64": 8}
+W_BYTES = {"params1024": 16, "params512": 16, "params2048": 16, "params64": 8, "synth64": 8,
+           "rns2": 16}
+
+
+def rns2_moduli(S, n=1024):
+    """BASELINE.json config 4: two NTT-friendly primes Bp < B, both 1 mod r, from the rule of
+    src/fhe2.jl:57-58 (find_modulus(r, bound), then the next one) with bound = ceil(sqrt(1220
+    r^4 n^2)) so that Q = B Bp keeps the noise margin of Params(n)."""
+    import math
+    r = 16 * n
+    bound = math.isqrt(1220 * r ** 4 * n ** 2) + 1
+    Bp = S.find_modulus(r, bound)
+    B = S.find_modulus(r, Bp + 1)
+    return B, Bp
 
 
 def make_params(S, name):
@@ -43,6 +66,9 @@ def make_params(S, name):
         m = 8192
         Q = S.find_modulus(2 * m, (1 << 63) - (1 << 40))
         return S.Params.custom(1024, Q, 1 << 32)
+    if name == "rns2":      # BASELINE.json config 4: composite Q = B * Bp, gadget base B
+        B, Bp = rns2_moduli(S)
+        return S.Params.custom(1024, B * Bp, B)
     raise SystemExit("unknown --config " + name)
 
 
@@ -66,49 +92,60 @@ def algorithmic_bytes_per_bootstrap(p, W, batch):
     return p.n * p.m * W * (4 + 8.0 / batch) + 40 * (p.n + 1)
 
 
+def source_hash():
+    """Hash of the kernel sources the loaded library was built from: profile counters are only
+    quoted when they were collected on the same code (tools/summarize_profile.py stamps them)."""
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "sgfhe.jl_amd", "csrc")
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith((".h", ".hip")):
+            h.update(f.encode())
+            h.update(open(os.path.join(csrc, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def _counters(config, chunk):
     """Per-launch PMC averages of the newest committed profile (tools/profile_round.sh collects
-    them in separate profiler runs, not inside this process).  None unless they match this
-    workload (Params(1024), same chunk)."""
+    them in separate profiler runs, not inside this process).  Returns (counters, reason)."""
     if config != "params1024":
-        return None
-    import glob
+        return None, "counters are collected for the params1024 workload only"
+    want = source_hash()
+    stale = None
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_counters.json")), reverse=True):
         with open(path) as f:
             d = json.load(f)
-        if d.get("chunk", 256) == chunk:
-            return dict(d["kernels"], source=os.path.basename(path))
-    return None
-
-
-def measured_traffic(config, chunk):
-    """HBM bytes per k_extprod launch (2 FETCH_SIZE + WRITE_SIZE, gfx950 correction) or None."""
-    c = _counters(config, chunk)
-    return c["k_extprod"].get("traffic_bytes_per_launch") if c else None
+        if d.get("chunk", 256) != chunk:
+            continue
+        if d.get("source_hash") != want:
+            stale = stale or os.path.basename(path)
+            continue
+        return dict(d["kernels"], source=os.path.basename(path), valu_mix=d.get("valu_mix")), None
+    if stale:
+        return None, "kernel sources changed since %s was collected (hash %s)" % (stale, want)
+    return None, "no committed counters for chunk %d" % chunk
 
 
 # Issue rates measured on the MI355X by tools/ubench_int.hip (profiles/r01_ubench_valu.txt), in
-# 10^12 lane-operations per second, and k_extprod's static instruction mix (fractions of its VALU
-# instructions: v_mad_u64_u32, v_mul_lo_u32, everything else).
+# 10^12 lane-operations per second.
 VALU_RATE = {"mad64": 32.39, "mul": 34.38, "simple": 56.08}
-VALU_MIX = {"mad64": 0.216, "mul": 0.111, "simple": 0.673}
 
 
-def valu_roofline(config, chunk, ext_s):
+def valu_roofline(c, ext_s):
     """The bound that actually limits k_extprod: integer VALU issue.  achieved = VALU
     instructions per launch (PMC SQ_INSTS_VALU) x 64 lanes / launch time; peak = the
-    micro-benchmarked issue rate of the same instruction mix."""
-    c = _counters(config, chunk)
-    if not c or "SQ_INSTS_VALU" not in c.get("k_extprod", {}) or ext_s <= 0:
+    micro-benchmarked issue rate of the kernel's own static instruction mix (fractions of
+    64-bit multiply-adds, 32-bit multiplies and everything else, tools/valu_mix.py)."""
+    if not c or "SQ_INSTS_VALU" not in c.get("k_extprod", {}) or not c.get("valu_mix") or ext_s <= 0:
         return None
+    mix = c["valu_mix"]
     insts = c["k_extprod"]["SQ_INSTS_VALU"]
-    peak = 1.0 / sum(VALU_MIX[k] / VALU_RATE[k] for k in VALU_MIX)
+    peak = 1.0 / sum(mix[k] / VALU_RATE[k] for k in VALU_RATE)
     ach = insts * 64 / ext_s / 1e12
     return {"bound": "valu-int32", "achieved": ach, "peak": peak, "unit": "Tlane-op/s",
-            "frac": ach / peak, "valu_insts_per_launch": insts, "source": c["source"]}
+            "frac": ach / peak, "valu_insts_per_launch": insts, "mix": mix, "source": c["source"]}
 
 
-def cpu_baseline(p, sk, key_seed, seconds_target=15.0):
+def cpu_baseline(p, sk, key_seed, cap, seconds_target=15.0):
     """Oracle 'port' (oracle/sgfhe_oracle.c: reference-shaped, 128-bit Montgomery, 24 NTTs per
     iteration) timed on the host cores of this box: one independent bootstrap per thread (OpenMP
     over the batch, the same sharding the GPUs use), over a k-loop truncated to about
@@ -118,10 +155,10 @@ def cpu_baseline(p, sk, key_seed, seconds_target=15.0):
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle_c
     try:
-        cores = len(os.sched_getaffinity(0))
+        avail = len(os.sched_getaffinity(0))
     except AttributeError:
-        cores = os.cpu_count() or 1
-    cores = max(1, min(16, cores))            # a one-GPU box's CPU share
+        avail = os.cpu_count() or 1
+    cores = max(1, min(cap, avail) if cap else avail)
     o = oracle_c.Oracle.from_params(p)
     key = o.bootstrap_key(sk, key_seed)
     rng = np.random.default_rng(7)
@@ -135,11 +172,62 @@ def cpu_baseline(p, sk, key_seed, seconds_target=15.0):
     o.bootstrap_batch(key, a[0], b[0], a[1], b[1], n_iters=iters, threads=cores)
     dt = time.perf_counter() - t0
     full = dt * p.n / iters
-    return {"value": cores / full, "unit": "bootstraps/sec", "cores": cores, "kind": "port",
+    return {"value": cores / full, "unit": "bootstraps/sec", "cores": cores,
+            "cores_available": avail, "cores_cap": cap or None, "kind": "port",
             "per_core": 1.0 / full,
             "sample": "%d bootstraps in parallel (one per thread), first %d of %d k-loop iterations "
                       "(%.1f s), scaled x%.2f; reference-shaped C restatement"
                       % (cores, iters, p.n, dt, p.n / iters)}
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def self_launch(args):
+    """`bench.py --gpus N` without a launcher: start N ranks as children (one per GPU) and relay
+    rank 0's JSON line.  This process never touches the GPU (a process that has initialised HIP
+    must not start or become another GPU program)."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+           "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [l for l in proc.stdout.splitlines() if l.startswith("{")]
+    for l in proc.stdout.splitlines():
+        if not l.startswith("{"):
+            print(l, file=sys.stderr)
+    if lines:
+        print(lines[-1])
+    sys.exit(proc.returncode if proc.returncode else (0 if lines else 1))
+
+
+def dry_run(args):
+    """The N-rank control flow of main() with gloo on the CPU and no engine: rendezvous, barrier,
+    MAX over ranks, one line from rank 0.  Exercised by tests/test_distributed_cpu.py."""
+    import torch
+    import torch.distributed as dist
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if world > 1 or "RANK" in os.environ:
+        dist.init_process_group("gloo")
+        dist.barrier()
+        t = torch.tensor([1.0 + rank], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        tmax = float(t.item())
+        dist.barrier()
+        dist.destroy_process_group()
+    else:
+        tmax = 1.0
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": world, "max_over_ranks": tmax,
+                          "steps": args.steps, "warmup": args.warmup}))
 
 
 def main():
@@ -148,11 +236,24 @@ def main():
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", default="params1024")
-    ap.add_argument("--batch", type=int, default=4096, help="bootstraps per GPU per step")
+    ap.add_argument("--batch", type=int, default=0,
+                    help="bootstraps per GPU per step (default 4096; 8192 on 8 GPUs = config 5)")
     ap.add_argument("--chunk", type=int, default=0, help="lock-step chunk (0 = engine default)")
     ap.add_argument("--lanes", type=int, default=1, help="1 = chunks in sequence, 2 = two streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-host-io", action="store_true",
+                    help="skip the extra step timed through host pointers (sgfhe_bootstrap_batch)")
+    ap.add_argument("--cpu-threads", type=int, default=16,
+                    help="cap on the cpu_baseline threads (0 = every core this process may use)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher rehearsal without a GPU: the ranks rendezvous over gloo, take the "
+                         "MAX of a dummy timing and rank 0 prints a stub line (tests/)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "RANK" not in os.environ:
+        self_launch(args)          # does not return
+    if args.dry_run:
+        return dry_run(args)
 
     import torch
     import sgfhe_jl_amd as S
@@ -172,36 +273,24 @@ def main():
 
     p = make_params(S, args.config)
     W = W_BYTES[args.config]
+    B = args.batch or (8192 if world == 8 else 4096)
     eng = S.Engine(p, device=local_rank)
     if args.chunk:
         eng.set_chunk(args.chunk)
     eng.set_lanes(args.lanes)
 
-    # ---- bootstrap key: rank 0 transforms, peers receive the device form over RCCL -------------
-    kbytes = eng.key_device_form_bytes()
+    # ---- bootstrap key: rank 0 generates, peers receive the device form over RCCL ---------------
     sk = np.random.default_rng(11).integers(0, 2, size=p.n, dtype=np.uint64)
     KEY_SEED = 1
+    t0 = time.perf_counter()
     if rank == 0:
         eng.generate_key(sk, KEY_SEED)
-    if dist:
-        blob = torch.empty(kbytes, dtype=torch.uint8, device="cuda")
-        if rank == 0:
-            eng.export_key_device_form(blob.data_ptr())
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        dist.broadcast(blob, src=0)
-        torch.cuda.synchronize()
-        bcast_s = time.perf_counter() - t0
-        if rank != 0:
-            eng.import_key_device_form(blob.data_ptr())
-        del blob
-    else:
-        bcast_s = 0.0
+    keygen_s = time.perf_counter() - t0
+    bcast_s = S.distributed.broadcast_key(eng, src=0)[1] if dist else 0.0
 
     # ---- synthetic LWE inputs, resident in HBM ---------------------------------------------------
     g = torch.Generator(device="cuda")
     g.manual_seed(1234 + rank)
-    B = args.batch
     a1 = torch.randint(0, p.r, (B, p.n), dtype=torch.int64, device="cuda", generator=g)
     a2 = torch.randint(0, p.r, (B, p.n), dtype=torch.int64, device="cuda", generator=g)
     b1 = torch.randint(0, p.r, (B,), dtype=torch.int64, device="cuda", generator=g)
@@ -238,6 +327,26 @@ def main():
     tm = eng.timing_read(reset=True)
     eng.timing_enable(False)
 
+    # ---- the metric as SURVEY.md 8(d) words it: host buffers in, host buffers out (PCIe inside) ----
+    host_io = None
+    if not args.no_host_io:
+        ha1, ha2 = a1.cpu().numpy().view(np.uint64), a2.cpu().numpy().view(np.uint64)
+        hb1, hb2 = b1.cpu().numpy().view(np.uint64), b2.cpu().numpy().view(np.uint64)
+        if dist:
+            dist.barrier()
+        t1 = time.perf_counter()
+        hout = eng.bootstrap_batch(ha1, hb1, ha2, hb2)       # sgfhe_bootstrap_batch: H2D, k-loop, D2H
+        hdt = time.perf_counter() - t1
+        same = bool(np.array_equal(hout.view(np.int64), out.cpu().numpy()))
+        if dist:
+            tmax = torch.tensor([hdt], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            hdt = float(tmax.item())
+        host_io = {"value": world * B / hdt, "unit": "bootstraps/sec", "ms_per_step": hdt * 1e3,
+                   "steps": 1, "equals_device_resident_output": same,
+                   "note": "inputs and outputs in host memory (sgfhe_bootstrap_batch): includes "
+                           "H2D of 2 (n + 1) and D2H of 3 (n + 1) words per bootstrap"}
+
     if rank == 0:
         total = world * args.steps * B
         value = total / dt
@@ -249,32 +358,38 @@ def main():
         crt_s = tm["crt_ms"] * 1e-3
         achieved = launch_bytes / ext_s / 1e9 if ext_s > 0 else 0.0
         pair = launch_bytes / (ext_s + crt_s) / 1e9 if ext_s + crt_s > 0 else 0.0
+        ctr, why = _counters(args.config, chunk)
         res = {
             "metric": "bootstraps/sec", "value": value, "unit": "bootstraps/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "i32", "data": "synthetic",
             "config": {"workload": "%s gate bootstraps (AND/OR/XOR), batch %d per GPU, "
                                    "deterministic flatten" % (args.config, B),
                        "n": p.n, "m": p.m, "log2_Q": round(float(np.log2(float(p.Q))), 2),
                        "batch_per_gpu": B, "chunk": chunk, "lanes": args.lanes,
                        "rns_primes": len(eng.primes()),
                        "key": "generated on the device from a seed (valid key)",
+                       "keygen_s": round(keygen_s, 3), "key_bytes": eng.key_device_form_bytes(),
                        "key_broadcast_s": round(bcast_s, 4)},
             "roofline": {"bound": "hbm", "kernel": "k_extprod", "achieved": achieved,
                          "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": achieved / PEAK_HBM_GBS,
-                         "traffic": measured_traffic(args.config, chunk),
+                         "traffic": ctr["k_extprod"].get("traffic_bytes_per_launch") if ctr else None,
+                         "traffic_note": None if ctr else why,
                          "launch_ms": tm["extprod_ms"], "launch_samples": tm["extprod_samples"],
                          "algorithmic_bytes_per_launch": launch_bytes,
                          "pair_kernel": "k_crt_acc", "pair_launch_ms": tm["crt_ms"],
                          "pair_achieved": pair, "pair_frac": pair / PEAK_HBM_GBS,
                          "whole_job_frac": per_boot * value / world / (PEAK_HBM_GBS * 1e9),
-                         "valu": valu_roofline(args.config, chunk, ext_s)},
+                         "valu": valu_roofline(ctr, ext_s)},
         }
+        if host_io:
+            res["host_io"] = host_io
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(p, sk, KEY_SEED)
+            res["cpu_baseline"] = cpu_baseline(p, sk, KEY_SEED, args.cpu_threads)
         print(json.dumps(res))
     if dist:
+        dist.barrier()
         dist.destroy_process_group()
     eng.close()
 

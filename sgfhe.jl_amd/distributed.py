@@ -15,7 +15,10 @@ def shard_range(batch, rank, world):
 
 
 def broadcast_key(engine, src=0, group=None):
-    """One-time RCCL broadcast of the device-form key (sgfhe_bkey_export/import_device_form)."""
+    """One-time RCCL broadcast of the device-form key blob (64-byte header + payload,
+    sgfhe_bkey_export/import_device_form) from rank `src` to every other rank of the group; the
+    import verifies the header against the receiving ctx.  Returns (bytes, seconds)."""
+    import time
     import torch
     import torch.distributed as dist
     nbytes = engine.key_device_form_bytes()
@@ -23,11 +26,13 @@ def broadcast_key(engine, src=0, group=None):
     if dist.get_rank(group) == src:
         engine.export_key_device_form(blob.data_ptr())
     torch.cuda.synchronize()
+    t0 = time.perf_counter()
     dist.broadcast(blob, src=src, group=group)
     torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
     if dist.get_rank(group) != src:
         engine.import_key_device_form(blob.data_ptr())
-    return nbytes
+    return nbytes, dt
 
 
 def bootstrap_sharded(bootstrap_fn, a1, b1, a2, b2, rank, world):

@@ -79,3 +79,35 @@ def test_two_rank_gloo_matches_single_process(tmp_path, oc):
     for r in range(world):
         full = np.load(os.path.join(str(tmp_path), "full_%d.npy" % r))
         assert full.tobytes() == ref.tobytes()
+
+
+@pytest.mark.parametrize("gpus", [1, 2])
+def test_bench_self_launch_dry_run(gpus):
+    """`python bench.py --gpus N` starts its own ranks (torch.distributed.run on 127.0.0.1) and
+    relays exactly one JSON line from rank 0; N = 1 runs in-process.  --dry-run swaps the engine
+    for a gloo rendezvous so the launcher path runs without a GPU."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(gpus),
+                        "--steps", "3", "--warmup", "1", "--dry-run"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == gpus and d["steps"] == 3 and d["warmup"] == 1
+    assert d["max_over_ranks"] == float(gpus)           # MAX over ranks of (1 + rank)
+
+
+def test_bench_refuses_mismatched_world():
+    """Started by a launcher with another world size, bench.py exits non-zero instead of
+    reporting a line for the wrong N."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run"],
+                       env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)

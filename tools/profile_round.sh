@@ -9,12 +9,17 @@ CHUNK=${2:-512}   # one chunk of the engine default size at Params(1024)
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o run -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline > $OUT/bench_stats.log 2>&1
+ONE="--batch $CHUNK --steps 1 --warmup 0 --no-cpu-baseline --no-host-io"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o run -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-host-io > $OUT/bench_stats.log 2>&1
 echo "stats done"
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_$C -o run -- python3 bench.py --batch $CHUNK --steps 1 --warmup 0 --no-cpu-baseline > $OUT/pmc_$C.log 2>&1
+  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_$C -o run -- python3 bench.py $ONE > $OUT/pmc_$C.log 2>&1
   echo "$C done"
 done
-rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVES --kernel-trace --output-format csv -d $OUT/pmc_SQ -o run -- python3 bench.py --batch $CHUNK --steps 1 --warmup 0 --no-cpu-baseline > $OUT/pmc_SQ.log 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVES --kernel-trace --output-format csv -d $OUT/pmc_SQ -o run -- python3 bench.py $ONE > $OUT/pmc_SQ.log 2>&1
 echo "SQ done"
+# where the wave cycles go (optional passes: a counter this ROCm does not know must not stop the round)
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d $OUT/pmc_SQW -o run -- python3 bench.py $ONE > $OUT/pmc_SQW.log 2>&1 || echo "SQW pass failed"
+rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_SQL -o run -- python3 bench.py $ONE > $OUT/pmc_SQL.log 2>&1 || echo "SQL pass failed"
+echo "SQ wait/LDS done"
 python3 tools/summarize_profile.py $OUT $TAG $CHUNK
