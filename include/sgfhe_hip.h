@@ -58,6 +58,9 @@ typedef struct {
 /* flags of sgfhe_bootstrap_batch* */
 #define SGFHE_FLAG_RAW_MODQ 1u /* return _bootstrap_internal's LWEs over Z_Q (fhe.jl:559-595) as
                                   16-byte residues instead of ModRed words (fhe.jl:616-618) */
+#define SGFHE_FLAG_RAW_RNS2 2u /* with RAW_MODQ: every residue leaves as the RNS2Number limb pair
+                                  (x mod m1, x mod m2) (src/rns.jl:16-18) of the moduli given to
+                                  sgfhe_bkey_upload_rns2, instead of {lo, hi} of x */
 
 /* Library / build information: "sgfhe_hip <version> gfx950". */
 const char *sgfhe_version(void);
@@ -79,8 +82,9 @@ const char *sgfhe_last_error_string(const sgfhe_ctx *ctx);
 
 /* Batch-scheduling knobs.  chunk: bootstraps that move through the k-loop in lock-step
  * (0 = default; rounded up to a multiple of 8; a chunk's buffers must stay below 4 GiB).  lanes: 1 (default) runs the
- * chunks of a batch one after the other; 2 runs consecutive chunks on two HIP streams (measured
- * equal to one stream with twice the chunk).  Every setting gives bit-identical results. */
+ * chunks of a batch one after the other; 2 runs pairs of chunks on two HIP streams (measured
+ * within 2 % of one stream with twice the chunk).  Every setting gives bit-identical results, in
+ * both flatten modes. */
 int32_t sgfhe_set_chunk(sgfhe_ctx *ctx, uint32_t chunk);
 /* Chunks of at most this many bootstraps (default 24, 0 = never, at most 256) run the k-loop in
  * its small-batch form: 6 workgroups per (bootstrap, RNS prime) and three launches per iteration
@@ -93,9 +97,13 @@ int32_t sgfhe_set_lanes(sgfhe_ctx *ctx, uint32_t lanes);
  * Flatten mode of the external product.  enable = 0 (default): deterministic flatten, the
  * `rng = nothing` branch (src/utils.jl:155-189), bit-exact with the reference.  enable = 1:
  * randomised flatten, the `rng::AbstractRNG` branch (src/utils.jl:198-241): every digit gets a
- * uniform v in [-3B/2, 3B/2] drawn from a Philox counter stream of `seed`; digits lie in
- * (-2B, 2B].  The results decrypt like the reference's but are not bit-comparable with it
- * (Julia's MersenneTwister stream is not reproduced).  Applies to later bootstrap calls.
+ * uniform v in [-3B/2, 3B/2] drawn from a Philox4x32-10 counter stream of `seed`; digits lie in
+ * (-2B, 2B].  The draw of a coefficient is addressed by (coefficient, iteration, index of the
+ * bootstrap in the call, number of the call since this function): results do not depend on chunk
+ * size, lanes or the small-batch threshold, and oracle/bigint_oracle.py reproduces them bit for
+ * bit.  They decrypt like the reference's but are not bit-comparable with it (Julia's
+ * MersenneTwister stream cannot be reproduced).  Applies to later bootstrap / pack calls; needs a
+ * ctx whose RNS primes cover it (SGFHE_CTX_RANDOM_FLATTEN), else SGFHE_ERR_UNSUPPORTED.
  */
 int32_t sgfhe_set_random_flatten(sgfhe_ctx *ctx, int enable, uint64_t seed);
 
@@ -110,20 +118,27 @@ int32_t sgfhe_bkey_upload(sgfhe_ctx *ctx, const uint64_t *canonical, size_t n_wo
 /*
  * Same for a key held as RNS2Number{UInt64, M1, M2} pairs (src/rns.jl:8-24; type_Q of
  * Scheme2, src/fhe2.jl:76): each coefficient is (v1, v2) = (x mod m1, x mod m2).  The boundary
- * conversion is the CRT of src/rns.jl:32-40; requires m1 * m2 == Q.
+ * conversion is the CRT of src/rns.jl:32-40, done on the device; requires m1 * m2 == Q, both
+ * prime and below 2^47.  A limb outside [0, m_i) is SGFHE_ERR_INVALID_ARG.
  */
 int32_t sgfhe_bkey_upload_rns2(sgfhe_ctx *ctx, const uint64_t *pairs, size_t n_words, uint64_t m1,
                                uint64_t m2);
+/* The two conversions of src/rns.jl on `count` coefficients (host pointers, run on the device):
+ * to_pairs = 0: (v1, v2) -> canonical x = (v1 c1 + v2 c2) mod (m1 m2) (rns.jl:32-40);
+ * to_pairs = 1: canonical x -> (x mod m1, x mod m2) (rns.jl:16-18).  m1 m2 must equal Q. */
+int32_t sgfhe_rns2_convert(sgfhe_ctx *ctx, int to_pairs, const uint64_t *in, size_t count,
+                           uint64_t m1, uint64_t m2, uint64_t *out);
 
 /*
  * BootstrapKey(rng, sk) (src/fhe.jl:181-201) generated on the device, directly in device form:
  * for every k and gadget row a uniform a_row in [0, Q)^m, noise e_row in [-noise, noise]^m
  * (the reference uses noise = n, src/fhe.jl:194), b_row = a_row * s + e_row, plus s_k G on the
  * constant terms.  sk: n words, bit 0 of each is the key bit (PrivateKey.key, src/fhe.jl:130-138).
- * Randomness: the SplitMix64 stream of `seed` (draw order documented in csrc/kernels.h); the
- * caller is responsible for a seed of cryptographic quality.
+ * Randomness: ChaCha20 (RFC 8439) keyed with the 32-byte `seed`, separate counter-addressed
+ * streams for the uniform polynomials and for the noise of every key row (layout in
+ * csrc/kernels.h).  The key's entropy is the seed's: pass 32 bytes from a cryptographic generator.
  */
-int32_t sgfhe_bkey_generate(sgfhe_ctx *ctx, const uint64_t *sk, size_t n_sk, uint64_t seed,
+int32_t sgfhe_bkey_generate(sgfhe_ctx *ctx, const uint64_t *sk, size_t n_sk, const uint8_t *seed,
                             uint32_t noise);
 
 /* Device-form key blob (for the one-time RCCL broadcast rank 0 -> peers). */
@@ -177,6 +192,21 @@ int32_t sgfhe_pack_encrypted_bits(sgfhe_ctx *ctx, const uint64_t *a, const uint6
 int32_t sgfhe_debug_accumulators(sgfhe_ctx *ctx, const uint64_t *a1, const uint64_t *b1,
                                  const uint64_t *a2, const uint64_t *b2, size_t batch,
                                  uint64_t n_iters, uint64_t *acc);
+
+/* Parity / debug hook: the stored digit planes after n_iters iterations, i.e. the flatten result
+ * (src/utils.jl:155-241) the next external product will consume: digits [batch][2][2][m] uint64,
+ * index order (accumulator c: 0 = a, 1 = b)(digit i)(coefficient).  Stored value e_i = u_i + s
+ * with s = B/2 - 1 (even B) or (B - 1)/2 and u_i the reference's i-th flatten output taken as a
+ * signed integer, u_i in (-B/2, B/2]; in the randomised mode e_i = u_i + s + xmax,
+ * xmax = 3 (B / 2), u_i in (-2B, 2B] (test/internals.test.jl:50-66).  sum_i u_i B^i == acc mod Q. */
+int32_t sgfhe_debug_digits(sgfhe_ctx *ctx, const uint64_t *a1, const uint64_t *b1,
+                           const uint64_t *a2, const uint64_t *b2, size_t batch, uint64_t n_iters,
+                           uint64_t *digits);
+
+/* Parity / debug hook: flatten_poly(nothing, ., Val(B), Val(2)) (src/utils.jl:155-189,253-264) of
+ * two polynomials on its own (k_flatten_canon): values [2][m][2] canonical residues ->
+ * digits [2][2][m] uint64 in the stored form of sgfhe_debug_digits (e_i = u_i + s).  Host pointers. */
+int32_t sgfhe_debug_flatten(sgfhe_ctx *ctx, const uint64_t *values, uint64_t *digits);
 
 /* Parity / debug hook: negacyclic NTT of one polynomial modulo RNS prime `prime_index`.
  * in/out: [m] uint32 residues; forward maps natural order to the engine's slot order,

@@ -25,8 +25,9 @@ MASK64 = (1 << 64) - 1
 
 
 # ----------------------------------------------------------------------------------------------
-# Deterministic PRNG shared (bit for bit) with oracle/sgfhe_oracle.c -- the build's own generator,
-# not Julia's MersenneTwister.
+# Deterministic PRNGs shared (bit for bit) with oracle/sgfhe_oracle.c -- the build's own generators,
+# not Julia's MersenneTwister: SplitMix64 for the test plumbing (private keys, LWE
+# encryptions), ChaCha20 for the bootstrap key (the stream the HIP engine's key generation uses).
 # ----------------------------------------------------------------------------------------------
 
 class SplitMix64:
@@ -49,6 +50,42 @@ class SplitMix64:
     def below(self, bound):
         """Value in [0, bound) from one 64-bit draw (bound < 2^63)."""
         return self.next() % bound
+
+
+def chacha20_blocks(key32, nonce, nblocks):
+    """ChaCha20 block function (RFC 8439 section 2.3) for block counters 0 .. nblocks-1:
+    key32 = 32 bytes, nonce = three 32-bit words.  Returns an [nblocks][16] array of words.
+    (numpy on whole counter ranges: the generator of the bootstrap key, shared with
+    oracle/sgfhe_oracle.c and the HIP engine's k_keygen_draw.)"""
+    import numpy as np
+    key = [int.from_bytes(key32[4 * i:4 * i + 4], "little") for i in range(8)]
+    init = [0x61707865, 0x3320646e, 0x79622d32, 0x6b206574] + key + [0] + [int(v) for v in nonce]
+    s = [np.full(nblocks, v, dtype=np.uint32) for v in init]
+    s[12] = np.arange(nblocks, dtype=np.uint32)
+    x = [v.copy() for v in s]
+
+    def rotl(v, n):
+        return (v << np.uint32(n)) | (v >> np.uint32(32 - n))
+
+    def qr(a, b, c, d):
+        x[a] = x[a] + x[b]; x[d] = rotl(x[d] ^ x[a], 16)
+        x[c] = x[c] + x[d]; x[b] = rotl(x[b] ^ x[c], 12)
+        x[a] = x[a] + x[b]; x[d] = rotl(x[d] ^ x[a], 8)
+        x[c] = x[c] + x[d]; x[b] = rotl(x[b] ^ x[c], 7)
+
+    with np.errstate(over="ignore"):
+        for _ in range(10):
+            qr(0, 4, 8, 12); qr(1, 5, 9, 13); qr(2, 6, 10, 14); qr(3, 7, 11, 15)
+            qr(0, 5, 10, 15); qr(1, 6, 11, 12); qr(2, 7, 8, 13); qr(3, 4, 9, 14)
+        return np.stack([x[i] + s[i] for i in range(16)], axis=1)
+
+
+def seed_bytes(seed):
+    """Key-generation seed: 32 bytes, or an int taken as 32 little-endian bytes."""
+    if isinstance(seed, (bytes, bytearray)):
+        assert len(seed) == 32
+        return bytes(seed)
+    return int(seed).to_bytes(32, "little")
 
 
 # ----------------------------------------------------------------------------------------------
@@ -248,14 +285,85 @@ def flatten(a, B, ell, Q):
     return [(d - s) % Q for d in decomp]                          # utils.jl:183-185
 
 
-def flatten_poly(a, B, ell, Q):
-    """src/utils.jl:253-264."""
+def flatten_xmax(B):
+    """Bound of the random shift of the randomised flatten, src/utils.jl:210-214."""
+    return (B - 1) // 2 * 3 if B % 2 else B // 2 * 3
+
+
+def flatten_random(draw, a, B, ell, Q):
+    """Randomised flatten, src/utils.jl:198-241: x_i = rand(rng, -xmax:xmax) for i = 1..ell
+    (:229-231), rand_a = a - sum x_i B^(i-1) (:233-234), y = flatten(nothing, rand_a) (:236),
+    result x_i + y_i (:237-239), all in Z_Q.  `draw(i)` returns the i-th draw (0-based) of this
+    coefficient as an integer in [-xmax, xmax]."""
+    x = [draw(i) for i in range(ell)]
+    rand_a = a
+    for i in range(ell):
+        rand_a = (rand_a - x[i] * B ** i) % Q
+    y = flatten(rand_a, B, ell, Q)
+    return [(x[i] + y[i]) % Q for i in range(ell)]
+
+
+def flatten_poly(a, B, ell, Q, draws=None):
+    """src/utils.jl:253-264.  draws = None: deterministic (rng = nothing); else a callable
+    (coefficient index j, digit index i) -> integer in [-xmax, xmax] standing for the reference's
+    rng: flatten_poly visits the coefficients in order and every coefficient draws ell values."""
     results = [[0] * len(a) for _ in range(ell)]
     for j, c in enumerate(a):
-        d = flatten(c, B, ell, Q)
+        if draws is None:
+            d = flatten(c, B, ell, Q)
+        else:
+            d = flatten_random(lambda i, j=j: draws(j, i), c, B, ell, Q)
         for i in range(ell):
             results[i][j] = d[i]
     return results
+
+
+# ----------------------------------------------------------------------------------------------
+# The randomness of the HIP engine's randomised flatten, restated: Philox4x32-10 addressed by
+# counter = (x: (c << log2 m) + j for coefficient j of accumulator c (0 = a, 1 = b),
+#            y: k for the flatten feeding k-loop iteration k (0-based); 2^31 | i for the flatten of
+#               as_i in pack_encrypted_bits,
+#            z: index of the bootstrap within the call (of the ciphertext, for packing),
+#            w: number of the call since the seed was set),        key = the 64-bit seed.
+# The 128 output bits give r_0 = (lo64 * span) >> 64, r_1 = (hi64 * span) >> 64 with
+# span = 2 xmax + 1, and the draws x_i = r_i - xmax (sgfhe.jl_amd/csrc/kernels.h random_digits).
+# The reference draws from Julia's MersenneTwister, which cannot be reproduced here (SURVEY.md
+# F6): this pins the engine's random mode to the reference's *algorithm* on the engine's stream.
+# ----------------------------------------------------------------------------------------------
+
+def philox4x32(ctr, seed):
+    c = [int(v) & 0xFFFFFFFF for v in ctr]
+    k0, k1 = seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF
+    for _ in range(10):
+        p0 = 0xD2511F53 * c[0]
+        p1 = 0xCD9E8D57 * c[2]
+        c = [((p1 >> 32) ^ c[1] ^ k0) & 0xFFFFFFFF, p1 & 0xFFFFFFFF,
+             ((p0 >> 32) ^ c[3] ^ k1) & 0xFFFFFFFF, p0 & 0xFFFFFFFF]
+        k0 = (k0 + 0x9E3779B9) & 0xFFFFFFFF
+        k1 = (k1 + 0xBB67AE85) & 0xFFFFFFFF
+    return c
+
+
+class PhiloxFlatten:
+    """Draw source of one bootstrap: rng(c, y)(j, i) is the draw for digit i of coefficient j of
+    accumulator c in the flatten tagged y."""
+
+    def __init__(self, p, seed, boot=0, call=0):
+        self.p, self.seed, self.boot, self.call = p, seed, boot, call
+        self.xmax = flatten_xmax(p.B)
+        self.logm = p.m.bit_length() - 1
+
+    def draws(self, c, y):
+        span = 2 * self.xmax + 1
+        cache = {}
+
+        def f(j, i):
+            if j not in cache:
+                rv = philox4x32(((c << self.logm) + j, y, self.boot, self.call), self.seed)
+                cache.clear()
+                cache[j] = ((((rv[1] << 32) | rv[0]) * span) >> 64, (((rv[3] << 32) | rv[2]) * span) >> 64)
+            return cache[j][i] - self.xmax
+        return f
 
 
 # ----------------------------------------------------------------------------------------------
@@ -270,8 +378,11 @@ def private_key(p, seed):
 
 def bootstrap_key(p, sk, seed, noise=None):
     """src/fhe.jl:181-201.  Returns key[k][row][col] = list of m residues mod Q.
-    Draw order: for k, for row: a_row[0..m) (128-bit draws), then e_row[0..m) (64-bit draws)."""
-    g = SplitMix64(seed)
+    Randomness (the build's own, not Julia's): ChaCha20 keyed with the 32-byte seed, one stream
+    per (domain, key row), nonce = (domain, k * 4 + row, 0); domain 1 = a_row (coefficient i from
+    words 4 (i mod 4) .. + 3 of block i / 4 as a 128-bit value mod Q), domain 2 = e_row
+    (coefficient i from words 2 (i mod 8), + 1 of block i / 8 as a 64-bit value mod 2 noise + 1)."""
+    key32 = seed_bytes(seed)
     noise = p.n if noise is None else noise
     ext_key = resize(sk, p.m)                                     # fhe.jl:185
     G = gadget_matrix(p)                                          # fhe.jl:190
@@ -279,10 +390,13 @@ def bootstrap_key(p, sk, seed, noise=None):
     for k in range(p.n):
         C = []
         for row in range(4):
-            aj = [g.below_wide(p.Q) for _ in range(p.m)]          # fhe.jl:193
-            ej = [(g.below(2 * noise + 1) - noise) % p.Q for _ in range(p.m)]   # fhe.jl:194
+            wa = chacha20_blocks(key32, (1, k * 4 + row, 0), (p.m + 3) // 4).reshape(-1).tolist()
+            we = chacha20_blocks(key32, (2, k * 4 + row, 0), (p.m + 7) // 8).reshape(-1).tolist()
+            aj = [(wa[4 * i] | (wa[4 * i + 1] << 32) | (wa[4 * i + 2] << 64) | (wa[4 * i + 3] << 96)) % p.Q
+                  for i in range(p.m)]                            # fhe.jl:193
+            ej = [((we[2 * i] | (we[2 * i + 1] << 32)) % (2 * noise + 1) - noise) % p.Q
+                  for i in range(p.m)]                            # fhe.jl:194
             bj = poly_add(poly_mul(aj, ext_key, p.Q), ej, p.Q)    # fhe.jl:195
-            aj = list(aj)
             # fhe.jl:196: `.+ ext_key.coeffs[i] * G` adds to the constant coefficient
             aj[0] = (aj[0] + ext_key[k] * G[row][0]) % p.Q
             bj[0] = (bj[0] + ext_key[k] * G[row][1]) % p.Q
@@ -323,9 +437,10 @@ def extract(a, i, n, Q):
 # Bootstrap
 # ----------------------------------------------------------------------------------------------
 
-def external_product(a, b, A, B, ell, Q):
-    """src/fhe.jl:519-530 (deterministic flatten)."""
-    u = flatten_poly(a, B, ell, Q) + flatten_poly(b, B, ell, Q)          # fhe.jl:524-526
+def external_product(a, b, A, B, ell, Q, draws_a=None, draws_b=None):
+    """src/fhe.jl:519-530.  draws_a / draws_b = None: rng = nothing; else the draw sources of the
+    flatten of a (first, fhe.jl:524) and of b (second, fhe.jl:525)."""
+    u = flatten_poly(a, B, ell, Q, draws_a) + flatten_poly(b, B, ell, Q, draws_b)   # fhe.jl:524-526
     N = len(a)
     a_res = [0] * N
     b_res = [0] * N
@@ -349,8 +464,9 @@ def mul_by_xj_minus_one(poly, j, Q):
     return poly_sub(mul_by_monomial(poly, j, Q), poly, Q)
 
 
-def bootstrap_internal(p, bkey, lwe1, lwe2, trace=None):
-    """src/fhe.jl:559-595.  Returns three LWEs over Z_Q: (AND, OR, XOR)."""
+def bootstrap_internal(p, bkey, lwe1, lwe2, trace=None, rng=None):
+    """src/fhe.jl:559-595.  Returns three LWEs over Z_Q: (AND, OR, XOR).  rng = None is the
+    reference's `rng = nothing`; a PhiloxFlatten selects the randomised flatten."""
     Q = p.Q
     ua = [(x + y) % p.r for x, y in zip(lwe1[0], lwe2[0])]               # fhe.jl:566
     ub = (lwe1[1] + lwe2[1]) % p.r
@@ -367,7 +483,10 @@ def bootstrap_internal(p, bkey, lwe1, lwe2, trace=None):
                 x[0] = (x[0] + G[row][col]) % Q                          # `.+ G`: constant term
                 Arow.append(x)
             A.append(Arow)
-        a, b = external_product(a, b, A, p.B, p.ell, Q)
+        if rng is None:
+            a, b = external_product(a, b, A, p.B, p.ell, Q)
+        else:
+            a, b = external_product(a, b, A, p.B, p.ell, Q, rng.draws(0, k), rng.draws(1, k))
         if trace is not None:
             trace(k, a, b)
     m, n = p.m, p.n
@@ -380,10 +499,10 @@ def bootstrap_internal(p, bkey, lwe1, lwe2, trace=None):
     return (and_a, and_b), (or_a, or_b), (xor_a, xor_b)
 
 
-def bootstrap(p, bkey, lwe1, lwe2):
+def bootstrap(p, bkey, lwe1, lwe2, rng=None):
     """src/fhe.jl:608-621.  Returns three LWEs over Z_r: (AND, OR, XOR)."""
     out = []
-    for a, b in bootstrap_internal(p, bkey, lwe1, lwe2):
+    for a, b in bootstrap_internal(p, bkey, lwe1, lwe2, rng=rng):
         out.append(([reduce_modulus(p.r, x, p.Q) for x in a],            # fhe.jl:616-618,644-648
                     reduce_modulus(p.r, b, p.Q)))
     return tuple(out)
@@ -410,9 +529,9 @@ def rns2_to_int(v1, v2, m1, m2):
 # Packing LWEs into an RLWE ciphertext (second caller of the hot path)
 # ----------------------------------------------------------------------------------------------
 
-def shortened_external_product(a, A, B, ell, Q):
+def shortened_external_product(a, A, B, ell, Q, draws=None):
     """src/fhe.jl:632-641: flatten(a) * A[l+1:2l, :]."""
-    u = flatten_poly(a, B, ell, Q)                                        # fhe.jl:637
+    u = flatten_poly(a, B, ell, Q, draws)                                 # fhe.jl:637
     N = len(a)
     a_res = [0] * N
     b_res = [0] * N
@@ -427,19 +546,25 @@ def reduce_modulus_poly(new_modulus, poly, old_modulus):
     return [reduce_modulus(new_modulus, x, old_modulus) for x in poly]
 
 
-def pack_encrypted_bits(p, bkey, enc_bits):
-    """src/fhe.jl:660-696 (rng = nothing).  enc_bits: n LWEs (a, b) over Z_r.
+def pack_encrypted_bits(p, bkey, enc_bits, seed=None, ct=0, call=0):
+    """src/fhe.jl:660-696.  enc_bits: n LWEs (a, b) over Z_r.  seed = None: rng = nothing; else
+    the engine's Philox stream (ciphertext `ct` of call `call`): bootstrap j of the group is
+    bootstrap ct * n + j of the call, and the flatten of as_i draws with y = 2^31 | i, z = ct.
     Returns the RLWE (w, v) over Z_r, two lists of m coefficients."""
     Q = p.Q
     assert len(enc_bits) == p.n                                           # fhe.jl:667
     enc_trivial = ([0] * p.n, p.Dr)                                       # fhe.jl:669-671
-    new_lwes = [bootstrap_internal(p, bkey, enc_trivial, eb)[0] for eb in enc_bits]   # fhe.jl:673
+    rngs = [None if seed is None else PhiloxFlatten(p, seed, ct * p.n + j, call) for j in range(p.n)]
+    new_lwes = [bootstrap_internal(p, bkey, enc_trivial, eb, rng=rngs[j])[0]
+                for j, eb in enumerate(enc_bits)]                         # fhe.jl:673
     as_ = [resize([new_lwes[j][0][i] for j in range(p.n)], p.m) for i in range(p.n)]  # :675-677
     b = resize([lw[1] for lw in new_lwes], p.m)                           # fhe.jl:678
     w_tilde = [0] * p.m
     v_tilde = [0] * p.m
+    pack_rng = None if seed is None else PhiloxFlatten(p, seed, ct, call)
     for i in range(p.n):                                                  # fhe.jl:683-687
-        w, v = shortened_external_product(as_[i], bkey[i], p.B, p.ell, Q)
+        draws = None if seed is None else pack_rng.draws(0, (1 << 31) | i)
+        w, v = shortened_external_product(as_[i], bkey[i], p.B, p.ell, Q, draws)
         w_tilde = poly_add(w_tilde, w, Q)
         v_tilde = poly_add(v_tilde, v, Q)
     w1 = [(Q - x) % Q for x in w_tilde]                                   # fhe.jl:689

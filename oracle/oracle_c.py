@@ -40,6 +40,8 @@ def lib():
         L.sgo_ctx_create.argtypes = [_u64p]
         L.sgo_ctx_destroy.argtypes = [ctypes.c_void_p]
         L.sgo_ctx_uses_ntt.argtypes = [ctypes.c_void_p]
+        L.sgo_ctx_set_rns2.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64]
+        L.sgo_ctx_uses_rns2.argtypes = [ctypes.c_void_p]
         L.sgo_find_modulus.argtypes = [ctypes.c_uint64, _u64p, _u64p, _u64p]
         L.sgo_params_make.argtypes = [ctypes.c_uint64, _u64p]
         L.sgo_rescale.argtypes = [_u64p, _u64p, _u64p, ctypes.c_int, _u64p]
@@ -48,7 +50,7 @@ def lib():
         L.sgo_poly_mul_schoolbook.argtypes = [ctypes.c_void_p, _u64p, _u64p, _u64p]
         L.sgo_external_product.argtypes = [ctypes.c_void_p, _u64p, _u64p, _u64p, _u64p, _u64p]
         L.sgo_private_key.argtypes = [ctypes.c_void_p, ctypes.c_uint64, _u64p]
-        L.sgo_bootstrap_key.argtypes = [ctypes.c_void_p, _u64p, ctypes.c_uint64, ctypes.c_uint64,
+        L.sgo_bootstrap_key.argtypes = [ctypes.c_void_p, _u64p, ctypes.c_char_p, ctypes.c_uint64,
                                         _u64p, ctypes.c_int]
         L.sgo_lwe_encrypt_bits.argtypes = [ctypes.c_void_p, _u64p, _u8p, ctypes.c_size_t,
                                            ctypes.c_uint64, _u64p, _u64p]
@@ -64,6 +66,15 @@ def lib():
 
 def _p(arr):
     return arr.ctypes.data_as(_u64p)
+
+
+def seed_bytes(seed):
+    """Key-generation seed: 32 bytes, or an int taken as 32 little-endian bytes."""
+    if isinstance(seed, (bytes, bytearray)):
+        if len(seed) != 32:
+            raise ValueError("key seed must be 32 bytes")
+        return bytes(seed)
+    return int(seed).to_bytes(32, "little")
 
 
 def to_words(x):
@@ -104,17 +115,22 @@ def params_make(n):
 class Oracle:
     """One parameter set of the C restatement."""
 
-    def __init__(self, n, r, m, Q, B, DQ_tilde, ell=2):
+    def __init__(self, n, r, m, Q, B, DQ_tilde, ell=2, rns2=None):
+        """rns2 = (m1, m2): Q = m1 m2 held as RNS2Number limbs (src/rns.jl): products per limb."""
         self.n, self.r, self.m, self.Q, self.B, self.DQ_tilde, self.ell = n, r, m, Q, B, DQ_tilde, ell
         self._words = params_words(n, r, m, ell, Q, B, DQ_tilde)
         self._ctx = lib().sgo_ctx_create(_p(self._words))
         if not self._ctx:
             raise ValueError("sgo_ctx_create rejected the parameters")
+        if rns2 is not None:
+            rc = lib().sgo_ctx_set_rns2(self._ctx, int(rns2[0]), int(rns2[1]))
+            if rc:
+                raise ValueError("sgo_ctx_set_rns2 failed: %d" % rc)
 
     @classmethod
-    def from_params(cls, p):
+    def from_params(cls, p, rns2=None):
         """p: anything with n, r, m, Q, B, DQ_tilde attributes."""
-        return cls(p.n, p.r, p.m, p.Q, p.B, p.DQ_tilde)
+        return cls(p.n, p.r, p.m, p.Q, p.B, p.DQ_tilde, rns2=rns2)
 
     @classmethod
     def make(cls, n):
@@ -132,6 +148,10 @@ class Oracle:
     @property
     def uses_ntt(self):
         return bool(lib().sgo_ctx_uses_ntt(self._ctx))
+
+    @property
+    def uses_rns2(self):
+        return bool(lib().sgo_ctx_uses_rns2(self._ctx))
 
     def flatten(self, a):
         ain = np.array(to_words(a), dtype=np.uint64)
@@ -166,7 +186,7 @@ class Oracle:
         """[n][4][2][m][2] uint64 canonical residues (fhe.jl:181-201)."""
         bkey = np.zeros((self.n, 4, 2, self.m, 2), dtype=np.uint64)
         sk = np.ascontiguousarray(sk, dtype=np.uint64)
-        lib().sgo_bootstrap_key(self._ctx, _p(sk), seed, self.n if noise is None else noise,
+        lib().sgo_bootstrap_key(self._ctx, _p(sk), seed_bytes(seed), self.n if noise is None else noise,
                                 _p(bkey), threads or os.cpu_count() or 1)
         return bkey
 

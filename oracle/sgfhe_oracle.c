@@ -23,6 +23,10 @@ struct sgo_ctx {
     u128 minv_R2;   /* m^-1 * R^2 mod Q */
     /* flatten constants, utils.jl:162-169 */
     u128 fl_s, fl_offset;
+    /* RNS2Number ring (src/rns.jl), Q = m1 m2: one word-size NTT context per limb modulus and the
+     * CRT idempotents c1 = m2^(m1-1), c2 = m1^(m2-1) mod Q of rns.jl:36-37 */
+    struct sgo_ctx *limb[2];
+    u128 rns_m[2], rns_c[2];
 };
 
 static inline u128 ld128(const uint64_t *p) { return ((u128)p[1] << 64) | p[0]; }
@@ -197,8 +201,31 @@ sgo_ctx *sgo_ctx_create(const uint64_t *w) {
 
 void sgo_ctx_destroy(sgo_ctx *c) {
     if (!c) return;
+    sgo_ctx_destroy(c->limb[0]);
+    sgo_ctx_destroy(c->limb[1]);
     free(c->psi_br); free(c->ipsi_br); free(c);
 }
+
+/* src/rns.jl:8-24: hold the coefficients of Z_Q, Q = m1 m2, as RNS2Number limb pairs.  Both limb
+ * moduli must be NTT-friendly primes (2m | m_i - 1: the rule of src/fhe2.jl:57-58). */
+int sgo_ctx_set_rns2(sgo_ctx *c, uint64_t m1, uint64_t m2) {
+    if ((u128)m1 * m2 != c->Q || m1 == m2) return -1;
+    uint64_t w[10] = {c->n, c->r, c->m, 2, 0, 0, 2, 0, 0, 0};
+    const uint64_t ms[2] = {m1, m2};
+    for (int i = 0; i < 2; i++) {
+        w[4] = ms[i];
+        sgo_ctx_destroy(c->limb[i]);
+        c->limb[i] = sgo_ctx_create(w);
+        if (!c->limb[i] || !c->limb[i]->use_ntt) return -2;
+        c->rns_m[i] = ms[i];
+    }
+    mont_t mt;
+    mont_init(&mt, c->Q);
+    c->rns_c[0] = powmod(&mt, m2, (u128)m1 - 1);            /* rns.jl:36 */
+    c->rns_c[1] = powmod(&mt, m1, (u128)m2 - 1);            /* rns.jl:37 */
+    return 0;
+}
+int sgo_ctx_uses_rns2(const sgo_ctx *c) { return c->limb[0] != NULL; }
 
 int sgo_ctx_uses_ntt(const sgo_ctx *c) { return c->use_ntt; }
 
@@ -270,7 +297,28 @@ static void poly_mul_schoolbook(const sgo_ctx *c, const u128 *a, const u128 *b, 
 /* DarkIntegers `Polynomial * Polynomial` (call sites fhe.jl:195,527-528): exact product mod
  * (x^m + 1, Q); [DI-recall] NTT path (2 forward + pointwise + 1 inverse) when Q is prime with
  * 2m | Q - 1, else a non-NTT exact algorithm. */
+static void poly_mul(const sgo_ctx *c, const u128 *a, const u128 *b, u128 *out);
+
+/* Polynomial * Polynomial over RNS2Number{UInt64, m1, m2} coefficients: conversion from the
+ * integer is (x mod m1, x mod m2) (rns.jl:16-18), `*`, `+`, `-` act limb-wise (rns.jl:51-60), so
+ * the product is one NTT multiply per limb; conversion back is the CRT of rns.jl:32-40. */
+static void poly_mul_rns2(const sgo_ctx *c, const u128 *a, const u128 *b, u128 *out) {
+    size_t m = c->m;
+    mont_t mt;
+    mont_init(&mt, c->Q);
+    u128 *la = (u128 *)malloc(4 * m * sizeof(u128));
+    u128 *lb = la + m, *r1 = la + 2 * m, *r2 = la + 3 * m;
+    for (int i = 0; i < 2; i++) {
+        for (size_t j = 0; j < m; j++) { la[j] = a[j] % c->rns_m[i]; lb[j] = b[j] % c->rns_m[i]; }
+        poly_mul(c->limb[i], la, lb, i ? r2 : r1);
+    }
+    for (size_t j = 0; j < m; j++)                            /* rns.jl:38 */
+        out[j] = addmod(mulmod_plain(&mt, r1[j], c->rns_c[0]), mulmod_plain(&mt, r2[j], c->rns_c[1]), c->Q);
+    free(la);
+}
+
 static void poly_mul(const sgo_ctx *c, const u128 *a, const u128 *b, u128 *out) {
+    if (!c->use_ntt && c->limb[0]) { poly_mul_rns2(c, a, b, out); return; }
     if (!c->use_ntt) { poly_mul_schoolbook(c, a, b, out); return; }
     mont_t mt = ctx_mont(c);
     size_t m = c->m;
@@ -415,45 +463,74 @@ void sgo_private_key(const sgo_ctx *c, uint64_t seed, uint64_t *sk) {
     for (uint64_t i = 0; i < c->n; i++) sk[i] = sm_next(&g) & 1;
 }
 
-/* fhe.jl:181-201.  The generator is advanced serially (draws per k are a fixed count), the
- * products run in parallel. */
-void sgo_bootstrap_key(const sgo_ctx *c, const uint64_t *sk, uint64_t seed, uint64_t noise,
+/* ChaCha20 block function (RFC 8439, section 2.3): key 8 words, block counter, nonce 3 words. */
+static void chacha20_block(const uint32_t key[8], uint32_t counter, const uint32_t nonce[3],
+                           uint32_t out[16]) {
+    uint32_t s[16] = {0x61707865u, 0x3320646eu, 0x79622d32u, 0x6b206574u,
+                      key[0], key[1], key[2], key[3], key[4], key[5], key[6], key[7],
+                      counter, nonce[0], nonce[1], nonce[2]};
+    uint32_t x[16];
+    memcpy(x, s, sizeof x);
+#define ROTL(v, n) (((v) << (n)) | ((v) >> (32 - (n))))
+#define QR(a, b, c, d)                                                                        \
+    x[a] += x[b]; x[d] ^= x[a]; x[d] = ROTL(x[d], 16); x[c] += x[d]; x[b] ^= x[c]; x[b] = ROTL(x[b], 12); \
+    x[a] += x[b]; x[d] ^= x[a]; x[d] = ROTL(x[d], 8);  x[c] += x[d]; x[b] ^= x[c]; x[b] = ROTL(x[b], 7);
+    for (int i = 0; i < 10; i++) {
+        QR(0, 4, 8, 12) QR(1, 5, 9, 13) QR(2, 6, 10, 14) QR(3, 7, 11, 15)
+        QR(0, 5, 10, 15) QR(1, 6, 11, 12) QR(2, 7, 8, 13) QR(3, 4, 9, 14)
+    }
+#undef QR
+#undef ROTL
+    for (int i = 0; i < 16; i++) out[i] = x[i] + s[i];
+}
+
+/* fhe.jl:181-201.  Randomness: ChaCha20 keyed with the 32-byte seed, one stream per
+ * (domain, key row) = nonce (domain, k * 4 + row, 0); domain 1: the uniform polynomials a_row
+ * (coefficient i = words 4 (i mod 4) .. + 3 of block i / 4: lo = w0 | w1 << 32,
+ * hi = w2 | w3 << 32, value (hi 2^64 + lo) mod Q), domain 2: the noise e_row (coefficient i =
+ * words 2 (i mod 8), + 1 of block i / 8: d = w0 | w1 << 32, value d mod (2 noise + 1) - noise).
+ * The same streams as sgfhe_bkey_generate (csrc/kernels.h), so both give the same key. */
+void sgo_bootstrap_key(const sgo_ctx *c, const uint64_t *sk, const uint8_t *seed, uint64_t noise,
                        uint64_t *bkey_words, int threads) {
     size_t m = c->m, n = c->n;
     u128 Q = c->Q;
     u128 *bkey = (u128 *)bkey_words;
     u128 *ext_key = (u128 *)calloc(m, sizeof(u128));         /* fhe.jl:185 resize */
     for (size_t i = 0; i < n; i++) ext_key[i] = sk[i];
-    u128 *e = (u128 *)malloc(n * 4 * m * sizeof(u128));
-    splitmix_t g = {seed};
-    for (size_t k = 0; k < n; k++) {
-        for (int row = 0; row < 4; row++) {
-            u128 *aj = bkey + ((k * 4 + row) * 2 + 0) * m;
-            u128 *ej = e + (k * 4 + row) * m;
-            for (size_t i = 0; i < m; i++) aj[i] = sm_below_wide(&g, Q);            /* :193 */
-            for (size_t i = 0; i < m; i++) {                                         /* :194 */
-                uint64_t d = sm_next(&g) % (2 * noise + 1);
-                ej[i] = d >= noise ? (u128)(d - noise) : Q - (u128)(noise - d);
-            }
-        }
-    }
+    uint32_t key[8];
+    for (int i = 0; i < 8; i++)
+        key[i] = (uint32_t)seed[4 * i] | ((uint32_t)seed[4 * i + 1] << 8) |
+                 ((uint32_t)seed[4 * i + 2] << 16) | ((uint32_t)seed[4 * i + 3] << 24);
     const u128 G[4][2] = {{1, 0}, {c->B % Q, 0}, {0, 1}, {0, c->B % Q}};   /* fhe.jl:119-122 */
-    (void)threads;
 #pragma omp parallel for num_threads(threads > 0 ? threads : 1) schedule(dynamic)
     for (long kr = 0; kr < (long)(n * 4); kr++) {
         size_t k = kr / 4;
         int row = kr % 4;
         u128 *aj = bkey + ((k * 4 + row) * 2 + 0) * m;
         u128 *bj = bkey + ((k * 4 + row) * 2 + 1) * m;
-        const u128 *ej = e + (k * 4 + row) * m;
+        u128 *ej = (u128 *)malloc(m * sizeof(u128));
+        uint32_t blk[16];
+        const uint32_t nonce_a[3] = {1u, (uint32_t)kr, 0u}, nonce_e[3] = {2u, (uint32_t)kr, 0u};
+        for (size_t i = 0; i < m; i++) {                                             /* :193 */
+            if ((i & 3) == 0) chacha20_block(key, (uint32_t)(i >> 2), nonce_a, blk);
+            const uint32_t *w = blk + 4 * (i & 3);
+            u128 v = ((u128)(((uint64_t)w[3] << 32) | w[2]) << 64) | (((uint64_t)w[1] << 32) | w[0]);
+            aj[i] = v % Q;
+        }
+        for (size_t i = 0; i < m; i++) {                                             /* :194 */
+            if ((i & 7) == 0) chacha20_block(key, (uint32_t)(i >> 3), nonce_e, blk);
+            const uint32_t *w = blk + 2 * (i & 7);
+            uint64_t d = ((((uint64_t)w[1] << 32) | w[0])) % (2 * noise + 1);
+            ej[i] = d >= noise ? (u128)(d - noise) : Q - (u128)(noise - d);
+        }
         poly_mul(c, aj, ext_key, bj);                                               /* :195 */
         for (size_t i = 0; i < m; i++) bj[i] = addmod(bj[i], ej[i], Q);
         if (ext_key[k]) {                                    /* :196 constant-term add of s_k G */
             aj[0] = addmod(aj[0], G[row][0], Q);
             bj[0] = addmod(bj[0], G[row][1], Q);
         }
+        free(ej);
     }
-    free(e);
     free(ext_key);
 }
 

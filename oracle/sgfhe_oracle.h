@@ -32,6 +32,12 @@ sgo_ctx *sgo_ctx_create(const uint64_t *words);
 void sgo_ctx_destroy(sgo_ctx *ctx);
 /* 1 if Q is prime with 2m | Q-1 (NTT multiply), 0 if the schoolbook multiply is used. */
 int sgo_ctx_uses_ntt(const sgo_ctx *ctx);
+/* RNS2Number ring of src/rns.jl (BASELINE.json config 4): Q = m1 m2 with two NTT-friendly primes
+ * (rule of src/fhe2.jl:57-58).  Polynomial products are then computed as the reference's RNS type
+ * does: limb-wise (rns.jl:51-60, one NTT multiply per limb) with the conversions of rns.jl:16-18
+ * (split) and rns.jl:32-40 (CRT).  Returns 0 on success. */
+int sgo_ctx_set_rns2(sgo_ctx *ctx, uint64_t m1, uint64_t m2);
+int sgo_ctx_uses_rns2(const sgo_ctx *ctx);
 
 /* utils.jl:7-28 find_modulus; qmax_* = 0,0 means "no upper bound". Returns 0 on success. */
 int sgo_find_modulus(uint64_t n, const uint64_t *qmin, const uint64_t *qmax, uint64_t *out);
@@ -51,10 +57,12 @@ void sgo_poly_mul_schoolbook(const sgo_ctx *ctx, const uint64_t *a, const uint64
 void sgo_external_product(const sgo_ctx *ctx, const uint64_t *a, const uint64_t *b,
                           const uint64_t *A, uint64_t *a_res, uint64_t *b_res);
 
-/* Keys and LWE plumbing with the build's SplitMix64 (same draws as bigint_oracle.py). */
+/* Private key and LWE test plumbing with the build's SplitMix64 (same draws as bigint_oracle.py). */
 void sgo_private_key(const sgo_ctx *ctx, uint64_t seed, uint64_t *sk /* [n] bits */);
-/* fhe.jl:181-201; bkey is [n][4][2][m] residues (2 words each); noise bound as fhe.jl:194. */
-void sgo_bootstrap_key(const sgo_ctx *ctx, const uint64_t *sk, uint64_t seed, uint64_t noise,
+/* fhe.jl:181-201; bkey is [n][4][2][m] residues (2 words each); noise bound as fhe.jl:194.
+ * Randomness: ChaCha20 streams of the 32-byte seed (layout in sgfhe_oracle.c), the same as
+ * sgfhe_bkey_generate of the HIP engine. */
+void sgo_bootstrap_key(const sgo_ctx *ctx, const uint64_t *sk, const uint8_t *seed, uint64_t noise,
                        uint64_t *bkey, int threads);
 /* `count` LWEs of bits[count] from one generator seeded with `seed` (fhe.jl:310-328,287-290). */
 void sgo_lwe_encrypt_bits(const sgo_ctx *ctx, const uint64_t *sk, const uint8_t *bits,

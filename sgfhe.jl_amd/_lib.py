@@ -70,7 +70,8 @@ def lib():
         "sgfhe_set_random_flatten": (i32, [vp, ctypes.c_int, u64]),
         "sgfhe_bkey_upload": (i32, [vp, vp, sz]),
         "sgfhe_bkey_upload_rns2": (i32, [vp, vp, sz, u64, u64]),
-        "sgfhe_bkey_generate": (i32, [vp, vp, sz, u64, u32]),
+        "sgfhe_rns2_convert": (i32, [vp, ctypes.c_int, vp, sz, u64, u64, vp]),
+        "sgfhe_bkey_generate": (i32, [vp, vp, sz, ctypes.c_char_p, u32]),
         "sgfhe_bkey_device_form_bytes": (i32, [vp, ctypes.POINTER(sz)]),
         "sgfhe_bkey_export_device_form": (i32, [vp, vp]),
         "sgfhe_bkey_import_device_form": (i32, [vp, vp]),
@@ -80,6 +81,8 @@ def lib():
         "sgfhe_external_product": (i32, [vp, vp, vp, vp, vp, vp]),
         "sgfhe_pack_encrypted_bits": (i32, [vp, vp, vp, sz, vp, vp]),
         "sgfhe_debug_accumulators": (i32, [vp, vp, vp, vp, vp, sz, u64, vp]),
+        "sgfhe_debug_digits": (i32, [vp, vp, vp, vp, vp, sz, u64, vp]),
+        "sgfhe_debug_flatten": (i32, [vp, vp, vp]),
         "sgfhe_debug_ntt": (i32, [vp, u32, ctypes.c_int, vp, vp]),
         "sgfhe_debug_primes": (i32, [vp, _u32p, _u32p]),
         "sgfhe_timing_enable": (i32, [vp, ctypes.c_int]),
@@ -95,8 +98,8 @@ def lib():
 
 EXPORTED_SYMBOLS = (
     "sgfhe_version", "sgfhe_ctx_create", "sgfhe_ctx_create_ex", "sgfhe_ctx_destroy", "sgfhe_last_error_string",
-    "sgfhe_set_chunk", "sgfhe_set_lanes", "sgfhe_set_small_batch_max", "sgfhe_set_random_flatten", "sgfhe_bkey_upload", "sgfhe_bkey_upload_rns2", "sgfhe_bkey_generate",
+    "sgfhe_set_chunk", "sgfhe_set_lanes", "sgfhe_set_small_batch_max", "sgfhe_set_random_flatten", "sgfhe_bkey_upload", "sgfhe_bkey_upload_rns2", "sgfhe_rns2_convert", "sgfhe_bkey_generate",
     "sgfhe_bkey_device_form_bytes", "sgfhe_bkey_export_device_form",
     "sgfhe_bkey_import_device_form", "sgfhe_bootstrap_batch", "sgfhe_bootstrap_batch_device",
-    "sgfhe_sync", "sgfhe_external_product", "sgfhe_pack_encrypted_bits", "sgfhe_debug_accumulators", "sgfhe_debug_ntt",
+    "sgfhe_sync", "sgfhe_external_product", "sgfhe_pack_encrypted_bits", "sgfhe_debug_accumulators", "sgfhe_debug_digits", "sgfhe_debug_flatten", "sgfhe_debug_ntt",
     "sgfhe_debug_primes", "sgfhe_timing_enable", "sgfhe_timing_read")

@@ -96,6 +96,9 @@ struct sgfhe_ctx {
     uint64_t rnd_seed = 0;
     uint32_t rnd_call = 0, last_call = 0;
     uint32_t create_flags = 0;
+    // RNS2Number form of Z_Q (src/rns.jl): set by sgfhe_bkey_upload_rns2 / sgfhe_rns2_convert
+    bool have_rns2 = false;
+    Rns2Const rns2;
     struct Lane {
         uint64_t *dig = nullptr;
         uint32_t *yres = nullptr;
@@ -367,31 +370,48 @@ void timing_flush(sgfhe_ctx *c) {
     c->ev.clear();
 }
 
-// ---- the k-loop over one chunk (fhe.jl:579-582) ---------------------------------------------------
+// ---- the k-loop (fhe.jl:579-582) over one chunk, or over two chunks in a pipeline --------------------
 
-int32_t run_iterations(sgfhe_ctx *c, const sgfhe_ctx::Lane &L, uint32_t cpad, uint64_t n_iters,
-                       hipStream_t st, bool full_chunk, uint32_t mode, RndArgs ra) {
+// One chunk of the batch on its lane (work buffers + stream).
+struct ChunkJob {
+    const sgfhe_ctx::Lane *L;
+    hipStream_t st;
+    uint32_t cb, cpad;  // bootstraps in the chunk, padded to a multiple of 8
+    size_t c0;          // index of its first bootstrap in the call
+    RndArgs ra;
+    bool sampled;       // HIP-event timing samples are taken on this chunk
+};
+
+// Iteration k of every job: k_extprod (or its small-batch form) then k_crt_acc, each job on its
+// own stream.  (Measured and rejected in round 2: chaining the two streams so that one chunk's
+// CRT kernel runs beside the other chunk's external product -- also with the CRT as a
+// one-workgroup-per-CU grid-stride "rider" kernel -- costs the external product as much time
+// as the CRT takes alone)
+int32_t run_iterations(sgfhe_ctx *c, ChunkJob *jobs, int njobs, uint64_t n_iters, uint32_t mode) {
     const size_t slice = (size_t)c->npr * 8 * c->M;
-    // few bootstraps: 6 workgroups per (bootstrap, prime) instead of 1 (k_fwd_phase / k_inv_column)
-    const bool small = cpad <= c->small_max && L.zpart != nullptr;
     for (uint64_t k = 0; k < n_iters; k++) {
-        const bool sample = c->timing && full_chunk && (k % 64 == 1) && c->ev.size() < 2048;
-        hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
-        if (sample) {
-            HIPCHK(c, hipEventCreate(&e0));
-            HIPCHK(c, hipEventCreate(&e1));
-            HIPCHK(c, hipEventCreate(&e2));
-            HIPCHK(c, hipEventRecord(e0, st));
-        }
-        int32_t rc = small ? launch_small(c, L, c->d_key + k * slice, cpad, (uint32_t)k, mode, st)
-                           : launch_extprod(c, L, c->d_key + k * slice, cpad, (uint32_t)k, mode, st);
-        if (rc) return rc;
-        if (sample) HIPCHK(c, hipEventRecord(e1, st));
-        rc = launch_crt(c, L, cpad, mode, st, ra, (uint32_t)k + 1);
-        if (rc) return rc;
-        if (sample) {
-            HIPCHK(c, hipEventRecord(e2, st));
-            c->ev.push_back({e0, e1, e2});
+        for (int j = 0; j < njobs; j++) {
+            const ChunkJob &J = jobs[j];
+            // few bootstraps: 6 workgroups per (bootstrap, prime) instead of 1 (k_fwd_phase / k_inv_column)
+            const bool small = J.cpad <= c->small_max && J.L->zpart != nullptr;
+            const bool sample = c->timing && J.sampled && (k % 64 == 1) && c->ev.size() < 2048;
+            hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
+            if (sample) {
+                HIPCHK(c, hipEventCreate(&e0));
+                HIPCHK(c, hipEventCreate(&e1));
+                HIPCHK(c, hipEventCreate(&e2));
+                HIPCHK(c, hipEventRecord(e0, J.st));
+            }
+            int32_t rc = small ? launch_small(c, *J.L, c->d_key + k * slice, J.cpad, (uint32_t)k, mode, J.st)
+                               : launch_extprod(c, *J.L, c->d_key + k * slice, J.cpad, (uint32_t)k, mode, J.st);
+            if (rc) return rc;
+            if (sample) HIPCHK(c, hipEventRecord(e1, J.st));
+            rc = launch_crt(c, *J.L, J.cpad, mode, J.st, J.ra, (uint32_t)k + 1);
+            if (rc) return rc;
+            if (sample) {
+                HIPCHK(c, hipEventRecord(e2, J.st));
+                c->ev.push_back({e0, e1, e2});
+            }
         }
     }
     return SGFHE_OK;
@@ -399,50 +419,79 @@ int32_t run_iterations(sgfhe_ctx *c, const sgfhe_ctx::Lane &L, uint32_t cpad, ui
 
 int32_t bootstrap_device(sgfhe_ctx *c, const uint64_t *a1, const uint64_t *b1, const uint64_t *a2,
                          const uint64_t *b2, size_t batch, uint64_t *out, uint32_t flags,
-                         uint64_t n_iters, ulonglong2 *acc_out, hipStream_t st) {
+                         uint64_t n_iters, ulonglong2 *acc_out, hipStream_t st,
+                         uint64_t *dig_out = nullptr) {
     if (!c->have_key) return fail(c, SGFHE_ERR_NO_KEY, "no bootstrap key uploaded");
     const uint32_t chunk = c->chunk ? c->chunk : default_chunk(c);
     const uint32_t n = c->n, M = c->M;
     const bool raw = flags & SGFHE_FLAG_RAW_MODQ;
+    if (flags & SGFHE_FLAG_RAW_RNS2) {
+        if (!raw) return fail(c, SGFHE_ERR_INVALID_ARG, "SGFHE_FLAG_RAW_RNS2 needs SGFHE_FLAG_RAW_MODQ");
+        if (!c->have_rns2)
+            return fail(c, SGFHE_ERR_INVALID_ARG, "SGFHE_FLAG_RAW_RNS2: no RNS2 moduli (upload the key with sgfhe_bkey_upload_rns2)");
+    }
     const bool two_lanes = c->lanes == 2 && batch > chunk;
     const uint32_t mode = c->rnd ? MODE_RANDOM : 0u;
     const uint32_t call = c->rnd ? c->rnd_call++ : 0u;
     c->last_call = call;
+    {   // work buffers for the largest chunk of this call, before anything of it is queued
+        const uint32_t first = (uint32_t)(batch < chunk ? batch : chunk);
+        int32_t rc = ensure_work(c, round_up8(first));
+        if (rc) return rc;
+        c->last_chunk = round_up8(first);
+    }
     if (two_lanes) {  // fork: the second lane starts after everything already queued on st
         HIPCHK(c, hipEventRecord(c->ev_fork, st));
         HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
     }
-    uint32_t idx = 0;
-    for (size_t c0 = 0; c0 < batch; c0 += chunk, idx++) {
-        const uint32_t cb = (uint32_t)((batch - c0 < chunk) ? batch - c0 : chunk);
-        const uint32_t cpad = round_up8(cb);
-        int32_t rc = ensure_work(c, cpad);
-        if (rc) return rc;
-        const uint32_t li = two_lanes ? (idx & 1) : 0;
-        const sgfhe_ctx::Lane &L = c->lane[li];
-        hipStream_t ls = li ? c->stream2 : st;
-        const bool full_chunk = (c0 == 0);  // later chunks are the same size or a smaller tail
-        if (full_chunk) c->last_chunk = cpad;
-        const uint32_t tot = cpad * M;
-        const RndArgs ra = {(uint32_t)c->rnd_seed, (uint32_t)(c->rnd_seed >> 32), call, (uint32_t)c0};
-        hipLaunchKernelGGL(k_init, dim3((tot + 255) / 256), dim3(256), 0, ls, a1 + c0 * n, b1 + c0,
-                           a2 + c0 * n, b2 + c0, L.dig, L.ua, c->d_crt, cb, cpad, n,
-                           (uint32_t)c->logm, mode, ra);
-        HIPCHK(c, hipGetLastError());
-        rc = run_iterations(c, L, cpad, n_iters, ls, li == 0 && cpad == c->last_chunk, mode, ra);
-        if (rc) return rc;
-        if (acc_out) {
-            const uint32_t t2 = cb * 2 * M;
-            hipLaunchKernelGGL(k_dump_acc, dim3((t2 + 255) / 256), dim3(256), 0, ls, L.dig,
-                               acc_out + c0 * 2 * M, c->d_crt, t2, (uint32_t)c->logm, mode);
+    const size_t stride = (size_t)chunk * (two_lanes ? 2 : 1);
+    for (size_t g0 = 0; g0 < batch; g0 += stride) {
+        ChunkJob jobs[2];
+        int njobs = 0;
+        for (int li = 0; li < (two_lanes ? 2 : 1); li++) {
+            const size_t c0 = g0 + (size_t)li * chunk;
+            if (c0 >= batch) break;
+            ChunkJob &J = jobs[njobs++];
+            J.L = &c->lane[li];
+            J.st = li ? c->stream2 : st;
+            J.cb = (uint32_t)((batch - c0 < chunk) ? batch - c0 : chunk);
+            J.cpad = round_up8(J.cb);
+            J.c0 = c0;
+            J.ra = RndArgs{(uint32_t)c->rnd_seed, (uint32_t)(c->rnd_seed >> 32), call, (uint32_t)c0};
+            J.sampled = li == 0 && J.cpad == c->last_chunk;
+            const uint32_t tot = J.cpad * M;
+            hipLaunchKernelGGL(k_init, dim3((tot + 255) / 256), dim3(256), 0, J.st, a1 + c0 * n, b1 + c0,
+                               a2 + c0 * n, b2 + c0, J.L->dig, J.L->ua, c->d_crt, J.cb, J.cpad, n,
+                               (uint32_t)c->logm, mode, J.ra);
             HIPCHK(c, hipGetLastError());
         }
-        if (out) {
-            const uint32_t t3 = cb * (n + 1);
-            hipLaunchKernelGGL(k_final, dim3((t3 + 255) / 256), dim3(256), 0, ls, L.dig,
-                               out + c0 * 3 * (n + 1) * (raw ? 2 : 1), c->d_crt, cb, n,
-                               (uint32_t)c->logm, raw ? 1u : 0u, mode);
-            HIPCHK(c, hipGetLastError());
+        int32_t rc = run_iterations(c, jobs, njobs, n_iters, mode);
+        if (rc) return rc;
+        for (int j = 0; j < njobs; j++) {
+            const ChunkJob &J = jobs[j];
+            if (acc_out) {
+                const uint32_t t2 = J.cb * 2 * M;
+                hipLaunchKernelGGL(k_dump_acc, dim3((t2 + 255) / 256), dim3(256), 0, J.st, J.L->dig,
+                                   acc_out + J.c0 * 2 * M, c->d_crt, t2, (uint32_t)c->logm, mode);
+                HIPCHK(c, hipGetLastError());
+            }
+            if (dig_out) {
+                const uint32_t t2 = J.cb * 2 * M;
+                hipLaunchKernelGGL(k_dump_digits, dim3((t2 + 255) / 256), dim3(256), 0, J.st, J.L->dig,
+                                   dig_out + J.c0 * 4 * M, t2, (uint32_t)c->logm);
+                HIPCHK(c, hipGetLastError());
+            }
+            if (out) {
+                const uint32_t t3 = J.cb * (n + 1);
+                hipLaunchKernelGGL(k_final, dim3((t3 + 255) / 256), dim3(256), 0, J.st, J.L->dig,
+                                   out + J.c0 * 3 * (n + 1) * (raw ? 2 : 1), c->d_crt, J.cb, n,
+                                   (uint32_t)c->logm, raw ? 1u : 0u, mode);
+                if (raw && (flags & SGFHE_FLAG_RAW_RNS2))  // residues leave as (v1, v2) pairs (rns.jl:16-18)
+                    hipLaunchKernelGGL(k_canon_to_rns2, dim3((3 * t3 + 255) / 256), dim3(256), 0, J.st,
+                                       reinterpret_cast<ulonglong2 *>(out) + J.c0 * 3 * (n + 1),
+                                       (size_t)3 * t3, c->rns2);
+                HIPCHK(c, hipGetLastError());
+            }
         }
     }
     if (two_lanes) {  // join
@@ -665,7 +714,8 @@ int32_t key_alloc(sgfhe_ctx *c) {
 }
 
 // canonical [npolys][m][2 words] in host memory -> NTT-domain key polys poly0.. in keyhat
-int32_t key_transform_host(sgfhe_ctx *c, const uint64_t *canon, uint32_t npolys, int32_t *keyhat) {
+int32_t key_transform_host(sgfhe_ctx *c, const uint64_t *canon, uint32_t npolys, int32_t *keyhat,
+                           const Rns2Const *rns2 = nullptr) {
     const size_t poly_bytes = (size_t)c->M * 16;
     uint32_t stage_polys = (uint32_t)(((size_t)64 << 20) / poly_bytes);
     if (stage_polys < 8) stage_polys = 8;
@@ -678,6 +728,11 @@ int32_t key_transform_host(sgfhe_ctx *c, const uint64_t *canon, uint32_t npolys,
         hipError_t e = hipMemcpyAsync(d_stage, canon + (size_t)p0 * c->M * 2, (size_t)np * poly_bytes,
                                       hipMemcpyHostToDevice, c->stream);
         if (e != hipSuccess) { rc = fail(c, SGFHE_ERR_HIP, hipGetErrorString(e)); break; }
+        if (rns2) {  // (v1, v2) limb pairs -> canonical residues, in place (rns.jl:32-40)
+            const size_t cnt = (size_t)np * c->M;
+            hipLaunchKernelGGL(k_rns2_to_canon, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0,
+                               c->stream, d_stage, cnt, *rns2, c->d_crt, c->d_bad);
+        }
         rc = launch_keytr(c, d_stage, keyhat, p0, np, c->stream);
         if (rc) break;
         e = hipStreamSynchronize(c->stream);
@@ -829,9 +884,14 @@ int32_t sgfhe_bkey_upload(sgfhe_ctx *c, const uint64_t *canonical, size_t n_word
     return SGFHE_OK;
 }
 
-int32_t sgfhe_bkey_generate(sgfhe_ctx *c, const uint64_t *sk, size_t n_sk, uint64_t seed,
+int32_t sgfhe_bkey_generate(sgfhe_ctx *c, const uint64_t *sk, size_t n_sk, const uint8_t *seed32,
                             uint32_t noise) {
-    if (!c || !sk) return SGFHE_ERR_INVALID_ARG;
+    if (!c || !sk || !seed32) return SGFHE_ERR_INVALID_ARG;
+    if (c->M < 8) return fail(c, SGFHE_ERR_UNSUPPORTED, "bkey_generate needs m >= 8");
+    ChaChaKey ck;
+    for (int i = 0; i < 8; i++)
+        ck.k[i] = (uint32_t)seed32[4 * i] | ((uint32_t)seed32[4 * i + 1] << 8) |
+                  ((uint32_t)seed32[4 * i + 2] << 16) | ((uint32_t)seed32[4 * i + 3] << 24);
     if (n_sk != c->n) return fail(c, SGFHE_ERR_INVALID_ARG, "bkey_generate: secret key must hold n bits");
     if (c->Q < ((u128)1 << 16)) return fail(c, SGFHE_ERR_UNSUPPORTED, "bkey_generate needs Q >= 2^16");
     (void)hipSetDevice(c->device);
@@ -859,8 +919,8 @@ int32_t sgfhe_bkey_generate(sgfhe_ctx *c, const uint64_t *sk, size_t n_sk, uint6
         if (rc) break;
         for (uint32_t row0 = 0; row0 < rows && rc == SGFHE_OK; row0 += R) {
             const uint32_t tot = R * M;
-            hipLaunchKernelGGL(k_keygen_draw, dim3((tot + 255) / 256), dim3(256), 0, c->stream, d_acan,
-                               d_e, c->d_crt, seed, noise, row0, R, (uint32_t)c->logm);
+            hipLaunchKernelGGL(k_keygen_draw, dim3((tot / 4 + 255) / 256), dim3(256), 0, c->stream,
+                               d_acan, d_e, c->d_crt, ck, noise, row0, R, (uint32_t)c->logm);
             rc = launch_keygen_ntt(c, d_sk, d_shat, d_acan, d_y, R, false, c->stream);
             if (rc) break;
             // CRT of the exact product, canonical residues into d_prod ([row][m] 16-byte values)
@@ -883,40 +943,88 @@ int32_t sgfhe_bkey_generate(sgfhe_ctx *c, const uint64_t *sk, size_t n_sk, uint6
     return rc;
 }
 
-int32_t sgfhe_bkey_upload_rns2(sgfhe_ctx *c, const uint64_t *pairs, size_t n_words, uint64_t m1,
-                               uint64_t m2) {
-    if (!c || !pairs) return SGFHE_ERR_INVALID_ARG;
-    const size_t expect = (size_t)c->n * 8 * c->M * 2;
-    if (n_words != expect) return fail(c, SGFHE_ERR_INVALID_ARG, "bkey_upload_rns2: bad n_words");
+static int32_t rns2_configure(sgfhe_ctx *c, uint64_t m1, uint64_t m2) {
     if ((u128)m1 * m2 != c->Q) return fail(c, SGFHE_ERR_INVALID_ARG, "m1 * m2 != Q");
-    if (m1 >= (1ull << 47) || m2 >= (1ull << 47))
-        return fail(c, SGFHE_ERR_UNSUPPORTED, "RNS2 limb moduli must be < 2^47");
-    // CRT of rns.jl:32-40: x = (v1 c1 + v2 c2) mod m, c1 = m2^(m1-1) mod m, c2 = m1^(m2-1) mod m.
-    // c1 = m2 * (m2^-1 mod m1), c2 = m1 * (m1^-1 mod m2) (Fermat idempotents, m1, m2 prime).
+    if (m1 >= (1ull << 47) || m2 >= (1ull << 47) || m1 < 2 || m2 < 2)
+        return fail(c, SGFHE_ERR_UNSUPPORTED, "RNS2 limb moduli must be in [2, 2^47)");
+    // CRT of rns.jl:32-40: c1 = m2^(m1-1) mod Q = m2 (m2^-1 mod m1), c2 = m1 (m1^-1 mod m2)
+    // (Fermat idempotents, m1 and m2 prime)
     auto powmod64 = [](uint64_t a, uint64_t e, uint64_t md) {
         u128 r = 1, b = a % md;
         while (e) { if (e & 1) r = r * b % md; b = b * b % md; e >>= 1; }
         return (uint64_t)r;
     };
-    const uint64_t i21 = powmod64(m2 % m1, m1 - 2, m1);  // m2^-1 mod m1
-    const uint64_t i12 = powmod64(m1 % m2, m2 - 2, m2);  // m1^-1 mod m2
-    if ((u128)(m2 % m1) * i21 % m1 != 1 || (u128)(m1 % m2) * i12 % m2 != 1)
+    Rns2Const rc;
+    rc.m1 = m1;
+    rc.m2 = m2;
+    rc.i21 = powmod64(m2 % m1, m1 - 2, m1);
+    rc.i12 = powmod64(m1 % m2, m2 - 2, m2);
+    if ((u128)(m2 % m1) * rc.i21 % m1 != 1 || (u128)(m1 % m2) * rc.i12 % m2 != 1)
         return fail(c, SGFHE_ERR_INVALID_ARG, "RNS2 limb moduli must be distinct primes");
-    const size_t count = expect / 2;
-    std::vector<uint64_t> canon;
-    try { canon.resize(expect); } catch (...) { return fail(c, SGFHE_ERR_OOM, "host allocation failed"); }
-    const u128 Q = c->Q;
-    for (size_t i = 0; i < count; i++) {
-        const uint64_t v1 = pairs[2 * i], v2 = pairs[2 * i + 1];
-        // x = v1 * m2 * i21 + v2 * m1 * i12 (mod Q); reduce the word-size factors first
-        const u128 t1 = (u128)((u128)v1 * i21 % m1) * m2;
-        const u128 t2 = (u128)((u128)v2 * i12 % m2) * m1;
-        u128 x = t1 + t2;
-        if (x >= Q) x -= Q;
-        canon[2 * i] = (uint64_t)x;
-        canon[2 * i + 1] = (uint64_t)(x >> 64);
+    rc.inv1 = 1.0 / (double)m1;
+    rc.inv2 = 1.0 / (double)m2;
+    c->rns2 = rc;
+    c->have_rns2 = true;
+    return SGFHE_OK;
+}
+
+int32_t sgfhe_bkey_upload_rns2(sgfhe_ctx *c, const uint64_t *pairs, size_t n_words, uint64_t m1,
+                               uint64_t m2) {
+    if (!c || !pairs) return SGFHE_ERR_INVALID_ARG;
+    (void)hipSetDevice(c->device);
+    const size_t expect = (size_t)c->n * 8 * c->M * 2;
+    if (n_words != expect) return fail(c, SGFHE_ERR_INVALID_ARG, "bkey_upload_rns2: bad n_words");
+    int32_t rc = rns2_configure(c, m1, m2);
+    if (rc) return rc;
+    rc = key_alloc(c);
+    if (rc) return rc;
+    HIPCHK(c, hipMemset(c->d_bad, 0, sizeof(uint32_t)));
+    rc = key_transform_host(c, pairs, c->n * 8, c->d_key, &c->rns2);
+    if (rc) return rc;
+    uint32_t bad = 0;
+    HIPCHK(c, hipMemcpy(&bad, c->d_bad, sizeof bad, hipMemcpyDeviceToHost));
+    if (bad) {
+        c->have_key = false;
+        return fail(c, SGFHE_ERR_INVALID_ARG, "bkey_upload_rns2: a limb is not in [0, m_i)");
     }
-    return sgfhe_bkey_upload(c, canon.data(), expect);
+    c->have_key = true;
+    return SGFHE_OK;
+}
+
+int32_t sgfhe_rns2_convert(sgfhe_ctx *c, int to_pairs, const uint64_t *in, size_t count, uint64_t m1,
+                           uint64_t m2, uint64_t *out) {
+    if (!c || !in || !out) return SGFHE_ERR_INVALID_ARG;
+    if (count == 0) return SGFHE_OK;
+    (void)hipSetDevice(c->device);
+    int32_t rc = rns2_configure(c, m1, m2);
+    if (rc) return rc;
+    ulonglong2 *d = nullptr;
+    HIPCHK(c, hipMalloc(&d, count * 16));
+    hipError_t e = hipSuccess;
+    uint32_t bad = 0;
+    do {
+        if ((e = hipMemsetAsync(c->d_bad, 0, sizeof(uint32_t), c->stream))) break;
+        if ((e = hipMemcpyAsync(d, in, count * 16, hipMemcpyHostToDevice, c->stream))) break;
+        const dim3 grid((unsigned)((count + 255) / 256));
+        if (to_pairs)
+            hipLaunchKernelGGL(k_canon_to_rns2, grid, dim3(256), 0, c->stream, d, count, c->rns2);
+        else
+            hipLaunchKernelGGL(k_rns2_to_canon, grid, dim3(256), 0, c->stream, d, count, c->rns2,
+                               c->d_crt, c->d_bad);
+        if ((e = hipGetLastError())) break;
+        if ((e = hipMemcpyAsync(out, d, count * 16, hipMemcpyDeviceToHost, c->stream))) break;
+        if ((e = hipMemcpyAsync(&bad, c->d_bad, sizeof bad, hipMemcpyDeviceToHost, c->stream))) break;
+        e = hipStreamSynchronize(c->stream);
+    } while (0);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(c, SGFHE_ERR_HIP, hipGetErrorString(e));
+    if (to_pairs) {  // canonical inputs must be below Q (checked on the host copy: debug hook)
+        for (size_t i = 0; i < count; i++)
+            if (ld128(in + 2 * i) >= c->Q) return fail(c, SGFHE_ERR_INVALID_ARG, "rns2_convert: value >= Q");
+    } else if (bad) {
+        return fail(c, SGFHE_ERR_INVALID_ARG, "rns2_convert: a limb is not in [0, m_i)");
+    }
+    return SGFHE_OK;
 }
 
 int32_t sgfhe_bkey_device_form_bytes(const sgfhe_ctx *c, size_t *bytes) {
@@ -978,13 +1086,14 @@ int32_t sgfhe_sync(sgfhe_ctx *c) {
 
 static int32_t bootstrap_host(sgfhe_ctx *c, const uint64_t *a1, const uint64_t *b1,
                               const uint64_t *a2, const uint64_t *b2, size_t batch, uint64_t *out,
-                              uint32_t flags, uint64_t n_iters, uint64_t *acc) {
+                              uint32_t flags, uint64_t n_iters, uint64_t *acc, uint64_t *digs = nullptr) {
     (void)hipSetDevice(c->device);
     const size_t n = c->n;
     const size_t out_words = batch * 3 * (n + 1) * ((flags & SGFHE_FLAG_RAW_MODQ) ? 2 : 1);
     const size_t acc_words = batch * 2 * (size_t)c->M * 2;
-    uint64_t *d_in = nullptr, *d_out = nullptr;
+    uint64_t *d_in = nullptr, *d_out = nullptr, *d_dig = nullptr;
     ulonglong2 *d_acc = nullptr;
+    const size_t dig_words = batch * 4 * (size_t)c->M;
     const size_t in_words = 2 * batch * (n + 1);
     HIPCHK(c, hipMalloc(&d_in, in_words * 8));
     int32_t rc = SGFHE_OK;
@@ -994,13 +1103,16 @@ static int32_t bootstrap_host(sgfhe_ctx *c, const uint64_t *a1, const uint64_t *
     do {
         if (out && (e = hipMalloc(&d_out, out_words * 8)) != hipSuccess) break;
         if (acc && (e = hipMalloc(&d_acc, acc_words * 8)) != hipSuccess) break;
+        if (digs && (e = hipMalloc(&d_dig, dig_words * 8)) != hipSuccess) break;
         if ((e = hipMemcpyAsync(d_a1, a1, batch * n * 8, hipMemcpyHostToDevice, c->stream))) break;
         if ((e = hipMemcpyAsync(d_a2, a2, batch * n * 8, hipMemcpyHostToDevice, c->stream))) break;
         if ((e = hipMemcpyAsync(d_b1, b1, batch * 8, hipMemcpyHostToDevice, c->stream))) break;
         if ((e = hipMemcpyAsync(d_b2, b2, batch * 8, hipMemcpyHostToDevice, c->stream))) break;
         rc = bootstrap_device(c, d_a1, d_b1, d_a2, d_b2, batch, d_out, flags, n_iters, d_acc,
-                              c->stream);
+                              c->stream, d_dig);
         if (rc) break;
+        if (digs && (e = hipMemcpyAsync(digs, d_dig, dig_words * 8, hipMemcpyDeviceToHost, c->stream)))
+            break;
         if (out && (e = hipMemcpyAsync(out, d_out, out_words * 8, hipMemcpyDeviceToHost, c->stream)))
             break;
         if (acc && (e = hipMemcpyAsync(acc, d_acc, acc_words * 8, hipMemcpyDeviceToHost, c->stream)))
@@ -1011,6 +1123,7 @@ static int32_t bootstrap_host(sgfhe_ctx *c, const uint64_t *a1, const uint64_t *
     (void)hipFree(d_in);
     if (d_out) (void)hipFree(d_out);
     if (d_acc) (void)hipFree(d_acc);
+    if (d_dig) (void)hipFree(d_dig);
     return rc;
 }
 
@@ -1029,6 +1142,45 @@ int32_t sgfhe_debug_accumulators(sgfhe_ctx *c, const uint64_t *a1, const uint64_
     if (n_iters > c->n) return fail(c, SGFHE_ERR_INVALID_ARG, "n_iters > n");
     if (batch == 0) return SGFHE_OK;
     return bootstrap_host(c, a1, b1, a2, b2, batch, nullptr, 0, n_iters, acc);
+}
+
+int32_t sgfhe_debug_digits(sgfhe_ctx *c, const uint64_t *a1, const uint64_t *b1, const uint64_t *a2,
+                           const uint64_t *b2, size_t batch, uint64_t n_iters, uint64_t *digits) {
+    if (!c || !a1 || !b1 || !a2 || !b2 || !digits) return SGFHE_ERR_INVALID_ARG;
+    if (n_iters > c->n) return fail(c, SGFHE_ERR_INVALID_ARG, "n_iters > n");
+    if (batch == 0) return SGFHE_OK;
+    return bootstrap_host(c, a1, b1, a2, b2, batch, nullptr, 0, n_iters, nullptr, digits);
+}
+
+int32_t sgfhe_debug_flatten(sgfhe_ctx *c, const uint64_t *values, uint64_t *digits) {
+    if (!c || !values || !digits) return SGFHE_ERR_INVALID_ARG;
+    (void)hipSetDevice(c->device);
+    const uint32_t M = c->M;
+    int32_t rc = ensure_work(c, 8);
+    if (rc) return rc;
+    const sgfhe_ctx::Lane &L = c->lane[0];
+    for (uint32_t i = 0; i < 2 * M; i++)
+        if (ld128(values + 2 * (size_t)i) >= c->Q)
+            return fail(c, SGFHE_ERR_INVALID_ARG, "debug_flatten: a value is not in [0, Q)");
+    ulonglong2 *d_in = nullptr;
+    uint64_t *d_out = nullptr;
+    HIPCHK(c, hipMalloc(&d_in, (size_t)2 * M * 16));
+    hipError_t e = hipMalloc(&d_out, (size_t)4 * M * 8);
+    if (e != hipSuccess) { (void)hipFree(d_in); return fail(c, SGFHE_ERR_HIP, hipGetErrorString(e)); }
+    do {
+        if ((e = hipMemcpyAsync(d_in, values, (size_t)2 * M * 16, hipMemcpyHostToDevice, c->stream))) break;
+        hipLaunchKernelGGL(k_flatten_canon, dim3((2 * M + 255) / 256), dim3(256), 0, c->stream, d_in,
+                           L.dig, c->d_crt, 2 * M, (uint32_t)c->logm);
+        hipLaunchKernelGGL(k_dump_digits, dim3((2 * M + 255) / 256), dim3(256), 0, c->stream, L.dig,
+                           d_out, 2 * M, (uint32_t)c->logm);
+        if ((e = hipGetLastError())) break;
+        if ((e = hipMemcpyAsync(digits, d_out, (size_t)4 * M * 8, hipMemcpyDeviceToHost, c->stream))) break;
+        e = hipStreamSynchronize(c->stream);
+    } while (0);
+    (void)hipFree(d_in);
+    (void)hipFree(d_out);
+    if (e != hipSuccess) return fail(c, SGFHE_ERR_HIP, hipGetErrorString(e));
+    return SGFHE_OK;
 }
 
 int32_t sgfhe_external_product(sgfhe_ctx *c, const uint64_t *a, const uint64_t *b,

@@ -210,8 +210,11 @@ __device__ __forceinline__ int32_t digit_reduce(uint64_t e, const Mod &md, int32
 // The four digit polynomials u = [a_lo, a_hi, b_lo, b_hi] (fhe.jl:524-526) go through the forward
 // NTT one at a time (phase = key row); the two product polynomials through the inverse NTT one at
 // a time.  The running NTT-domain sum z_0 lives in registers, z_1 in LDS.
+#ifndef SGFHE_EXT_WAVES
+#define SGFHE_EXT_WAVES 4
+#endif
 template <int LOGM>
-__global__ void __launch_bounds__((NttGeom<LOGM, LOGE>::T), (NttGeom<LOGM, LOGE>::T >= 256 ? 4 : 1))
+__global__ void __launch_bounds__((NttGeom<LOGM, LOGE>::T), (NttGeom<LOGM, LOGE>::T >= 256 ? SGFHE_EXT_WAVES : 1))
 k_extprod(const uint64_t *__restrict__ dig, const int32_t *__restrict__ keyk,
           uint32_t *__restrict__ yres, const uint32_t *__restrict__ ua, PrimeSet PS, uint32_t k,
           uint32_t n, uint32_t mode) {
@@ -230,7 +233,11 @@ k_extprod(const uint64_t *__restrict__ dig, const int32_t *__restrict__ keyk,
     const Mod md = mod_of(P);
 
     const int32_t sRd = (mode & MODE_RANDOM) ? P.sRr : P.sR;  // digit offset of the flatten mode
+#ifndef SGFHE_ACC0_64
+    int32_t acc0[E];  // column 0 summed like column 1, Montgomery-reduced per phase (< 2.9 * 2^29)
+#else
     int64_t acc0[E];  // 64-bit NTT-domain sum of column 0 over the four phases (|.| < 2^61)
+#endif
 #pragma unroll
     for (int e = 0; e < E; e++) { acc0[e] = 0; z1[e * T] = 0; }
     // A real loop (not unrolled): one copy of the forward NTT in the instruction stream, and the
@@ -261,7 +268,11 @@ k_extprod(const uint64_t *__restrict__ dig, const int32_t *__restrict__ keyk,
         // 2. forward NTT of u[ph].  At m = 8192 the key slice rows of this phase are requested
         //    before the last pass of the transform, so they have arrived (from L2) when the
         //    products start; at smaller m the extra live registers cost more than the wait.
+#ifdef SGFHE_NO_KEY_EARLY
+        constexpr bool KEY_EARLY = false;
+#else
         constexpr bool KEY_EARLY = LOGM >= 13;
+#endif
         const int32_t *kp = keyk + ((size_t)pi * 8 + ph * 2) * M + E * tid;
         int4 ka4[E / 4], kb4[E / 4];
         auto load_key = [&]() {
@@ -295,7 +306,11 @@ k_extprod(const uint64_t *__restrict__ dig, const int32_t *__restrict__ keyk,
             for (int t = 0; t < 4; t++) {
                 const int e = 4 * h + t;
                 const int32_t u = x[0][e];
+#ifndef SGFHE_ACC0_64
+                acc0[e] += smont(u, ka[t], md);
+#else
                 acc0[e] += (int64_t)u * ka[t];
+#endif
                 int32_t *zp = reinterpret_cast<int32_t *>(lds) + M + e * T + tid;
                 *zp += smont(u, kb[t], md);
             }
@@ -307,7 +322,11 @@ k_extprod(const uint64_t *__restrict__ dig, const int32_t *__restrict__ keyk,
     int32_t z[2][E];
 #pragma unroll
     for (int e = 0; e < E; e++) {
+#ifndef SGFHE_ACC0_64
+        z[0][e] = sred(acc0[e], md);
+#else
         z[0][e] = sred(sredc(acc0[e], md), md);  // |REDC| < 1.4 * 2^29
+#endif
         z[1][e] = sred(z1[e * T], md);           // four phases: < 2.9 * 2^29
     }
     SGFHE_SYNC();  // every thread has taken its z_1 out of the buffer the exchanges now reuse
@@ -696,6 +715,19 @@ k_dump_acc(const uint64_t *__restrict__ dig, ulonglong2 *__restrict__ out,
     out[t] = make_ulonglong2((uint64_t)x, (uint64_t)(x >> 64));
 }
 
+// stored digit planes -> [bootstrap][c][digit][m] uint64 (debug hook): e_i = u_i + s, or
+// u_i + s + xmax in the randomised mode, u the reference's flatten result as a signed integer
+__global__ void __launch_bounds__(256)
+k_dump_digits(const uint64_t *__restrict__ dig, uint64_t *__restrict__ out, uint32_t total,
+              uint32_t logm) {
+    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= total) return;
+    const uint32_t M = 1u << logm, bc = t >> logm, i = t & (M - 1);
+    const ulonglong2 d = load_digits(dig, bc, i, M);
+    out[((size_t)bc * 2 + 0) * M + i] = d.x;
+    out[((size_t)bc * 2 + 1) * M + i] = d.y;
+}
+
 // canonical residues -> digits of x' = (v + off) mod Q  (flatten, utils.jl:155-189)
 __global__ void __launch_bounds__(256)
 k_flatten_canon(const ulonglong2 *__restrict__ in, uint64_t *__restrict__ dig,
@@ -877,20 +909,43 @@ k_pack_finish(const uint32_t *__restrict__ yg, const ulonglong2 *__restrict__ ra
 
 // ==================================================================================================
 // Bootstrap-key generation on the device: BootstrapKey(rng, sk) (src/fhe.jl:181-201), SURVEY.md 8f
-// row N2.  Randomness: the SplitMix64 stream of the given seed, addressed by draw index (the
-// stream is counter based: draw k = mix(seed + (k + 1) gamma)), in the order
-//   for k, for row:  a_row[0..m) (two draws each: hi, lo; value = (hi 2^64 + lo) mod Q),
-//                    e_row[0..m) (one draw each: d mod (2 noise + 1) - noise)
-// -- the order of the oracle's generator, so that both produce the same key from one seed.
+// row N2.  Randomness: ChaCha20 (RFC 8439 block function) keyed with the caller's 32-byte seed,
+// one stream per (domain, key row), nonce = (domain, k * 4 + row, 0), block counter from 0:
+//   domain 1  the uniform polynomial a_row: coefficient i = words 4 (i mod 4) .. + 3 of block i / 4,
+//             lo = w0 | w1 << 32, hi = w2 | w3 << 32, value (hi 2^64 + lo) mod Q   (fhe.jl:193)
+//   domain 2  the noise e_row: coefficient i = words 2 (i mod 8), + 1 of block i / 8,
+//             d = w0 | w1 << 32, value d mod (2 noise + 1) - noise                   (fhe.jl:194)
+// The streams are counter-addressed, so every thread computes its own block; the oracle's
+// generator (oracle/sgfhe_oracle.c, oracle/bigint_oracle.py) reads the same streams and produces
+// the same key from the same seed.
 // Per batch of rows:  k_keygen_draw -> k_polymul_s (a (*) s, exact, per prime) -> k_crt_acc (CANON)
 // -> k_keygen_finish (b = a (*) s + e, + s_k G on the constant terms) -> k_key_transform.
 // ==================================================================================================
 
-__device__ __forceinline__ uint64_t splitmix_at(uint64_t seed, uint64_t k) {
-    uint64_t z = seed + (k + 1) * 0x9E3779B97F4A7C15ull;
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    return z ^ (z >> 31);
+struct ChaChaKey {
+    uint32_t k[8];
+};
+__device__ __forceinline__ void chacha20_block(const ChaChaKey &key, uint32_t counter, uint32_t n0,
+                                               uint32_t n1, uint32_t n2, uint32_t (&out)[16]) {
+    const uint32_t s[16] = {0x61707865u, 0x3320646eu, 0x79622d32u, 0x6b206574u,
+                            key.k[0], key.k[1], key.k[2], key.k[3],
+                            key.k[4], key.k[5], key.k[6], key.k[7], counter, n0, n1, n2};
+    uint32_t x[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) x[i] = s[i];
+#define SGFHE_QR(a, b, c, d)                                                             \
+    x[a] += x[b]; x[d] = __builtin_rotateleft32(x[d] ^ x[a], 16);                        \
+    x[c] += x[d]; x[b] = __builtin_rotateleft32(x[b] ^ x[c], 12);                        \
+    x[a] += x[b]; x[d] = __builtin_rotateleft32(x[d] ^ x[a], 8);                         \
+    x[c] += x[d]; x[b] = __builtin_rotateleft32(x[b] ^ x[c], 7);
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        SGFHE_QR(0, 4, 8, 12) SGFHE_QR(1, 5, 9, 13) SGFHE_QR(2, 6, 10, 14) SGFHE_QR(3, 7, 11, 15)
+        SGFHE_QR(0, 5, 10, 15) SGFHE_QR(1, 6, 11, 12) SGFHE_QR(2, 7, 8, 13) SGFHE_QR(3, 4, 9, 14)
+    }
+#undef SGFHE_QR
+#pragma unroll
+    for (int i = 0; i < 16; i++) out[i] = x[i] + s[i];
 }
 // (hi 2^64 + lo) mod Q for 2^16 <= Q < 2^94: long division in base 2^32 (quotients < 2^32 are
 // exact through the double-precision estimate of mod_wide)
@@ -901,20 +956,34 @@ __device__ __forceinline__ u128 mod128(uint64_t hi, uint64_t lo, const CrtConst 
     r = mod_wide((r << 32) | (uint32_t)(lo >> 32), Q, CC->invQ, nullptr);
     return mod_wide((r << 32) | (uint32_t)lo, Q, CC->invQ, nullptr);
 }
-// rows [row0, row0 + R) (row = k * 4 + gadget row): canonical a into acan[r][m], noise into e[r][m]
+// rows [row0, row0 + R) (row = k * 4 + gadget row): canonical a into acan[r][m], noise into e[r][m].
+// One thread per 64-byte block of the a stream (four coefficients); every second thread also takes
+// one block of the e stream (eight coefficients).
 __global__ void __launch_bounds__(256)
 k_keygen_draw(ulonglong2 *__restrict__ acan, int32_t *__restrict__ e,
-              const CrtConst *__restrict__ CC, uint64_t seed, uint32_t noise, uint32_t row0,
+              const CrtConst *__restrict__ CC, ChaChaKey key, uint32_t noise, uint32_t row0,
               uint32_t R, uint32_t logm) {
     const uint32_t t = blockIdx.x * 256 + threadIdx.x;
-    const uint32_t M = 1u << logm;
-    if (t >= R * M) return;
-    const uint32_t i = t & (M - 1), r = t >> logm;
-    const uint64_t base = (uint64_t)(row0 + r) * 3 * M;
-    const u128 a = mod128(splitmix_at(seed, base + 2 * i), splitmix_at(seed, base + 2 * i + 1), CC);
-    acan[t] = make_ulonglong2((uint64_t)a, (uint64_t)(a >> 64));
-    const uint64_t d = splitmix_at(seed, base + 2 * M + i) % (2 * (uint64_t)noise + 1);
-    e[t] = (int32_t)d - (int32_t)noise;
+    const uint32_t M = 1u << logm, bpr = M >> 2;  // a-stream blocks per row
+    if (t >= R * bpr) return;
+    const uint32_t blk = t & (bpr - 1), r = t / bpr;
+    uint32_t w[16];
+    chacha20_block(key, blk, 1u, row0 + r, 0u, w);
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const uint64_t lo = ((uint64_t)w[4 * q + 1] << 32) | w[4 * q];
+        const uint64_t hi = ((uint64_t)w[4 * q + 3] << 32) | w[4 * q + 2];
+        const u128 a = mod128(hi, lo, CC);
+        acan[(size_t)r * M + 4 * blk + q] = make_ulonglong2((uint64_t)a, (uint64_t)(a >> 64));
+    }
+    if (blk & 1u) return;
+    chacha20_block(key, blk >> 1, 2u, row0 + r, 0u, w);
+    const uint64_t span = 2 * (uint64_t)noise + 1;
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+        const uint64_t d = (((uint64_t)w[2 * q + 1] << 32) | w[2 * q]) % span;
+        e[(size_t)r * M + 4 * blk + q] = (int32_t)d - (int32_t)noise;
+    }
 }
 
 // Residue mod p of a canonical value C < 2^96 given as three 32-bit limbs, lifted to the centred
@@ -1050,6 +1119,41 @@ k_key_transform(const ulonglong2 *__restrict__ canon, int32_t *__restrict__ keyh
         for (int t = 0; t < 4; t++) o[t] = scentre(sred(x[0][4 * h + t], md), md);  // [-(p-1)/2, (p-1)/2]
         reinterpret_cast<int4 *>(dst)[h] = make_int4(o[0], o[1], o[2], o[3]);
     }
+}
+
+// ---- RNS2Number boundary conversions (src/rns.jl, BASELINE.json config 4) --------------------------
+// The reference's two-modulus residue type holds a coefficient of Z_Q, Q = m1 m2, as
+// (v1, v2) = (x mod m1, x mod m2) (rns.jl:16-18) and converts back with the Fermat idempotents
+// c1 = m2^(m1-1), c2 = m1^(m2-1) mod Q: x = (v1 c1 + v2 c2) mod Q (rns.jl:32-40).  With
+// c1 = m2 (m2^-1 mod m1) and c2 = m1 (m1^-1 mod m2) that is
+//   x = ((v1 i21) mod m1) m2 + ((v2 i12) mod m2) m1,  minus Q if >= Q.
+// Both kernels work in place on 16-byte elements ({v1, v2} <-> {x lo, x hi}).
+struct Rns2Const {
+    uint64_t m1, m2;   // limb moduli, distinct primes below 2^47
+    uint64_t i21, i12; // m2^-1 mod m1, m1^-1 mod m2
+    double inv1, inv2; // 1 / m1, 1 / m2
+};
+__global__ void __launch_bounds__(256)
+k_rns2_to_canon(ulonglong2 *__restrict__ buf, size_t count, Rns2Const rc,
+                const CrtConst *__restrict__ CC, uint32_t *__restrict__ bad) {
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= count) return;
+    const ulonglong2 v = buf[t];
+    if (v.x >= rc.m1 || v.y >= rc.m2) { *bad = 1u; return; }  // not an RNS2Number of these moduli
+    const u128 h1 = mod_wide((u128)v.x * rc.i21, (u128)rc.m1, rc.inv1, nullptr);
+    const u128 h2 = mod_wide((u128)v.y * rc.i12, (u128)rc.m2, rc.inv2, nullptr);
+    u128 x = h1 * rc.m2 + h2 * rc.m1;
+    if (x >= CC->Q) x -= CC->Q;
+    buf[t] = make_ulonglong2((uint64_t)x, (uint64_t)(x >> 64));
+}
+__global__ void __launch_bounds__(256)
+k_canon_to_rns2(ulonglong2 *__restrict__ buf, size_t count, Rns2Const rc) {
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= count) return;
+    const ulonglong2 v = buf[t];
+    const u128 x = ((u128)v.y << 64) | v.x;  // < Q = m1 m2: both quotients are below 2^47
+    buf[t] = make_ulonglong2((uint64_t)mod_wide(x, (u128)rc.m1, rc.inv1, nullptr),
+                             (uint64_t)mod_wide(x, (u128)rc.m2, rc.inv2, nullptr));
 }
 
 // ---- k_debug_ntt ----------------------------------------------------------------------------------

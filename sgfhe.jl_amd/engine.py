@@ -12,6 +12,7 @@ import numpy as np
 from . import _lib
 
 FLAG_RAW_MODQ = 1
+FLAG_RAW_RNS2 = 2
 CTX_RANDOM_FLATTEN = 1
 
 
@@ -81,10 +82,24 @@ class Engine:
         a, ptr = _c(pairs)
         self._chk(self._L.sgfhe_bkey_upload_rns2(self._h, ptr, a.size, m1, m2))
 
+    def rns2_convert(self, values, m1, m2, to_pairs):
+        """src/rns.jl on the device: [..., 2] uint64 canonical {lo, hi} -> (x mod m1, x mod m2)
+        (to_pairs=True, rns.jl:16-18) or limb pairs -> canonical (to_pairs=False, rns.jl:32-40)."""
+        a, ptr = _c(values)
+        out = np.zeros_like(a)
+        self._chk(self._L.sgfhe_rns2_convert(self._h, int(bool(to_pairs)), ptr, a.size // 2, m1, m2,
+                                             out.ctypes.data_as(ctypes.c_void_p)))
+        return out
+
     def generate_key(self, sk_bits, seed, noise=None):
-        """BootstrapKey(rng, sk) (fhe.jl:181-201) generated on the device from a 64-bit seed."""
+        """BootstrapKey(rng, sk) (fhe.jl:181-201) generated on the device from a 32-byte seed
+        (ChaCha20 streams); an int is taken as 32 little-endian bytes (tests, benchmarks)."""
         a, ptr = _c(sk_bits)
-        self._chk(self._L.sgfhe_bkey_generate(self._h, ptr, a.size, seed & 0xFFFFFFFFFFFFFFFF,
+        if not isinstance(seed, (bytes, bytearray)):
+            seed = int(seed).to_bytes(32, "little")
+        if len(seed) != 32:
+            raise ValueError("key seed must be 32 bytes")
+        self._chk(self._L.sgfhe_bkey_generate(self._h, ptr, a.size, bytes(seed),
                                               self.params.n if noise is None else noise))
 
     def key_device_form_bytes(self):
@@ -128,17 +143,19 @@ class Engine:
         keep = (a1, a2, b1, b2)
         return batch, (p1, q1, p2, q2), keep
 
-    def bootstrap_batch(self, a1, b1, a2, b2, raw=False):
+    def bootstrap_batch(self, a1, b1, a2, b2, raw=False, rns2=False):
         """bootstrap(bkey, nothing, ., .) (fhe.jl:608-621) over a batch of LWE pairs.
         Returns [batch][3][n+1] uint64 (AND, OR, XOR; a then b), or [batch][3][n+1][2] residues
-        mod Q with raw=True (_bootstrap_internal, fhe.jl:559-595)."""
+        mod Q with raw=True (_bootstrap_internal, fhe.jl:559-595): {lo, hi} of the canonical
+        value, or with rns2=True the RNS2Number limb pair (v1, v2) (src/rns.jl:16-18)."""
         batch, (p1, q1, p2, q2), _keep = self._lwe_args(a1, b1, a2, b2)
         n = self.params.n
+        raw = raw or rns2
         out = np.zeros((batch, 3, n + 1, 2) if raw else (batch, 3, n + 1), dtype=np.uint64)
         if batch:
             self._chk(self._L.sgfhe_bootstrap_batch(
                 self._h, p1, q1, p2, q2, batch, out.ctypes.data_as(ctypes.c_void_p),
-                FLAG_RAW_MODQ if raw else 0))
+                (FLAG_RAW_MODQ if raw else 0) | (FLAG_RAW_RNS2 if rns2 else 0)))
         return out
 
     def bootstrap_batch_device(self, a1_ptr, b1_ptr, a2_ptr, b2_ptr, batch, out_ptr, raw=False,
@@ -191,6 +208,26 @@ class Engine:
             self._chk(self._L.sgfhe_debug_accumulators(self._h, p1, q1, p2, q2, batch, n_iters,
                                                        acc.ctypes.data_as(ctypes.c_void_p)))
         return acc
+
+    def debug_digits(self, a1, b1, a2, b2, n_iters):
+        """Stored digit planes after n_iters iterations: [batch][2][2][m] uint64 (sgfhe_debug_digits)."""
+        batch, (p1, q1, p2, q2), _keep = self._lwe_args(a1, b1, a2, b2)
+        dig = np.zeros((batch, 2, 2, self.params.m), dtype=np.uint64)
+        if batch:
+            self._chk(self._L.sgfhe_debug_digits(self._h, p1, q1, p2, q2, batch, n_iters,
+                                                 dig.ctypes.data_as(ctypes.c_void_p)))
+        return dig
+
+    def debug_flatten(self, values):
+        """Deterministic flatten_poly of two polynomials: values [2][m][2] uint64 canonical residues
+        -> stored digits [2][2][m] (sgfhe_debug_flatten)."""
+        m = self.params.m
+        a, ptr = _c(values)
+        if a.size != 4 * m:
+            raise ValueError("debug_flatten: values is [2][m][2]")
+        dig = np.zeros((2, 2, m), dtype=np.uint64)
+        self._chk(self._L.sgfhe_debug_flatten(self._h, ptr, dig.ctypes.data_as(ctypes.c_void_p)))
+        return dig
 
     def debug_ntt(self, prime_index, poly, inverse=False):
         x, px = _c(poly, np.uint32)

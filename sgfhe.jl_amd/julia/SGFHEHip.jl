@@ -38,17 +38,27 @@ function check(ctx::Ptr{Cvoid}, rc::Int32)
     error("sgfhe_hip error $rc: $msg")
 end
 
+const CTX_RANDOM_FLATTEN = UInt32(1)
+
+function create_ctx(p::Params, device::Integer, random_flatten::Bool)
+    cp = Ref(CParams(p.n, p.r, p.m, 2, words(p.Q), words(p.B), words(p.DQ_tilde)))
+    ctx = Ref{Ptr{Cvoid}}(C_NULL)
+    rc = ccall((:sgfhe_ctx_create_ex, libsgfhe_hip), Int32,
+               (Ref{CParams}, Cint, UInt32, Ref{Ptr{Cvoid}}), cp, device,
+               random_flatten ? CTX_RANDOM_FLATTEN : UInt32(0), ctx)
+    check(ctx[], rc)
+    ctx
+end
+
 mutable struct HipBootstrapKey
     params::Params
     ctx::Ptr{Cvoid}
 
-    function HipBootstrapKey(bkey::BootstrapKey; device::Integer=0)
+    # random_flatten = true sizes the engine's RNS basis for `rng::AbstractRNG` calls
+    # (SGFHE_CTX_RANDOM_FLATTEN: a sixth prime at Params(1024), nothing elsewhere).
+    function HipBootstrapKey(bkey::BootstrapKey; device::Integer=0, random_flatten::Bool=false)
         p = bkey.params
-        cp = Ref(CParams(p.n, p.r, p.m, 2, words(p.Q), words(p.B), words(p.DQ_tilde)))
-        ctx = Ref{Ptr{Cvoid}}(C_NULL)
-        rc = ccall((:sgfhe_ctx_create, libsgfhe_hip), Int32,
-                   (Ref{CParams}, Cint, Ref{Ptr{Cvoid}}), cp, device, ctx)
-        check(ctx[], rc)
+        ctx = create_ctx(p, device, random_flatten)
         # value.(p.coeffs) of every polynomial, order [k][row][col][coef], 2 x UInt64 each
         # (BootstrapKey.key is a Vector of 4x2 Matrix{Polynomial}, src/fhe.jl:176-201).
         canon = Vector{UInt64}(undef, p.n * 8 * p.m * 2)
@@ -121,19 +131,18 @@ function SGFHE.bootstrap(hkey::HipBootstrapKey, rng::Union{AbstractRNG,Nothing},
 end
 
 """
-    HipBootstrapKey(params, sk::PrivateKey, seed::UInt64; device=0)
+    HipBootstrapKey(params, sk::PrivateKey, seed::Vector{UInt8}; device=0, random_flatten=false)
 
-Generates the bootstrap key on the GPU (BootstrapKey(rng, sk), src/fhe.jl:181-201) from a seed.
+Generates the bootstrap key on the GPU (BootstrapKey(rng, sk), src/fhe.jl:181-201) from a
+32-byte seed (ChaCha20 streams on the device): `rand(RandomDevice(), UInt8, 32)` for real keys.
 """
-function HipBootstrapKey(params::Params, sk::SGFHE.PrivateKey, seed::UInt64; device::Integer=0)
-    cp = Ref(CParams(params.n, params.r, params.m, 2, words(params.Q), words(params.B),
-                     words(params.DQ_tilde)))
-    ctx = Ref{Ptr{Cvoid}}(C_NULL)
-    check(ctx[], ccall((:sgfhe_ctx_create, libsgfhe_hip), Int32,
-                       (Ref{CParams}, Cint, Ref{Ptr{Cvoid}}), cp, device, ctx))
+function HipBootstrapKey(params::Params, sk::SGFHE.PrivateKey, seed::Vector{UInt8};
+                         device::Integer=0, random_flatten::Bool=false)
+    @assert length(seed) == 32
+    ctx = create_ctx(params, device, random_flatten)
     bits = UInt64[UInt64(value(c)) for c in sk.key.coeffs]
     check(ctx[], ccall((:sgfhe_bkey_generate, libsgfhe_hip), Int32,
-                       (Ptr{Cvoid}, Ptr{UInt64}, Csize_t, UInt64, UInt32),
+                       (Ptr{Cvoid}, Ptr{UInt64}, Csize_t, Ptr{UInt8}, UInt32),
                        ctx[], bits, length(bits), seed, UInt32(params.n)))
     key = HipBootstrapKey(params, ctx[], nothing)
     finalizer(k -> ccall((:sgfhe_ctx_destroy, libsgfhe_hip), Int32, (Ptr{Cvoid},), k.ctx), key)
@@ -141,12 +150,14 @@ function HipBootstrapKey(params::Params, sk::SGFHE.PrivateKey, seed::UInt64; dev
 end
 
 """
-    pack_encrypted_bits(hkey, nothing, enc_bits)
+    pack_encrypted_bits(hkey, rng, enc_bits)
 
-src/fhe.jl:660-696 on the GPU: n EncryptedBits -> one RLWE Ciphertext.
+src/fhe.jl:660-696 on the GPU: n EncryptedBits -> one RLWE Ciphertext; `rng` selects the flatten
+mode exactly as for `bootstrap`.
 """
-function SGFHE.pack_encrypted_bits(hkey::HipBootstrapKey, rng::Nothing,
+function SGFHE.pack_encrypted_bits(hkey::HipBootstrapKey, rng::Union{AbstractRNG,Nothing},
                                    enc_bits::AbstractVector{EncryptedBit})
+    set_flatten_mode(hkey, rng)
     p = hkey.params
     @assert length(enc_bits) == p.n
     a, b = lwe_words(enc_bits, p.n)

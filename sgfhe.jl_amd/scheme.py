@@ -125,7 +125,10 @@ class BootstrapKey:
         if on_host:
             self.engine.upload_key(self._generate(rng, sk))
         else:
-            self.engine.generate_key(sk.key, int(rng.integers(0, 1 << 63, dtype=np.uint64)))
+            # 256 bits from the caller's generator (pass a cryptographic one for real keys, e.g.
+            # np.random.Generator over a CSPRNG bit generator, or use Engine.generate_key with
+            # os.urandom(32)); the device expands them with ChaCha20
+            self.engine.generate_key(sk.key, rng.bytes(32))
 
     @classmethod
     def from_canonical(cls, params, residues, device=0, engine=None):

@@ -4,7 +4,13 @@
 The reference itself holds no fixtures and cannot run here, so these vectors are
 the build's own; they pin the C oracle and the HIP engine to the big-integer restatement.
 
-Usage: python tests/golden/make_golden.py [p64] [extprod] [tables] [p512] [p1024]
+cfg4 (BASELINE.json config 4: n = 1024 over the composite Q = B * Bp of the src/fhe2.jl:57-58
+prime rule) is generated with the C restatement in its RNS2Number mode (limb-wise NTT products,
+src/rns.jl:51-60) -- the big-integer oracle would need hours for the 1 GiB key -- and pinned to
+the big-integer oracle where that is affordable: every key polynomial product of slices 0 and 1
+and the accumulators after the first two iterations are recomputed with Kronecker products.
+
+Usage: python tests/golden/make_golden.py [p64] [extprod] [tables] [p512] [p1024] [pack64] [cfg4]
 """
 
 import hashlib
@@ -121,8 +127,88 @@ def pack_case():
             "key_sha256": key_hash(bk)}
 
 
+def cfg4_case():
+    import math
+    import numpy as np
+    import oracle_c as OC
+    n = 1024
+    r = 16 * n
+    bound = math.isqrt(1220 * r ** 4 * n ** 2) + 1
+    Bp = O.find_modulus(r, bound)                        # src/fhe2.jl:57
+    B = O.find_modulus(r, Bp + 1)                        # src/fhe2.jl:58
+    Q = B * Bp
+    p = O.Params.custom(n, Q, B)
+    o = OC.Oracle.from_params(p, rns2=(B, Bp))
+    sk_seed, key_seed, in_seed = 41, 42, 45
+    sk = o.private_key(sk_seed)
+    t0 = time.time()
+    bkey = o.bootstrap_key(sk, key_seed)
+    print("  key (C, RNS2 limbs)", time.time() - t0, "s", flush=True)
+    skl = [int(x) for x in sk]
+    # big-integer check of the first two key slices (a, a * s + e + s_k G)
+    ext = O.resize(skl, p.m)
+    G = O.gadget_matrix(p)
+    for k in range(2):
+        for row in range(4):
+            a = OC.u128_to_ints(bkey[k, row, 0])
+            bb = OC.u128_to_ints(bkey[k, row, 1])
+            a0 = list(a)
+            a0[0] = (a0[0] - ext[k] * G[row][0]) % Q
+            prod = O.poly_mul(a0, ext, Q)
+            e = [(x - y) % Q for x, y in zip(bb, prod)]
+            e[0] = (e[0] - ext[k] * G[row][1]) % Q
+            assert all(v <= n or v >= Q - n for v in e), "noise out of range: key product wrong"
+    print("  key slices 0, 1 verified with Kronecker products", flush=True)
+    bits = np.array([1, 1], dtype=np.uint8)
+    a, b = o.lwe_encrypt_bits(sk, bits, in_seed)
+    l1 = ([int(x) for x in a[0]], int(b[0]))
+    l2 = ([int(x) for x in a[1]], int(b[1]))
+    cps = {}
+    for k in (1, 2, 512, 1024):
+        t0 = time.time()
+        _, acc = o.bootstrap_batch(bkey, a[0:1], b[0:1], a[1:2], b[1:2], n_iters=k, want_acc=True)
+        cps[str(k)] = [h_ints(OC.u128_to_ints(acc[0, 0])), h_ints(OC.u128_to_ints(acc[0, 1]))]
+        print("  acc after", k, time.time() - t0, "s", flush=True)
+    # big-integer oracle for the first two iterations (needs key slices 0 and 1 only)
+    bk2 = [[[OC.u128_to_ints(bkey[k, row, c]) for c in range(2)] for row in range(4)] for k in range(2)]
+    ua = [(x + y) % p.r for x, y in zip(l1[0], l2[0])]
+    ub = (l1[1] + l2[1]) % p.r
+    ba = [0] * p.m
+    bbp = [(c * p.DQ_tilde) % Q for c in O.mul_by_monomial(O.initial_poly(p), -ub, Q)]
+    for k in range(2):
+        A = []
+        for row in range(4):
+            Arow = []
+            for col in range(2):
+                x = O.mul_by_xj_minus_one(bk2[k][row][col], ua[k], Q)
+                x[0] = (x[0] + G[row][col]) % Q
+                Arow.append(x)
+            A.append(Arow)
+        ba, bbp = O.external_product(ba, bbp, A, p.B, p.ell, Q)
+        assert [h_ints(ba), h_ints(bbp)] == cps[str(k + 1)], "C RNS2 path differs from the big-integer oracle"
+    print("  iterations 1, 2 verified with the big-integer oracle", flush=True)
+    raw = o.bootstrap_batch(bkey, a[0:1], b[0:1], a[1:2], b[1:2], raw=True)
+    out = o.bootstrap_batch(bkey, a[0:1], b[0:1], a[1:2], b[1:2])
+    dec = o.lwe_decrypt_bits(sk, out[0, :, :n], out[0, :, n])
+    assert list(dec) == [1, 1, 0], dec
+    case = {"bits": [1, 1], "lwe1": {"a": l1[0], "b": l1[1]}, "lwe2": {"a": l2[0], "b": l2[1]},
+            "acc_sha256_after": cps,
+            "raw_sha256": [h_ints(OC.u128_to_ints(raw[0, g])) for g in range(3)],
+            "out_sha256": [h_ints([int(v) for v in out[0, g]], 8) for g in range(3)],
+            "out_head": [[int(v) for v in out[0, g, :8]] + [int(out[0, g, n])] for g in range(3)]}
+    import hashlib as _h
+    return {"params": {"n": n, "r": r, "m": p.m, "Q": str(Q), "B": str(B), "Bp": str(Bp),
+                       "DQ_tilde": str(p.DQ_tilde)},
+            "prng": "ChaCha20 key streams, SplitMix64 test plumbing (oracle/)", "sk_seed": sk_seed,
+            "key_seed": key_seed, "in_seed": in_seed,
+            "key_sha256": _h.sha256(np.ascontiguousarray(bkey).tobytes()).hexdigest(),
+            "generated_by": "oracle/sgfhe_oracle.c in RNS2Number mode; key slices 0-1 and iterations "
+                            "1-2 re-derived with oracle/bigint_oracle.py",
+            "cases": [case]}
+
+
 def main():
-    what = sys.argv[1:] or ["p64", "extprod", "tables", "p512", "p1024", "pack64"]
+    what = sys.argv[1:] or ["p64", "extprod", "tables", "p512", "p1024", "pack64", "cfg4"]
     pairs4 = [(0, 0), (0, 1), (1, 0), (1, 1)]
     for w in what:
         print(w, flush=True)
@@ -138,6 +224,8 @@ def main():
             d = tables()
         elif w == "pack64":
             d = pack_case()
+        elif w == "cfg4":
+            d = cfg4_case()
         else:
             raise SystemExit("unknown " + w)
         with open(os.path.join(HERE, w + ".json"), "w") as f:

@@ -74,15 +74,57 @@ def test_external_product_golden(S):
     eng.close()
 
 
+@pytest.mark.parametrize("B", [4, 5, 6, 7])
+def test_flatten_kernel_exhaustive_small_moduli(S, B):
+    """k_flatten_canon on its own against the exhaustive tables of test/internals.test.jl:69-112
+    (deterministic branch, l = 2: the engine's decomposition length): every a in Z_q, q = B^2 - 1,
+    restores (sum(b .* B.^(0:l-1)) == a) and lands in the limits of decomposition_limits
+    (:48-66); B in {4, 5} also equal the committed big-integer tables (tests/golden/tables.json)."""
+    import bigint_oracle as BO
+    q = B * B - 1
+    params = S.Params.custom(8, q, B)
+    eng = S.Engine(params)
+    m = params.m
+    vals = np.zeros((2, m, 2), dtype=np.uint64)
+    flat = np.arange(2 * m, dtype=np.uint64) % q          # every residue, several times over
+    vals[:, :, 0] = flat.reshape(2, m)
+    dig = eng.debug_flatten(vals)
+    s = B // 2 - 1 if B % 2 == 0 else (B - 1) // 2
+    lim_lo, lim_hi = q - s, B - s - 1
+    table = None
+    for t in json.load(open(os.path.join(G, "tables.json")))["flatten"]:
+        if t["B"] == B and t["ell"] == 2:
+            table = t["values"]
+    for c in range(2):
+        for j in range(m):
+            a = int(vals[c, j, 0])
+            d = [(int(dig[c, i, j]) - s) % q for i in range(2)]       # stored e_i = u_i + s
+            assert d == BO.flatten(a, B, 2, q)
+            assert (d[0] + d[1] * B) % q == a
+            assert all(x <= lim_hi or x >= lim_lo for x in d)
+            if table is not None:
+                assert d == table[a]
+    with pytest.raises(S.SgfheError):
+        bad = vals.copy()
+        bad[0, 0, 0] = q
+        eng.debug_flatten(bad)
+    eng.close()
+
+
 # ---- edge cases of the boundary ---------------------------------------------------------------------
 
-@pytest.fixture(scope="module")
-def p64(S, oc):
+@pytest.fixture(scope="module", params=["small-batch form", "throughput form"])
+def p64(S, oc, request):
+    """Params(64) engine; every test using it runs once with the default small-batch threshold
+    (chunks of <= 24 bootstraps take k_fwd_phase / k_inv_column) and once with the threshold at 0
+    (every chunk takes k_extprod<9>)."""
     params = S.Params(64)
     o = oc.Oracle.from_params(params)
     sk = o.private_key(1)
     bkey = o.bootstrap_key(sk, 2)
     eng = S.Engine(params)
+    eng.default_small = 24 if request.param == "small-batch form" else 0
+    eng.set_small_batch_max(eng.default_small)
     eng.upload_key(bkey)
     yield params, o, sk, bkey, eng
     eng.close()
@@ -122,8 +164,12 @@ def test_chunk_size_independence_and_determinism(S, p64):
         eng.set_small_batch_max(small)
         for chunk in (0, 8, 24):
             eng.set_chunk(chunk)
-            assert np.array_equal(eng.bootstrap_batch(a1, b1, a2, b2), base)
+            for lanes in (1, 2):                       # 2: pairs of chunks on two streams
+                eng.set_lanes(lanes)
+                assert np.array_equal(eng.bootstrap_batch(a1, b1, a2, b2), base)
+    eng.set_lanes(1)
     eng.set_chunk(0)
+    eng.set_small_batch_max(eng.default_small)         # leave the shared engine as the fixture made it
     assert np.array_equal(base, o.bootstrap_batch(bkey, a1, b1, a2, b2))
 
 
@@ -200,71 +246,6 @@ def test_device_form_export_import(S, p64):
         z = np.zeros((1, params.n), dtype=np.uint64)
         eng3.bootstrap_batch(z, [0], z, [0])
     eng3.close()
-
-
-def test_rns2_key_upload_matches_canonical(S, oc):
-    """BASELINE.json config 4 boundary (src/rns.jl:16-18,32-40): a key held as RNS2Number limb
-    pairs over Q = B * Bp gives the same bootstrap as the same key in canonical form; the result
-    equals the oracle over the composite modulus."""
-    import bigint_oracle as BO
-    n, m = 16, 128
-    Bp = BO.find_modulus(2 * m, 1 << 24)
-    B = BO.find_modulus(2 * m, Bp + 1)                         # rule of src/fhe2.jl:57-58
-    Q = B * Bp
-    params = S.Params.custom(n, Q, B)
-    o = oc.Oracle.from_params(params)
-    assert not o.uses_ntt
-    sk = o.private_key(9)
-    bkey = o.bootstrap_key(sk, 10, noise=2)
-    vals = oc.u128_to_ints(bkey)
-    pairs = np.array([BO.rns2_from_int(v, B, Bp) for v in vals], dtype=np.uint64).reshape(bkey.shape)
-    e1 = S.Engine(params)
-    e1.upload_key(bkey)
-    e2 = S.Engine(params)
-    e2.upload_key_rns2(pairs, B, Bp)
-    bits = np.array([0, 1, 1, 1, 0, 0], dtype=np.uint8)
-    a, b = o.lwe_encrypt_bits(sk, bits, 11)
-    out1 = e1.bootstrap_batch(a[0::2], b[0::2], a[1::2], b[1::2])
-    out2 = e2.bootstrap_batch(a[0::2], b[0::2], a[1::2], b[1::2])
-    assert np.array_equal(out1, out2)
-    assert np.array_equal(out1, o.bootstrap_batch(bkey, a[0::2], b[0::2], a[1::2], b[1::2]))
-    e1.close()
-    e2.close()
-
-
-def test_config4_full_ring_composite_modulus(S, oc):
-    """BASELINE.json config 4 at its real size: n = 1024, m = 8192, Q = B * Bp with the two primes
-    of the src/fhe2.jl:57-58 rule near 2^43.13 (Q ~ 2^86.3, not prime: the oracle multiplies by
-    schoolbook, so only the first k-loop iteration is compared), key handed over as RNS2Number
-    limb pairs (src/rns.jl:16-18)."""
-    import bench
-    import bigint_oracle as BO
-    n, m, r = 1024, 8192, 16384
-    bound = int((1220 * r ** 4 * n ** 2) ** 0.5)
-    Bp = BO.find_modulus(r, bound)
-    B = BO.find_modulus(r, Bp + 1)
-    Q = B * Bp
-    params = S.Params.custom(n, Q, B)
-    assert (params.m, params.r) == (m, r) and 86 < np.log2(float(Q)) < 87
-    o = oc.Oracle.from_params(params)
-    assert not o.uses_ntt
-    key = bench.random_key(params, 5)[:1]                      # only slice k = 0 is used
-    full = np.zeros((n, 4, 2, m, 2), dtype=np.uint64)
-    full[0] = key[0]
-    vals = oc.u128_to_ints(full[0])
-    pairs = np.zeros_like(full)
-    pairs[0] = np.array([BO.rns2_from_int(v, B, Bp) for v in vals], dtype=np.uint64).reshape(full[0].shape)
-    eng = S.Engine(params)
-    eng.upload_key_rns2(pairs, B, Bp)
-    rng = np.random.default_rng(6)
-    a1 = rng.integers(0, r, size=(2, n), dtype=np.uint64)
-    a2 = rng.integers(0, r, size=(2, n), dtype=np.uint64)
-    b1 = rng.integers(0, r, size=2, dtype=np.uint64)
-    b2 = rng.integers(0, r, size=2, dtype=np.uint64)
-    _, acc_ref = o.bootstrap_batch(full, a1, b1, a2, b2, n_iters=1, want_acc=True, threads=2)
-    acc = eng.debug_accumulators(a1, b1, a2, b2, 1)
-    assert np.array_equal(acc, acc_ref)
-    eng.close()
 
 
 def test_batch_position_independence_params1024(S):

@@ -78,16 +78,29 @@ def test_external_product(S, oc, use_gadget):
     eng.close()
 
 
-@pytest.mark.parametrize("n", [8, 16, 32])
-def test_small_synthetic_bootstrap(S, oc, n):
-    """Synthetic tiny rings (m = 64, 128, 256: all three pass structures) vs the oracle:
-    accumulators after every iteration count, raw LWEs mod Q, and ModRed words."""
+FORMS = ["small-batch form", "throughput form"]
+
+
+def _engine(S, params, form):
+    """Engine whose small chunks take the small-batch kernels (k_fwd_phase / k_inv_column, default
+    threshold 24) or, threshold 0, the throughput kernel k_extprod<LOGM> like a large batch."""
+    eng = S.Engine(params)
+    if form == "throughput form":
+        eng.set_small_batch_max(0)
+    return eng
+
+
+@pytest.mark.parametrize("form", FORMS)
+@pytest.mark.parametrize("n", [8, 16, 32, 128, 256])
+def test_small_synthetic_bootstrap(S, oc, n, form):
+    """Synthetic rings (m = 64 ... 2048: every pass structure below the full-size rings) vs the
+    oracle: accumulators after every iteration count, raw LWEs mod Q, and ModRed words."""
     Q, B = _synthetic(n)
     params = S.Params.custom(n, Q, B)
     o = oc.Oracle.from_params(params)
     sk = o.private_key(100 + n)
     bkey = o.bootstrap_key(sk, 200 + n, noise=2)
-    eng = S.Engine(params)
+    eng = _engine(S, params, form)
     eng.upload_key(bkey)
     batch = 5
     bits, a1, b1, a2, b2 = _inputs(o, sk, batch, 300 + n)
@@ -125,7 +138,7 @@ def test_params64_bootstrap_truth_table(S, oc):
 
 # ---- BASELINE.json configurations at full ring size --------------------------------------------
 
-def _big_case(S, oc, params, batch, key_seed, in_seed, valid_key, iters_checked):
+def _big_case(S, oc, params, batch, key_seed, in_seed, valid_key, iters_checked, form=FORMS[0]):
     o = oc.Oracle.from_params(params)
     sk = o.private_key(key_seed)
     if valid_key:
@@ -133,7 +146,7 @@ def _big_case(S, oc, params, batch, key_seed, in_seed, valid_key, iters_checked)
     else:
         import bench
         bkey = bench.random_key(params, key_seed)
-    eng = S.Engine(params)
+    eng = _engine(S, params, form)
     eng.upload_key(bkey)
     bits, a1, b1, a2, b2 = _inputs(o, sk, batch, in_seed)
     for it in iters_checked:
@@ -152,10 +165,11 @@ def _big_case(S, oc, params, batch, key_seed, in_seed, valid_key, iters_checked)
     return out
 
 
-def test_params512_vs_oracle(S, oc):
+@pytest.mark.parametrize("form", FORMS)
+def test_params512_vs_oracle(S, oc, form):
     """BASELINE.json config 2 ring (Params(512), Q 80.25 bits): bit-exact vs the oracle, decrypts."""
     _big_case(S, oc, S.Params(512), batch=8, key_seed=11, in_seed=12, valid_key=True,
-              iters_checked=(1, 2))
+              iters_checked=(1, 2), form=form)
 
 
 def test_params512_full_batch_1024(S, oc):
@@ -177,10 +191,11 @@ def test_params512_full_batch_1024(S, oc):
     eng.close()
 
 
-def test_params1024_vs_oracle(S, oc):
+@pytest.mark.parametrize("form", FORMS)
+def test_params1024_vs_oracle(S, oc, form):
     """BASELINE.json config 4' (the reference's own Params(1024), Q 86.25 bits)."""
     _big_case(S, oc, S.Params(1024), batch=4, key_seed=21, in_seed=22, valid_key=True,
-              iters_checked=(1, 2))
+              iters_checked=(1, 2), form=form)
 
 
 def test_params1024_full_batch_4096(S, oc):
@@ -205,7 +220,8 @@ def test_params1024_full_batch_4096(S, oc):
     eng.close()
 
 
-def test_params2048_largest_reference_ring(S, oc):
+@pytest.mark.parametrize("form", FORMS)
+def test_params2048_largest_reference_ring(S, oc, form):
     """Params(2048): the largest parameter set the reference can build (Q 92.25 bits < 2^128,
     src/fhe.jl:74-77): m = 16384, six RNS primes, B just above 2^46.  The first two k-loop
     iterations against the oracle (only key slices 0 and 1 are filled), then complete gate
@@ -213,7 +229,7 @@ def test_params2048_largest_reference_ring(S, oc):
     import bench
     params = S.Params(2048)
     o = oc.Oracle.from_params(params)
-    eng = S.Engine(params)
+    eng = _engine(S, params, form)
     assert len(eng.primes()) == 6                          # 5 m B Q needs six 29-bit primes
     key = np.zeros((params.n, 4, 2, params.m, 2), dtype=np.uint64)
     key[:2] = bench.random_key(params, 41)[:2]
@@ -241,9 +257,11 @@ def test_params2048_largest_reference_ring(S, oc):
     eng.close()
 
 
-def test_synthetic_single_limb_1024(S, oc):
+@pytest.mark.parametrize("form", FORMS)
+def test_synthetic_single_limb_1024(S, oc, form):
     """BASELINE.json config 3: n = 1024, single-limb 64-bit prime Q', B' = 2^32 (synthetic: the
     parity target is the oracle at the same parameters, not decryption)."""
     import bench
     params = bench.make_params(S, "synth64")
-    _big_case(S, oc, params, batch=2, key_seed=31, in_seed=32, valid_key=False, iters_checked=(1, 3))
+    _big_case(S, oc, params, batch=2, key_seed=31, in_seed=32, valid_key=False, iters_checked=(1, 3),
+              form=form)

@@ -1,0 +1,176 @@
+"""Randomised flatten (`rng::AbstractRNG` branch, src/utils.jl:198-241) on the HIP engine against
+the oracle's literal restatement on the same Philox stream: accumulators, raw and ModRed outputs
+and the digits themselves bit for bit, the reference's digit limits (test/internals.test.jl:48-112,
+use_rng = true) on the device digits, and randomised pack_encrypted_bits (test/api.test.jl:86-108).
+Run on the GPU box with `pytest -m gpu`."""
+
+import numpy as np
+import pytest
+
+import bigint_oracle as BO
+
+pytestmark = pytest.mark.gpu
+
+SEED = 0x0123456789ABCDEF
+
+
+def _key_lists(oc, bkey, n, m):
+    vals = oc.u128_to_ints(bkey)
+    return [[[vals[((k * 4 + r) * 2 + c) * m:((k * 4 + r) * 2 + c + 1) * m] for c in range(2)]
+             for r in range(4)] for k in range(n)]
+
+
+def _setup(S, oc, params, key_seed, noise=None, random_flatten=False):
+    o = oc.Oracle.from_params(params)
+    sk = o.private_key(key_seed)
+    bkey = o.bootstrap_key(sk, key_seed + 1, noise=noise)
+    eng = S.Engine(params, random_flatten=random_flatten)
+    eng.upload_key(bkey)
+    bp = BO.Params.custom(params.n, params.Q, params.B, DQ_tilde=params.DQ_tilde)
+    return o, sk, bkey, eng, bp, _key_lists(oc, bkey, params.n, params.m)
+
+
+def _oracle_run(bp, bk, a1, b1, a2, b2, boot, call, checkpoints):
+    """Oracle bootstrap of one input pair as bootstrap `boot` of call `call`."""
+    rng = BO.PhiloxFlatten(bp, SEED, boot, call)
+    acc = {}
+
+    def trace(k, a, b):
+        if (k + 1) in checkpoints:
+            acc[k + 1] = (list(a), list(b))
+    raw = BO.bootstrap_internal(bp, bk, ([int(x) for x in a1], int(b1)), ([int(x) for x in a2], int(b2)),
+                                trace=trace, rng=rng)
+    return raw, acc, rng
+
+
+def _ints(arr):
+    flat = np.ascontiguousarray(arr).reshape(-1, 2)
+    return [int(lo) | (int(hi) << 64) for lo, hi in flat]
+
+
+@pytest.mark.parametrize("ring", ["params64", "synthetic"])
+def test_random_mode_equals_oracle_bit_for_bit(S, oc, ring):
+    if ring == "params64":
+        params, noise = S.Params(64), None
+    else:                                       # m = 128: another pass structure, odd-free base
+        n = 16
+        params, noise = S.Params.custom(n, BO.find_modulus(16 * n, 1 << 52), 1 << 27), 2
+    o, sk, bkey, eng, bp, bk = _setup(S, oc, params, 300, noise)
+    n, m, B, Q = params.n, params.m, params.B, params.Q
+    bits = np.array([1, 1, 0, 1, 1, 0], dtype=np.uint8)
+    a, b = o.lwe_encrypt_bits(sk, bits, 301)
+    a1, b1, a2, b2 = a[0::2], b[0::2], a[1::2], b[1::2]
+    batch = 3
+    eng.set_random_flatten(True, SEED)
+    checkpoints = (1, 2, n)
+    call = 0
+    s_shift = (B // 2 - 1 if B % 2 == 0 else (B - 1) // 2) + BO.flatten_xmax(B)
+    for it in checkpoints:                      # every call advances the call counter
+        acc = eng.debug_accumulators(a1, b1, a2, b2, it)
+        for t in range(batch):
+            _, ref, _ = _oracle_run(bp, bk, a1[t], b1[t], a2[t], b2[t], t, call, {it})
+            assert _ints(acc[t, 0]) == ref[it][0], "acc_a, bootstrap %d after %d" % (t, it)
+            assert _ints(acc[t, 1]) == ref[it][1], "acc_b, bootstrap %d after %d" % (t, it)
+        call += 1
+    # the digits the next iteration consumes: the oracle's flatten output, inside (-2B, 2B]
+    dig = eng.debug_digits(a1, b1, a2, b2, 2)
+    for t in range(batch):
+        _, ref, rng = _oracle_run(bp, bk, a1[t], b1[t], a2[t], b2[t], t, call, {2})
+        for c in range(2):
+            want = BO.flatten_poly(ref[2][c], B, 2, Q, rng.draws(c, 2))
+            for i in range(2):
+                u = [int(v) - s_shift for v in dig[t, c, i]]
+                assert all(-2 * B < x <= 2 * B for x in u)        # internals.test.jl:48-52
+                assert [x % Q for x in u] == want[i]
+            restored = [(int(dig[t, c, 0, j]) - s_shift + (int(dig[t, c, 1, j]) - s_shift) * B) % Q
+                        for j in range(m)]
+            assert restored == ref[2][c]                          # sum(u .* B.^(0:l-1)) == a
+    call += 1
+    raw = eng.bootstrap_batch(a1, b1, a2, b2, raw=True)
+    for t in range(batch):
+        ref_raw, _, _ = _oracle_run(bp, bk, a1[t], b1[t], a2[t], b2[t], t, call, set())
+        for g in range(3):
+            assert _ints(raw[t, g]) == ref_raw[g][0] + [ref_raw[g][1]]
+    call += 1
+    out = eng.bootstrap_batch(a1, b1, a2, b2)
+    for t in range(batch):
+        ref_raw, _, _ = _oracle_run(bp, bk, a1[t], b1[t], a2[t], b2[t], t, call, set())
+        for g in range(3):
+            want = [BO.reduce_modulus(params.r, x, Q) for x in ref_raw[g][0] + [ref_raw[g][1]]]
+            assert [int(v) for v in out[t, g]] == want
+    y1, y2 = bits[0::2], bits[1::2]
+    for g, fn in enumerate((np.bitwise_and, np.bitwise_or, np.bitwise_xor)):
+        assert np.array_equal(o.lwe_decrypt_bits(sk, out[:, g, :n], out[:, g, n]), fn(y1, y2))
+    eng.close()
+
+
+def test_random_mode_independent_of_scheduling(S, oc):
+    """The draw of a coefficient is addressed by the bootstrap's index in the call, so chunk size,
+    lanes and the small-batch threshold do not change a randomised result (include/sgfhe_hip.h)."""
+    params = S.Params(64)
+    o, sk, bkey, eng, bp, bk = _setup(S, oc, params, 310)
+    bits = np.random.default_rng(5).integers(0, 2, size=2 * 40).astype(np.uint8)
+    a, b = o.lwe_encrypt_bits(sk, bits, 311)
+    a1, b1, a2, b2 = a[0::2], b[0::2], a[1::2], b[1::2]
+
+    def run(chunk, lanes, small):
+        eng.set_chunk(chunk)
+        eng.set_lanes(lanes)
+        eng.set_small_batch_max(small)
+        eng.set_random_flatten(True, SEED)          # resets the call counter
+        return eng.bootstrap_batch(a1, b1, a2, b2)
+    base = run(0, 1, 24)
+    for chunk, lanes, small in ((8, 1, 24), (16, 2, 24), (24, 1, 0), (8, 2, 0), (0, 1, 0), (16, 1, 8)):
+        assert np.array_equal(run(chunk, lanes, small), base), (chunk, lanes, small)
+    # bootstrap 17 of the batch alone is bootstrap 0 of its call: a different stream
+    eng.set_random_flatten(True, SEED)
+    single = eng.bootstrap_batch(a1[17:18], b1[17:18], a2[17:18], b2[17:18])
+    assert not np.array_equal(single[0], base[17])
+    ref_raw, _, _ = _oracle_run(bp, bk, a1[17], b1[17], a2[17], b2[17], 17, 0, set())
+    want = [BO.reduce_modulus(params.r, x, params.Q) for x in ref_raw[0][0] + [ref_raw[0][1]]]
+    assert [int(v) for v in base[17, 0]] == want
+    eng.close()
+
+
+def test_randomised_pack_equals_oracle(S, oc):
+    """pack_encrypted_bits(bkey, rng, enc_bits) (src/fhe.jl:660-696, test/api.test.jl:86-108 with
+    use_rng = true) bit for bit against the oracle on the engine's stream: the n bootstraps and the
+    flatten of every as_i (all m coefficients of the resized polynomial) are randomised."""
+    n = 8
+    params = S.Params.custom(n, BO.find_modulus(16 * n, 1 << 50), 1 << 26)
+    o, sk, bkey, eng, bp, bk = _setup(S, oc, params, 320, noise=2)
+    bits = np.array([1, 0, 0, 1, 1, 1, 0, 1, 0, 0, 1, 0, 1, 1, 1, 0], dtype=np.uint8)
+    a, b = o.lwe_encrypt_bits(sk, bits, 321)
+    eng.set_random_flatten(True, SEED)
+    first = eng.bootstrap_batch(a[:2], b[:2], a[2:4], b[2:4])          # call 0
+    w, v = eng.pack_encrypted_bits(a.reshape(2, n, n), b.reshape(2, n))   # call 1, two ciphertexts
+    skl = [int(x) for x in sk]
+    for ct in range(2):
+        lwes = [([int(x) for x in a[ct * n + i]], int(b[ct * n + i])) for i in range(n)]
+        pw, pv = BO.pack_encrypted_bits(bp, bk, lwes, seed=SEED, ct=ct, call=1)
+        assert [int(x) for x in w[ct]] == pw and [int(x) for x in v[ct]] == pv
+        assert BO.decrypt_ciphertext(bp, skl, pw, pv) == [int(x) for x in bits[ct * n:(ct + 1) * n]]
+    eng.set_random_flatten(False)
+    wd, vd = eng.pack_encrypted_bits(a.reshape(2, n, n), b.reshape(2, n))
+    assert not np.array_equal(wd, w)
+    lw, lv = o.pack_encrypted_bits(bkey, a[:n], b[:n])                  # deterministic: C oracle
+    assert np.array_equal(wd[0], lw) and np.array_equal(vd[0], lv)
+    assert first.shape == (2, 3, n + 1)
+    eng.close()
+
+
+def test_random_mode_needs_headroom_at_params1024(S):
+    """Params(1024) runs on five 29-bit primes (deterministic flatten); the randomised flatten
+    needs the sixth, chosen at ctx creation (SGFHE_CTX_RANDOM_FLATTEN)."""
+    params = S.Params(1024)
+    plain = S.Engine(params)
+    assert len(plain.primes()) == 5
+    with pytest.raises(S.SgfheError) as ei:
+        plain.set_random_flatten(True, 1)
+    assert ei.value.code == -2
+    plain.close()
+    both = S.Engine(params, random_flatten=True)
+    assert len(both.primes()) == 6
+    both.set_random_flatten(True, 1)
+    both.set_random_flatten(False)
+    both.close()

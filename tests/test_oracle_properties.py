@@ -69,6 +69,45 @@ def test_flatten_exhaustive(B, ell):
         assert all(x <= hi or x >= lo for x in d)
 
 
+@pytest.mark.parametrize("B", [4, 5])
+@pytest.mark.parametrize("ell", [3, 4])
+def test_flatten_random_exhaustive(B, ell):
+    """test/internals.test.jl:69-112, use_rng = true: for every a in Z_q the randomised flatten
+    restores a and every digit lies within (-2B, 2B] (decomposition_limits :48-52), with draws from
+    a numpy generator standing for the reference's MersenneTwister."""
+    q = B ** ell - 1
+    lim_lo, lim_hi = q - 2 * B, 2 * B
+    xmax = BO.flatten_xmax(B)
+    rng = np.random.default_rng(100 * B + ell)
+    seen = set()
+    for a in range(q):
+        d = BO.flatten_random(lambda i: int(rng.integers(-xmax, xmax + 1)), a, B, ell, q)
+        assert sum(x * B ** i for i, x in enumerate(d)) % q == a
+        assert all(x <= lim_hi or x >= lim_lo for x in d)
+        seen.add(tuple(d))
+    assert len(seen) > q // 2                   # it is actually randomised
+    for v in (-xmax, xmax):                     # and the extreme draws stay inside the limits
+        for a in range(q):
+            d = BO.flatten_random(lambda i: v, a, B, ell, q)
+            assert sum(x * B ** i for i, x in enumerate(d)) % q == a
+            assert all(x <= lim_hi or x >= lim_lo for x in d)
+
+
+def test_philox_known_answer_and_draw_range():
+    """Philox4x32-10 against the Random123 known-answer vectors; the engine's draw mapping stays
+    inside [-xmax, xmax] and reaches both ends of it."""
+    assert BO.philox4x32((0, 0, 0, 0), 0) == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    assert BO.philox4x32((0xffffffff,) * 4, 0xffffffffffffffff) == [0x408f276d, 0x41c83b0e,
+                                                                     0xa20bc7c6, 0x6d5451fd]
+    assert BO.philox4x32((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344),
+                         (0x299f31d0 << 32) | 0xa4093822) == [0xd16cfe09, 0x94fdcceb, 0x5001e420,
+                                                              0x24126ea1]
+    p = BO.Params.custom(8, 17, 5)                                 # tiny base: both ends show up
+    g = BO.PhiloxFlatten(p, 12345)
+    vals = [g.draws(c, y)(j, i) for c in (0, 1) for y in range(8) for j in range(64) for i in (0, 1)]
+    assert min(vals) == -g.xmax and max(vals) == g.xmax and g.xmax == 6
+
+
 @pytest.mark.parametrize("B", [4, 5, 6, 7])
 def test_flatten_c_matches_python(oc, B):
     q = B * B - 1
@@ -187,6 +226,97 @@ def test_rns2_roundtrip():
         x = g.below_wide(m1 * m2)
         v1, v2 = BO.rns2_from_int(x, m1, m2)
         assert BO.rns2_to_int(v1, v2, m1, m2) == x
+
+
+def test_c_rns2_limbwise_products_equal_bigint(oc):
+    """BASELINE.json config 4 ring, small: Q = B * Bp (rule of src/fhe2.jl:57-58).  The C
+    restatement in RNS2Number mode (products per limb, src/rns.jl:51-60; CRT of rns.jl:32-40)
+    equals its schoolbook product, the big-integer Kronecker product, and a whole bootstrap agrees
+    between the three."""
+    n, m = 16, 128
+    Bp = BO.find_modulus(2 * m, 1 << 24)
+    B = BO.find_modulus(2 * m, Bp + 1)
+    Q = B * Bp
+    p = BO.Params.custom(n, Q, B)
+    o_sb = oc.Oracle.from_params(p)
+    o_rns = oc.Oracle.from_params(p, rns2=(B, Bp))
+    assert o_rns.uses_rns2 and not o_rns.uses_ntt and not o_sb.uses_rns2
+    with pytest.raises(ValueError):
+        oc.Oracle.from_params(p, rns2=(B, Bp + 2))                 # m1 * m2 != Q
+    g = BO.SplitMix64(3)
+    for trial in range(3):
+        a = [g.below_wide(Q) for _ in range(m)]
+        b = [g.below_wide(Q) for _ in range(m)] if trial else [Q - 1] * m
+        want = BO.poly_mul(a, b, Q)
+        assert oc.u128_to_ints(o_rns.poly_mul(_u128(a), _u128(b))) == want
+        assert oc.u128_to_ints(o_sb.poly_mul(_u128(a), _u128(b), schoolbook=True)) == want
+    sk = o_sb.private_key(9)
+    bkey = o_sb.bootstrap_key(sk, 10, noise=2)
+    assert np.array_equal(bkey, o_rns.bootstrap_key(sk, 10, noise=2))
+    bits = np.array([1, 1, 0, 1], dtype=np.uint8)
+    a, b = o_sb.lwe_encrypt_bits(sk, bits, 11)
+    r1 = o_sb.bootstrap_batch(bkey, a[0::2], b[0::2], a[1::2], b[1::2], raw=True)
+    r2 = o_rns.bootstrap_batch(bkey, a[0::2], b[0::2], a[1::2], b[1::2], raw=True)
+    assert np.array_equal(r1, r2)
+    vals = oc.u128_to_ints(bkey)
+    bk = [[[vals[((k * 4 + r) * 2 + c) * m:((k * 4 + r) * 2 + c + 1) * m] for c in range(2)]
+           for r in range(4)] for k in range(n)]
+    big = BO.bootstrap_internal(p, bk, ([int(x) for x in a[0]], int(b[0])), ([int(x) for x in a[1]], int(b[1])))
+    for gate in range(3):
+        assert oc.u128_to_ints(r2[0, gate]) == big[gate][0] + [big[gate][1]]
+    out = o_rns.bootstrap_batch(bkey, a[0::2], b[0::2], a[1::2], b[1::2])
+    assert list(o_rns.lwe_decrypt_bits(sk, out[:, 0, :n], out[:, 0, n])) == [1, 0]
+
+
+def test_chacha20_key_stream_vectors(oc):
+    """The bootstrap-key generator: RFC 8439 section 2.3.2 block test vector, and the C / Python
+    generators produce the same key from an int seed and from 32 explicit bytes."""
+    key = bytes(range(32))
+    blk = BO.chacha20_blocks(key, (0x09000000, 0x4a000000, 0), 2)[1]
+    assert [int(v) for v in blk] == [
+        0xe4e7f110, 0x15593bd1, 0x1fdd0f50, 0xc47120a3, 0xc7f4d1c7, 0x0368c033, 0x9aaa2204, 0x4e6cd4c3,
+        0x466482d2, 0x09aa9f07, 0x05d7c214, 0xa2028bd9, 0xd19c12b5, 0xb94e16de, 0xe883d0cb, 0x4e3c50a2]
+    p = BO.Params.custom(8, BO.find_modulus(128, 1 << 50), 1 << 26)
+    o = oc.Oracle.from_params(p)
+    sk = o.private_key(5)
+    k_int = o.bootstrap_key(sk, 6, noise=2)
+    k_bytes = o.bootstrap_key(sk, (6).to_bytes(32, "little"), noise=2)
+    assert np.array_equal(k_int, k_bytes)
+    assert not np.array_equal(k_int, o.bootstrap_key(sk, 7, noise=2))
+    flat = [c for k in BO.bootstrap_key(p, [int(x) for x in sk], 6, noise=2) for row in k for col in row for c in col]
+    assert oc.u128_to_ints(k_int) == flat
+    with pytest.raises(ValueError):
+        o.bootstrap_key(sk, b"short")
+
+
+# ---- test/api.test.jl:45-83 / :86-108 with use_rng = true, on the engine's Philox stream -----------
+
+def test_randomised_bootstrap_and_pack_decrypt():
+    """bootstrap(bkey, rng, ...) and pack_encrypted_bits(bkey, rng, ...) with the randomised
+    flatten (src/utils.jl:198-241): truth table and packing round trip at Params(64) noise
+    levels on a small ring; different from the deterministic result, reproducible per seed."""
+    n, m = 8, 64
+    Q = BO.find_modulus(2 * m, 1 << 50)
+    p = BO.Params.custom(n, Q, 1 << 26)
+    sk = BO.private_key(p, 7)
+    bk = BO.bootstrap_key(p, sk, 8, noise=2)
+    g = BO.SplitMix64(9)
+    for y1 in (0, 1):
+        for y2 in (0, 1):
+            l1, l2 = BO.lwe_encrypt_bit(p, sk, y1, g), BO.lwe_encrypt_bit(p, sk, y2, g)
+            det = BO.bootstrap(p, bk, l1, l2)
+            rnd = BO.bootstrap(p, bk, l1, l2, rng=BO.PhiloxFlatten(p, 5, boot=3, call=1))
+            assert rnd != det
+            assert rnd == BO.bootstrap(p, bk, l1, l2, rng=BO.PhiloxFlatten(p, 5, boot=3, call=1))
+            assert rnd != BO.bootstrap(p, bk, l1, l2, rng=BO.PhiloxFlatten(p, 5, boot=4, call=1))
+            assert [BO.lwe_decrypt_bit(p, sk, o) for o in rnd] == [y1 & y2, y1 | y2, y1 ^ y2]
+    bits = [1, 0, 0, 1, 1, 1, 0, 1]
+    lwes = [BO.lwe_encrypt_bit(p, sk, b, g) for b in bits]
+    w0, v0 = BO.pack_encrypted_bits(p, bk, lwes)
+    w1, v1 = BO.pack_encrypted_bits(p, bk, lwes, seed=77)
+    assert (w1, v1) != (w0, v0)
+    assert BO.decrypt_ciphertext(p, sk, w1, v1) == bits
+    assert [BO.lwe_decrypt_bit(p, sk, l) for l in BO.split_ciphertext(p, w1, v1)] == bits
 
 
 # ---- test/api.test.jl:86-108 (packing, deterministic branch) on a small synthetic ring ------------

@@ -125,6 +125,52 @@ def test_pipeline_matches_oracle():
         assert E.acc_from_digits(dig_b) == trace[k][1]
 
 
+def test_pipeline_matches_oracle_randomised():
+    """The same with the randomised flatten: the model's Philox digits (device counter layout,
+    shifted representation e = u + s + xmax) against the oracle's literal restatement of
+    src/utils.jl:198-241 on the same stream -- accumulators after every k, and the stored digits
+    equal the oracle's flatten output shifted, inside (-2B, 2B]."""
+    n, m = 8, 64
+    Q = BO.find_modulus(2 * m, 1 << 50)
+    B = 1 << 26
+    p = BO.Params.custom(n, Q, B)
+    sk = BO.private_key(p, 5)
+    bk = BO.bootstrap_key(p, sk, 6, noise=2)
+    E = RM.EngineModel(n, m, Q, B, p.DQ_tilde, random_flatten=True)
+    C = E.C
+    key = [[[E.key_transform(bk[k][rc // 2][rc % 2], pi) for rc in range(8)]
+            for pi in range(C.npr)] for k in range(n)]
+    g = BO.SplitMix64(7)
+    l1 = BO.lwe_encrypt_bit(p, sk, 1, g)
+    l2 = BO.lwe_encrypt_bit(p, sk, 0, g)
+    seed, boot, call = 0x1234567890ABCDEF, 11, 2
+    rng = BO.PhiloxFlatten(p, seed, boot, call)
+    trace = []
+    BO.bootstrap_internal(p, bk, l1, l2, trace=lambda k, a, b: trace.append((list(a), list(b))), rng=rng)
+    ua = [(x + y) % p.r for x, y in zip(l1[0], l2[0])]
+    ub = (l1[1] + l2[1]) % p.r
+    b0 = [(c * p.DQ_tilde) % Q for c in BO.mul_by_monomial(BO.initial_poly(p), -ub, Q)]
+    # k_init in the randomised mode: digits of (acc + off_rnd) with the draws tagged y = 0
+    dig_a = [E.random_digits(C.off_rnd % Q, seed, (i, 0, boot, call)) for i in range(m)]
+    dig_b = [E.random_digits((v + C.off_rnd) % Q, seed, (m + i, 0, boot, call)) for i, v in enumerate(b0)]
+    shift = C.s + C.xmax
+    acc_a, acc_b = [0] * m, b0
+    for k in range(n):
+        # the stored digits are the oracle's randomised flatten of the current accumulators
+        for c, (dig, acc) in enumerate(((dig_a, acc_a), (dig_b, acc_b))):
+            ref = BO.flatten_poly(acc, B, 2, Q, rng.draws(c, k))
+            for i in range(m):
+                u = [dig[i][0] - shift, dig[i][1] - shift]
+                assert all(-2 * B < x <= 2 * B for x in u)
+                assert [x % Q for x in u] == [ref[0][i], ref[1][i]]
+        ys = E.extprod(dig_a, dig_b, key[k], ua[k], random=True)
+        dig_a = E.crt_acc(ys[0], dig_a, rnd=(seed, 0, k + 1, boot, call))
+        dig_b = E.crt_acc(ys[1], dig_b, rnd=(seed, 1, k + 1, boot, call))
+        acc_a, acc_b = E.acc_from_digits(dig_a, random=True), E.acc_from_digits(dig_b, random=True)
+        assert acc_a == trace[k][0]
+        assert acc_b == trace[k][1]
+
+
 def test_exactness_bound_reference_params():
     """5 m B Q < product of the RNS primes for every reference parameter set (20 m B Q when the
     ctx is created for the randomised flatten): prime counts the engine ends up with."""
