@@ -58,6 +58,8 @@ def lib():
         L.sgo_bootstrap_batch.argtypes = [ctypes.c_void_p, _u64p, _u64p, _u64p, _u64p, _u64p,
                                           ctypes.c_size_t, _u64p, ctypes.c_int, ctypes.c_uint64,
                                           _u64p, ctypes.c_int]
+        L.sgo_key_transform.argtypes = [ctypes.c_void_p, _u64p, _u64p, ctypes.c_int]
+        L.sgo_bootstrap_batch_opt.argtypes = L.sgo_bootstrap_batch.argtypes
         L.sgo_pack_encrypted_bits.argtypes = [ctypes.c_void_p, _u64p, _u64p, _u64p, _u64p, _u64p,
                                               ctypes.c_int]
         _lib = L
@@ -206,10 +208,21 @@ class Oracle:
         return np.array([lib().sgo_lwe_decrypt_bit(self._ctx, _p(sk), _p(a[i]), int(b[i]))
                          for i in range(len(b))], dtype=np.uint8)
 
+    def key_transform(self, bkey, threads=None):
+        """NTT-domain key for bootstrap_batch(..., opt=True) (sgo_key_transform)."""
+        bkey = np.ascontiguousarray(bkey, dtype=np.uint64)
+        khat = np.zeros_like(bkey)
+        rc = lib().sgo_key_transform(self._ctx, _p(bkey), _p(khat), threads or os.cpu_count() or 1)
+        if rc:
+            raise RuntimeError("sgo_key_transform failed: %d" % rc)
+        return khat
+
     def bootstrap_batch(self, bkey, a1, b1, a2, b2, raw=False, n_iters=None, want_acc=False,
-                        threads=None):
+                        threads=None, opt=False):
         """fhe.jl:559-621 over a batch.  Returns out ([batch][3][n+1] uint64, or [..][2] if raw)
-        and, if want_acc, the accumulators [batch][2][m][2] after `n_iters` iterations."""
+        and, if want_acc, the accumulators [batch][2][m][2] after `n_iters` iterations.
+        opt=True: `bkey` is the NTT-domain key of key_transform and the k-loop runs in the GPU
+        path's algebra (4 + 2 NTTs per iteration, BASELINE.md `cpu_opt`); same outputs."""
         bkey = np.ascontiguousarray(bkey, dtype=np.uint64)
         a1 = np.ascontiguousarray(a1, dtype=np.uint64).reshape(-1, self.n)
         a2 = np.ascontiguousarray(a2, dtype=np.uint64).reshape(-1, self.n)
@@ -219,7 +232,8 @@ class Oracle:
         shape = (batch, 3, self.n + 1, 2) if raw else (batch, 3, self.n + 1)
         out = np.zeros(shape, dtype=np.uint64)
         acc = np.zeros((batch, 2, self.m, 2), dtype=np.uint64) if want_acc else None
-        rc = lib().sgo_bootstrap_batch(self._ctx, _p(bkey), _p(a1), _p(b1), _p(a2), _p(b2), batch,
+        fn = lib().sgo_bootstrap_batch_opt if opt else lib().sgo_bootstrap_batch
+        rc = fn(self._ctx, _p(bkey), _p(a1), _p(b1), _p(a2), _p(b2), batch,
                                        _p(out), 1 if raw else 0,
                                        self.n if n_iters is None else n_iters,
                                        _p(acc) if want_acc else None,

@@ -565,9 +565,42 @@ int sgo_lwe_decrypt_bit(const sgo_ctx *c, const uint64_t *sk, const uint64_t *a,
 /* fhe.jl:237-244, 0-based i0 = i - 1 with i >= n (both call sites, fhe.jl:586,589) */
 static inline u128 extract_at(const u128 *a, size_t i0, size_t k) { return a[i0 - k]; }
 
-static int bootstrap_one(const sgo_ctx *c, const u128 *bkey, const uint64_t *a1, uint64_t b1,
-                         const uint64_t *a2, uint64_t b2, uint64_t n_iters, u128 *out_raw,
-                         u128 *acc_out) {
+/* One k-loop iteration in the algebra of the GPU path (`cpu_opt`): with
+ * A = (x^j - 1) C_k + G and sum_i u_i G_i = (a, b) (the restore property of flatten,
+ * test/internals.test.jl:138-140,161-165) the external product of fhe.jl:580-581 is
+ *   acc <- acc + (x^j - 1) sum_row u_row (*) C_k[row],
+ * so the key is held in the NTT domain (khat) and an iteration is 4 forward + 2 inverse NTTs
+ * instead of 24.  Exact arithmetic mod Q: bit-identical to the reference-shaped path. */
+static void iteration_opt(const sgo_ctx *c, const u128 *khat_k, uint64_t j, u128 *a, u128 *b,
+                          u128 *work /* 6 m */) {
+    size_t m = c->m;
+    u128 Q = c->Q;
+    mont_t mt = ctx_mont(c);
+    u128 *u[4] = {work, work + m, work + 2 * m, work + 3 * m};
+    u128 *P = work + 4 * m, *rot = work + 5 * m;
+    for (size_t i = 0; i < m; i++) {                                    /* fhe.jl:524-526 */
+        flatten2(c, a[i], &u[0][i], &u[1][i]);
+        flatten2(c, b[i], &u[2][i], &u[3][i]);
+    }
+    for (int row = 0; row < 4; row++) ntt_fwd(c, u[row]);
+    for (int col = 0; col < 2; col++) {
+        for (size_t i = 0; i < m; i++) {
+            u128 acc = 0;
+            for (int row = 0; row < 4; row++)
+                acc = addmod(acc, mont_mul(&mt, u[row][i], khat_k[((size_t)row * 2 + col) * m + i]), Q);
+            P[i] = acc;
+        }
+        ntt_inv(c, P);
+        for (size_t i = 0; i < m; i++) P[i] = mont_mul(&mt, P[i], c->minv_R2);
+        mul_by_monomial(c, P, j, rot);                                  /* fhe.jl:554-556 on the product */
+        u128 *dst = col ? b : a;
+        for (size_t i = 0; i < m; i++) dst[i] = addmod(dst[i], submod(rot[i], P[i], Q), Q);
+    }
+}
+
+static int bootstrap_one(const sgo_ctx *c, const u128 *bkey, const u128 *khat, const uint64_t *a1,
+                         uint64_t b1, const uint64_t *a2, uint64_t b2, uint64_t n_iters,
+                         u128 *out_raw, u128 *acc_out) {
     size_t m = c->m, n = c->n;
     u128 Q = c->Q;
     mont_t mt = ctx_mont(c);
@@ -591,6 +624,10 @@ static int bootstrap_one(const sgo_ctx *c, const u128 *bkey, const uint64_t *a1,
 
     for (uint64_t k = 0; k < n_iters && k < n; k++) {                   /* fhe.jl:579-582 */
         uint64_t j = (a1[k] + a2[k]) % c->r;                            /* fhe.jl:566 */
+        if (khat) {
+            iteration_opt(c, khat + (size_t)k * 8 * m, j, a, b, A);
+            continue;
+        }
         for (int row = 0; row < 4; row++) {
             for (int col = 0; col < 2; col++) {                         /* fhe.jl:580, :554-556 */
                 const u128 *C = bkey + (((size_t)k * 4 + row) * 2 + col) * m;
@@ -622,16 +659,18 @@ static int bootstrap_one(const sgo_ctx *c, const u128 *bkey, const uint64_t *a1,
     return 0;
 }
 
-int sgo_bootstrap_batch(const sgo_ctx *c, const uint64_t *bkey, const uint64_t *a1,
-                        const uint64_t *b1, const uint64_t *a2, const uint64_t *b2, size_t batch,
-                        uint64_t *out, int raw, uint64_t n_iters, uint64_t *acc_out, int threads) {
+static int bootstrap_batch(const sgo_ctx *c, int opt, const uint64_t *bkey, const uint64_t *a1,
+                           const uint64_t *b1, const uint64_t *a2, const uint64_t *b2, size_t batch,
+                           uint64_t *out, int raw, uint64_t n_iters, uint64_t *acc_out, int threads) {
     size_t n = c->n, m = c->m;
     int rc = 0;
+    if (opt && !c->use_ntt) return -2;
 #pragma omp parallel for num_threads(threads > 0 ? threads : 1) schedule(dynamic)
     for (long t = 0; t < (long)batch; t++) {
         u128 *rawbuf = (u128 *)malloc(3 * (n + 1) * sizeof(u128));
-        int r1 = bootstrap_one(c, (const u128 *)bkey, a1 + (size_t)t * n, b1[t],
-                               a2 + (size_t)t * n, b2[t], n_iters, out ? rawbuf : NULL,
+        int r1 = bootstrap_one(c, opt ? NULL : (const u128 *)bkey, opt ? (const u128 *)bkey : NULL,
+                               a1 + (size_t)t * n, b1[t], a2 + (size_t)t * n, b2[t], n_iters,
+                               out ? rawbuf : NULL,
                                acc_out ? (u128 *)acc_out + (size_t)t * 2 * m : NULL);
         if (r1) {
 #pragma omp atomic write
@@ -648,6 +687,29 @@ int sgo_bootstrap_batch(const sgo_ctx *c, const uint64_t *bkey, const uint64_t *
         free(rawbuf);
     }
     return rc;
+}
+
+int sgo_bootstrap_batch(const sgo_ctx *c, const uint64_t *bkey, const uint64_t *a1,
+                        const uint64_t *b1, const uint64_t *a2, const uint64_t *b2, size_t batch,
+                        uint64_t *out, int raw, uint64_t n_iters, uint64_t *acc_out, int threads) {
+    return bootstrap_batch(c, 0, bkey, a1, b1, a2, b2, batch, out, raw, n_iters, acc_out, threads);
+}
+
+/* NTT-domain form of the bootstrap key for sgo_bootstrap_batch_opt: every polynomial through the
+ * forward transform (same [k][row][col][slot] order).  Needs Q prime with 2m | Q - 1. */
+int sgo_key_transform(const sgo_ctx *c, const uint64_t *bkey, uint64_t *khat, int threads) {
+    if (!c->use_ntt) return -2;
+    size_t m = c->m, polys = c->n * 8;
+    memcpy(khat, bkey, polys * m * sizeof(u128));
+#pragma omp parallel for num_threads(threads > 0 ? threads : 1) schedule(static)
+    for (long p = 0; p < (long)polys; p++) ntt_fwd(c, (u128 *)khat + (size_t)p * m);
+    return 0;
+}
+
+int sgo_bootstrap_batch_opt(const sgo_ctx *c, const uint64_t *khat, const uint64_t *a1,
+                            const uint64_t *b1, const uint64_t *a2, const uint64_t *b2, size_t batch,
+                            uint64_t *out, int raw, uint64_t n_iters, uint64_t *acc_out, int threads) {
+    return bootstrap_batch(c, 1, khat, a1, b1, a2, b2, batch, out, raw, n_iters, acc_out, threads);
 }
 
 /* ---------------------------------------------------------------- packing */
@@ -684,8 +746,8 @@ int sgo_pack_encrypted_bits(const sgo_ctx *c, const uint64_t *bkey, const uint64
 #pragma omp parallel for num_threads(threads > 0 ? threads : 1) schedule(dynamic)
     for (long t = 0; t < (long)n; t++) {
         u128 *out3 = (u128 *)malloc(3 * (n + 1) * sizeof(u128));
-        int r1 = bootstrap_one(c, (const u128 *)bkey, zeros, c->Dr, a + (size_t)t * n, b[t], n, out3,
-                               NULL);
+        int r1 = bootstrap_one(c, (const u128 *)bkey, NULL, zeros, c->Dr, a + (size_t)t * n, b[t], n,
+                               out3, NULL);
         if (r1) {
 #pragma omp atomic write
             rc = r1;

@@ -83,6 +83,18 @@ int sgo_bootstrap_batch(const sgo_ctx *ctx, const uint64_t *bkey, const uint64_t
                         const uint64_t *b1, const uint64_t *a2, const uint64_t *b2, size_t batch,
                         uint64_t *out, int raw, uint64_t n_iters, uint64_t *acc_out, int threads);
 
+/*
+ * `cpu_opt` of BASELINE.md section 3: the same bootstrap in the algebra of the GPU path -- key in
+ * the NTT domain (sgo_key_transform), acc <- acc + (x^j - 1) sum_row u_row (*) C_k[row], i.e.
+ * 4 forward + 2 inverse NTTs per iteration instead of 24 -- still 128-bit Montgomery arithmetic
+ * mod Q, bit-identical outputs.  Prime NTT-friendly Q only.  Same arguments as
+ * sgo_bootstrap_batch with khat in place of bkey.
+ */
+int sgo_key_transform(const sgo_ctx *ctx, const uint64_t *bkey, uint64_t *khat, int threads);
+int sgo_bootstrap_batch_opt(const sgo_ctx *ctx, const uint64_t *khat, const uint64_t *a1,
+                            const uint64_t *b1, const uint64_t *a2, const uint64_t *b2, size_t batch,
+                            uint64_t *out, int raw, uint64_t n_iters, uint64_t *acc_out, int threads);
+
 /* fhe.jl:660-696 pack_encrypted_bits(bkey, nothing, enc_bits): a [n][n], b [n] over Z_r ->
  * RLWE (w, v), [m] words in [0, r) each. */
 int sgo_pack_encrypted_bits(const sgo_ctx *ctx, const uint64_t *bkey, const uint64_t *a,

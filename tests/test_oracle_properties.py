@@ -268,6 +268,30 @@ def test_c_rns2_limbwise_products_equal_bigint(oc):
     assert list(o_rns.lwe_decrypt_bits(sk, out[:, 0, :n], out[:, 0, n])) == [1, 0]
 
 
+def test_cpu_opt_variant_is_bit_identical(oc):
+    """BASELINE.md section 3 `cpu_opt` (NTT-domain key, CMux form: 6 NTTs per iteration) against
+    the reference-shaped restatement (24 NTTs): accumulators after 1, 2, n iterations, raw and
+    ModRed outputs, at Params(64) and a synthetic ring; refused where Q has no NTT."""
+    for o, noise in ((oc.Oracle.make(64), None),
+                     (oc.Oracle.from_params(BO.Params.custom(16, BO.find_modulus(256, 1 << 52), 1 << 27)), 2)):
+        sk = o.private_key(3)
+        bkey = o.bootstrap_key(sk, 4, noise=noise)
+        khat = o.key_transform(bkey)
+        bits = np.array([0, 1, 1, 1, 1, 0], dtype=np.uint8)
+        a, b = o.lwe_encrypt_bits(sk, bits, 5)
+        lwe = (a[0::2], b[0::2], a[1::2], b[1::2])
+        for it in (1, 2, o.n):
+            _, acc = o.bootstrap_batch(bkey, *lwe, n_iters=it, want_acc=True)
+            _, acc2 = o.bootstrap_batch(khat, *lwe, n_iters=it, want_acc=True, opt=True)
+            assert np.array_equal(acc, acc2)
+        assert np.array_equal(o.bootstrap_batch(bkey, *lwe, raw=True),
+                              o.bootstrap_batch(khat, *lwe, raw=True, opt=True))
+        assert np.array_equal(o.bootstrap_batch(bkey, *lwe), o.bootstrap_batch(khat, *lwe, opt=True))
+    comp = oc.Oracle(n=8, r=128, m=64, Q=(1 << 60) - 1, B=1 << 30, DQ_tilde=1 << 57)
+    with pytest.raises(RuntimeError):
+        comp.key_transform(np.zeros((8, 4, 2, 64, 2), dtype=np.uint64))
+
+
 def test_chacha20_key_stream_vectors(oc):
     """The bootstrap-key generator: RFC 8439 section 2.3.2 block test vector, and the C / Python
     generators produce the same key from an int seed and from 32 explicit bytes."""
