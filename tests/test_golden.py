@@ -96,6 +96,46 @@ def test_params1024_golden(oc):
     _check_bootstrap_golden(oc, "p1024", full=False)
 
 
+def test_config4_golden(oc):
+    """BASELINE.json config 4 fixture (n = 1024 over the composite Q = B * Bp; tests/golden/cfg4.json,
+    made by the C restatement in RNS2Number mode and cross-checked with the big-integer oracle):
+    the key regenerates from its seed, the accumulators after the first two iterations reproduce,
+    and the big-integer oracle re-derives iteration 1 from the key's first slice."""
+    d = load("cfg4")
+    n, m = d["params"]["n"], d["params"]["m"]
+    Q, B, Bp = int(d["params"]["Q"]), int(d["params"]["B"]), int(d["params"]["Bp"])
+    assert Q == B * Bp and (B - 1) % (2 * m) == 0 and (Bp - 1) % (2 * m) == 0 and Bp < B
+    assert BO.is_prime(B) and BO.is_prime(Bp)
+    p = BO.Params.custom(n, Q, B)
+    o = oc.Oracle.from_params(p, rns2=(B, Bp))
+    sk = o.private_key(d["sk_seed"])
+    bkey = o.bootstrap_key(sk, d["key_seed"])
+    assert hashlib.sha256(np.ascontiguousarray(bkey).tobytes()).hexdigest() == d["key_sha256"]
+    case = d["cases"][0]
+    a1, b1 = np.array([case["lwe1"]["a"]], dtype=np.uint64), [case["lwe1"]["b"]]
+    a2, b2 = np.array([case["lwe2"]["a"]], dtype=np.uint64), [case["lwe2"]["b"]]
+    for k in (1, 2):
+        _, acc = o.bootstrap_batch(bkey, a1, b1, a2, b2, n_iters=k, want_acc=True)
+        ha, hb = case["acc_sha256_after"][str(k)]
+        assert h_ints(oc.u128_to_ints(acc[0, 0])) == ha and h_ints(oc.u128_to_ints(acc[0, 1])) == hb
+    # iteration 1 with Kronecker products over the composite modulus
+    bk0 = [[oc.u128_to_ints(bkey[0, row, c]) for c in range(2)] for row in range(4)]
+    ua0 = (case["lwe1"]["a"][0] + case["lwe2"]["a"][0]) % p.r
+    ub = (case["lwe1"]["b"] + case["lwe2"]["b"]) % p.r
+    G = BO.gadget_matrix(p)
+    A = []
+    for row in range(4):
+        Arow = []
+        for col in range(2):
+            x = BO.mul_by_xj_minus_one(bk0[row][col], ua0, Q)
+            x[0] = (x[0] + G[row][col]) % Q
+            Arow.append(x)
+        A.append(Arow)
+    b0 = [(c * p.DQ_tilde) % Q for c in BO.mul_by_monomial(BO.initial_poly(p), -ub, Q)]
+    ra, rb = BO.external_product([0] * m, b0, A, p.B, p.ell, Q)
+    assert [h_ints(ra), h_ints(rb)] == case["acc_sha256_after"]["1"]
+
+
 def test_pack_encrypted_bits_golden(oc):
     """the C restatement of pack_encrypted_bits (src/fhe.jl:660-696) against
     the big-integer golden vector; decrypts both ways (test/api.test.jl:86-108)."""
