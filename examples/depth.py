@@ -22,7 +22,7 @@ def main(levels=100, chains=16):
     rng = np.random.default_rng()
     params = S.Params(512)
     key = S.PrivateKey(params, rng)
-    bkey = S.BootstrapKey(rng, key)
+    bkey = S.BootstrapKey(rng, key, random_flatten=True)   # both flatten modes are used below
     bits = rng.integers(0, 2, size=params.n).astype(bool)
     enc = S.split_ciphertext(S.encrypt(key, rng, bits))
     e1, e2 = enc[0:2 * chains:2], enc[1:2 * chains:2]

@@ -233,7 +233,7 @@ k_extprod(const uint64_t *__restrict__ dig, const int32_t *__restrict__ keyk,
     const Mod md = mod_of(P);
 
     const int32_t sRd = (mode & MODE_RANDOM) ? P.sRr : P.sR;  // digit offset of the flatten mode
-#ifndef SGFHE_ACC0_64
+#ifdef SGFHE_ACC0_32
     int32_t acc0[E];  // column 0 summed like column 1, Montgomery-reduced per phase (< 2.9 * 2^29)
 #else
     int64_t acc0[E];  // 64-bit NTT-domain sum of column 0 over the four phases (|.| < 2^61)
@@ -295,7 +295,10 @@ k_extprod(const uint64_t *__restrict__ dig, const int32_t *__restrict__ keyk,
 
         // 3. pointwise: z_c += U * K[ph][c]   (fhe.jl:527-528 in the NTT domain), |U| < 3.5 * 2^29,
         //    |K| <= p / 2
-        //    column 0: 64-bit multiply-accumulate (v_mad_i64_i32), reduced once after the loop
+        //    column 0: 64-bit multiply-accumulate (one v_mad_i64_i32 per product), reduced once after
+        //              the loop.  (SGFHE_ACC0_32: Montgomery-reduced per phase into 16 registers
+        //              instead of 32 -- 104 VGPRs and no spills, but 2 more multiplies per product:
+        //              measured 230.8 against 225.1 us per launch, profiles/r02_acc32_* vs r02_v1_*.)
         //    column 1: Montgomery-reduced (|.| < 0.72 * 2^29) and added to the LDS accumulator
 #pragma unroll
         for (int h = 0; h < E / 4; h++) {
@@ -306,7 +309,7 @@ k_extprod(const uint64_t *__restrict__ dig, const int32_t *__restrict__ keyk,
             for (int t = 0; t < 4; t++) {
                 const int e = 4 * h + t;
                 const int32_t u = x[0][e];
-#ifndef SGFHE_ACC0_64
+#ifdef SGFHE_ACC0_32
                 acc0[e] += smont(u, ka[t], md);
 #else
                 acc0[e] += (int64_t)u * ka[t];
@@ -322,7 +325,7 @@ k_extprod(const uint64_t *__restrict__ dig, const int32_t *__restrict__ keyk,
     int32_t z[2][E];
 #pragma unroll
     for (int e = 0; e < E; e++) {
-#ifndef SGFHE_ACC0_64
+#ifdef SGFHE_ACC0_32
         z[0][e] = sred(acc0[e], md);
 #else
         z[0][e] = sred(sredc(acc0[e], md), md);  // |REDC| < 1.4 * 2^29

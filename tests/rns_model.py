@@ -443,12 +443,17 @@ class EngineModel:
                 assert int(np.max(np.abs(v))) <= p + (1 << 16)
                 U.append(self.ntt.forward(self.ntt.to_regs(v), P["twf"], P).reshape(-1))
             for c in range(2):
-                # both columns: Montgomery product per phase (|.| < 0.72 * 2^29), summed over the
-                # four phases (column 0 in registers, column 1 in the LDS accumulator), one sred
-                z = np.zeros(M, dtype=np.int64)
-                for row in range(4):
-                    z = i32(z + smont(U[row], keyslice[pi][row * 2 + c], P))
-                z = sred(z, P)
+                if c == 0:
+                    # column 0: 64-bit accumulation over the four phases, one reduction
+                    acc = sum(U[row] * keyslice[pi][row * 2] for row in range(4))
+                    z = sred(sredc(acc, P), P)
+                else:
+                    # column 1: Montgomery product per phase (|.| < 0.72 * 2^29), summed in the LDS
+                    # accumulator over the four phases, one sred
+                    z = np.zeros(M, dtype=np.int64)
+                    for row in range(4):
+                        z = i32(z + smont(U[row], keyslice[pi][row * 2 + 1], P))
+                    z = sred(z, P)
                 z = self.ntt.inverse(z.reshape(T, self.ntt.E), P["twi"], P)
                 Pn = self.ntt.from_regs(z)                         # natural order, |.| < 1.4 * 2^29
                 if plain:
