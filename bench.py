@@ -168,9 +168,10 @@ def cpu_baseline(p, sk, key_seed, cap, seconds_target=12.0):
     b = rng.integers(0, p.r, size=(2, cores), dtype=np.uint64)
 
     def timed(k, opt):
+        o.bootstrap_batch(k, a[0], b[0], a[1], b[1], n_iters=1, threads=cores, opt=opt)   # thread start-up
         t0 = time.perf_counter()
-        o.bootstrap_batch(k, a[0], b[0], a[1], b[1], n_iters=2, threads=cores, opt=opt)
-        per_iter = max((time.perf_counter() - t0) / 2, 1e-6)
+        o.bootstrap_batch(k, a[0], b[0], a[1], b[1], n_iters=8, threads=cores, opt=opt)
+        per_iter = max((time.perf_counter() - t0) / 8, 1e-6)
         iters = int(min(p.n, max(4, seconds_target / per_iter)))
         t0 = time.perf_counter()
         o.bootstrap_batch(k, a[0], b[0], a[1], b[1], n_iters=iters, threads=cores, opt=opt)

@@ -174,6 +174,17 @@ int32_t sgfhe_external_product(sgfhe_ctx *ctx, const uint64_t *a, const uint64_t
                                const uint64_t *A, uint64_t *a_res, uint64_t *b_res);
 
 /*
+ * One k-loop iteration on caller-chosen operands, exactly as the hot path runs it
+ * (src/fhe.jl:580-581): (a, b) <- external_product(nothing, a, b, (x^j - 1) C .+ G, Val(B), Val(2))
+ * = (a, b) + (x^j - 1) sum_row flatten(a, b)_row (*) C[row], through k_flatten_canon -> k_extprod
+ * (with the rotation) -> k_crt_acc.  a, b: [m][2]; C: [4][2][m][2] canonical residues (one key
+ * slice); j in [0, 2 m).  Host pointers; synchronous.  Parity / debug hook: lets a test drive the
+ * exact-integer CRT to the bound it is sized for (digits +-B/2, key residues +-Q/2, j = m).
+ */
+int32_t sgfhe_debug_cmux(sgfhe_ctx *ctx, const uint64_t *a, const uint64_t *b, const uint64_t *C,
+                         uint64_t j, uint64_t *a_res, uint64_t *b_res);
+
+/*
  * pack_encrypted_bits(bkey, nothing, enc_bits) (src/fhe.jl:660-696, with
  * shortened_external_product :632-641): `count` groups of n LWEs each -> `count` RLWE
  * ciphertexts over Z_r.

@@ -80,6 +80,7 @@ def lib():
         "sgfhe_sync": (i32, [vp]),
         "sgfhe_external_product": (i32, [vp, vp, vp, vp, vp, vp]),
         "sgfhe_pack_encrypted_bits": (i32, [vp, vp, vp, sz, vp, vp]),
+        "sgfhe_debug_cmux": (i32, [vp, vp, vp, vp, u64, vp, vp]),
         "sgfhe_debug_accumulators": (i32, [vp, vp, vp, vp, vp, sz, u64, vp]),
         "sgfhe_debug_digits": (i32, [vp, vp, vp, vp, vp, sz, u64, vp]),
         "sgfhe_debug_flatten": (i32, [vp, vp, vp]),
@@ -101,5 +102,5 @@ EXPORTED_SYMBOLS = (
     "sgfhe_set_chunk", "sgfhe_set_lanes", "sgfhe_set_small_batch_max", "sgfhe_set_random_flatten", "sgfhe_bkey_upload", "sgfhe_bkey_upload_rns2", "sgfhe_rns2_convert", "sgfhe_bkey_generate",
     "sgfhe_bkey_device_form_bytes", "sgfhe_bkey_export_device_form",
     "sgfhe_bkey_import_device_form", "sgfhe_bootstrap_batch", "sgfhe_bootstrap_batch_device",
-    "sgfhe_sync", "sgfhe_external_product", "sgfhe_pack_encrypted_bits", "sgfhe_debug_accumulators", "sgfhe_debug_digits", "sgfhe_debug_flatten", "sgfhe_debug_ntt",
+    "sgfhe_sync", "sgfhe_external_product", "sgfhe_pack_encrypted_bits", "sgfhe_debug_cmux", "sgfhe_debug_accumulators", "sgfhe_debug_digits", "sgfhe_debug_flatten", "sgfhe_debug_ntt",
     "sgfhe_debug_primes", "sgfhe_timing_enable", "sgfhe_timing_read")

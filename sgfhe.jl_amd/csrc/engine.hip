@@ -1220,6 +1220,49 @@ int32_t sgfhe_external_product(sgfhe_ctx *c, const uint64_t *a, const uint64_t *
     return rc;
 }
 
+int32_t sgfhe_debug_cmux(sgfhe_ctx *c, const uint64_t *a, const uint64_t *b, const uint64_t *C,
+                         uint64_t j, uint64_t *a_res, uint64_t *b_res) {
+    if (!c || !a || !b || !C || !a_res || !b_res) return SGFHE_ERR_INVALID_ARG;
+    if (j >= 2 * (uint64_t)c->M) return fail(c, SGFHE_ERR_INVALID_ARG, "debug_cmux: j must be in [0, 2 m)");
+    (void)hipSetDevice(c->device);
+    const uint32_t M = c->M;
+    const uint32_t cpad = 8;
+    int32_t rc = ensure_work(c, cpad);
+    if (rc) return rc;
+    const sgfhe_ctx::Lane &L = c->lane[0];
+    int32_t *d_C = nullptr;
+    ulonglong2 *d_ab = nullptr;
+    HIPCHK(c, hipMalloc(&d_C, (size_t)c->npr * 8 * M * 4));
+    hipError_t e = hipMalloc(&d_ab, (size_t)2 * M * 16);
+    if (e != hipSuccess) { (void)hipFree(d_C); return fail(c, SGFHE_ERR_HIP, hipGetErrorString(e)); }
+    const uint32_t jw = (uint32_t)j;
+    do {
+        rc = key_transform_host(c, C, 8, d_C);  // C[4][2][m] is one key slice
+        if (rc) break;
+        if ((e = hipMemsetAsync(L.dig, 0, (size_t)cpad * 2 * M * 16, c->stream))) break;
+        if ((e = hipMemsetAsync(L.ua, 0, (size_t)cpad * c->n * 4, c->stream))) break;
+        if ((e = hipMemcpyAsync(L.ua, &jw, 4, hipMemcpyHostToDevice, c->stream))) break;  // u.a[0] of bootstrap 0
+        if ((e = hipMemcpyAsync(d_ab, a, (size_t)M * 16, hipMemcpyHostToDevice, c->stream))) break;
+        if ((e = hipMemcpyAsync(d_ab + M, b, (size_t)M * 16, hipMemcpyHostToDevice, c->stream))) break;
+        hipLaunchKernelGGL(k_flatten_canon, dim3((2 * M + 255) / 256), dim3(256), 0, c->stream, d_ab,
+                           L.dig, c->d_crt, 2 * M, (uint32_t)c->logm);
+        rc = launch_extprod(c, L, d_C, cpad, 0, 0u, c->stream);     // iteration k = 0, with the rotation
+        if (rc) break;
+        rc = launch_crt(c, L, cpad, 0u, c->stream);                  // acc <- acc + D, flattened again
+        if (rc) break;
+        hipLaunchKernelGGL(k_dump_acc, dim3((2 * M + 255) / 256), dim3(256), 0, c->stream, L.dig, d_ab,
+                           c->d_crt, 2 * M, (uint32_t)c->logm, 0u);
+        if ((e = hipGetLastError())) break;
+        if ((e = hipMemcpyAsync(a_res, d_ab, (size_t)M * 16, hipMemcpyDeviceToHost, c->stream))) break;
+        if ((e = hipMemcpyAsync(b_res, d_ab + M, (size_t)M * 16, hipMemcpyDeviceToHost, c->stream))) break;
+        e = hipStreamSynchronize(c->stream);
+    } while (0);
+    if (e != hipSuccess && rc == SGFHE_OK) rc = fail(c, SGFHE_ERR_HIP, hipGetErrorString(e));
+    (void)hipFree(d_C);
+    (void)hipFree(d_ab);
+    return rc;
+}
+
 int32_t sgfhe_pack_encrypted_bits(sgfhe_ctx *c, const uint64_t *a, const uint64_t *b, size_t count,
                                   uint64_t *out_w, uint64_t *out_v) {
     if (!c || !a || !b || !out_w || !out_v) return SGFHE_ERR_INVALID_ARG;

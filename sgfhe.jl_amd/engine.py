@@ -201,6 +201,21 @@ class Engine:
                                                  rb.ctypes.data_as(ctypes.c_void_p)))
         return ra, rb
 
+    def debug_cmux(self, a, b, C, j):
+        """One k-loop iteration on chosen operands (sgfhe_debug_cmux): a, b [m][2], C [4][2][m][2]
+        -> (a, b) + (x^j - 1) sum_row flatten(a, b)_row (*) C[row]."""
+        m = self.params.m
+        a, pa = _c(a)
+        b, pb = _c(b)
+        C, pC = _c(C)
+        if a.size != 2 * m or b.size != 2 * m or C.size != 16 * m:
+            raise ValueError("debug_cmux: a, b are [m][2]; C is [4][2][m][2]")
+        ra = np.zeros((m, 2), dtype=np.uint64)
+        rb = np.zeros((m, 2), dtype=np.uint64)
+        self._chk(self._L.sgfhe_debug_cmux(self._h, pa, pb, pC, int(j), ra.ctypes.data_as(ctypes.c_void_p),
+                                           rb.ctypes.data_as(ctypes.c_void_p)))
+        return ra, rb
+
     def debug_accumulators(self, a1, b1, a2, b2, n_iters):
         batch, (p1, q1, p2, q2), _keep = self._lwe_args(a1, b1, a2, b2)
         acc = np.zeros((batch, 2, self.params.m, 2), dtype=np.uint64)
