@@ -265,3 +265,31 @@ def test_synthetic_single_limb_1024(S, oc, form):
     params = bench.make_params(S, "synth64")
     _big_case(S, oc, params, batch=2, key_seed=31, in_seed=32, valid_key=False, iters_checked=(1, 3),
               form=form)
+
+
+def test_params64_soak_4096_random_bootstraps(S, oc):
+    """4096 independent gate bootstraps at Params(64) with a device-generated key, every output
+    word against the oracle (random LWE inputs and valid encryptions mixed), all three gates
+    decrypting where the inputs are encryptions: a wide net for rare range / carry cases of the
+    signed lazy arithmetic (the worst case proper is tests/test_gpu_worstcase.py)."""
+    params = S.Params(64)
+    o = oc.Oracle.from_params(params)
+    sk = o.private_key(71)
+    bkey = o.bootstrap_key(sk, 72)
+    eng = S.Engine(params)
+    eng.generate_key(sk, 72)
+    rng = np.random.default_rng(73)
+    bits = rng.integers(0, 2, size=2 * 2048).astype(np.uint8)
+    a, b = o.lwe_encrypt_bits(sk, bits, 74)
+    a1 = np.concatenate([a[0::2], rng.integers(0, params.r, size=(2048, params.n), dtype=np.uint64)])
+    a2 = np.concatenate([a[1::2], rng.integers(0, params.r, size=(2048, params.n), dtype=np.uint64)])
+    b1 = np.concatenate([b[0::2], rng.integers(0, params.r, size=2048, dtype=np.uint64)])
+    b2 = np.concatenate([b[1::2], rng.integers(0, params.r, size=2048, dtype=np.uint64)])
+    out = eng.bootstrap_batch(a1, b1, a2, b2)
+    ref = o.bootstrap_batch(bkey, a1, b1, a2, b2, threads=16)
+    assert np.array_equal(out, ref)
+    y1, y2 = bits[0::2], bits[1::2]
+    for g, fn in enumerate((np.bitwise_and, np.bitwise_or, np.bitwise_xor)):
+        dec = o.lwe_decrypt_bits(sk, out[:2048, g, :params.n], out[:2048, g, params.n])
+        assert np.array_equal(dec, fn(y1, y2))
+    eng.close()
