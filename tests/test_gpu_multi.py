@@ -30,7 +30,9 @@ def _inputs(params, batch):
             rng.integers(0, params.r, size=batch, dtype=np.uint64))
 
 
-def _worker(rank, world, port, tmpdir):
+def _worker(rank, world, port, tmpdir, one_gpu=False):
+    """One rank of the sharded job.  one_gpu: both ranks drive device 0 and the key blob travels
+    over gloo (RCCL refuses two ranks on one device); everything else is the production path."""
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, root)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -39,11 +41,15 @@ def _worker(rank, world, port, tmpdir):
     import torch
     import torch.distributed as dist
     import sgfhe_jl_amd as S
-    torch.cuda.set_device(rank)
-    dist.init_process_group("nccl", rank=rank, world_size=world,
-                            device_id=torch.device("cuda", rank))
+    dev = 0 if one_gpu else rank
+    torch.cuda.set_device(dev)
+    if one_gpu:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    else:
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", dev))
     params = S.Params(64)
-    eng = S.Engine(params, device=rank)
+    eng = S.Engine(params, device=dev)
     sk = np.random.default_rng(5).integers(0, 2, size=params.n, dtype=np.uint64)
     if rank == 0:
         eng.generate_key(sk, 9)
@@ -58,6 +64,24 @@ def _worker(rank, world, port, tmpdir):
     dist.barrier()
     dist.destroy_process_group()
     eng.close()
+
+
+def test_two_ranks_on_one_gpu_equal_one_process(tmp_path, S):
+    """The multi-rank flow on the hardware this box has: two processes (one ctx each on device 0),
+    rank 0 generates the key and exports the device-form blob, the blob is broadcast (gloo here),
+    rank 1 imports it after the header check, each rank bootstraps its contiguous shard, and the
+    gathered outputs are byte-identical to one process doing the whole batch."""
+    import torch.multiprocessing as mp
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), True), nprocs=world, join=True)
+    params = S.Params(64)
+    eng = S.Engine(params, device=0)
+    eng.generate_key(np.random.default_rng(5).integers(0, 2, size=params.n, dtype=np.uint64), 9)
+    ref = eng.bootstrap_batch(*_inputs(params, 37))
+    eng.close()
+    for r in range(world):
+        full = np.load(os.path.join(str(tmp_path), "full_%d.npy" % r))
+        assert full.tobytes() == ref.tobytes()
 
 
 def test_two_gpu_shards_equal_one_gpu(tmp_path, S):
