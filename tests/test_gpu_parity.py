@@ -166,6 +166,16 @@ def _big_case(S, oc, params, batch, key_seed, in_seed, valid_key, iters_checked,
 
 
 @pytest.mark.parametrize("form", FORMS)
+@pytest.mark.parametrize("n", [128, 256])
+def test_params128_256_vs_oracle(S, oc, n, form):
+    """The reference's parameter sets between Params(64) and Params(512) (Q 68.25 / 74.25 bits,
+    m = 1024 / 2048: the pass structures with a 2- and a 3-stage partial pass): complete
+    bootstraps, bit-exact and decrypting."""
+    _big_case(S, oc, S.Params(n), batch=6, key_seed=40 + n, in_seed=50 + n, valid_key=True,
+              iters_checked=(1, n), form=form)
+
+
+@pytest.mark.parametrize("form", FORMS)
 def test_params512_vs_oracle(S, oc, form):
     """BASELINE.json config 2 ring (Params(512), Q 80.25 bits): bit-exact vs the oracle, decrypts."""
     _big_case(S, oc, S.Params(512), batch=8, key_seed=11, in_seed=12, valid_key=True,
