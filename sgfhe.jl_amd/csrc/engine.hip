@@ -587,7 +587,7 @@ int32_t build_constants(sgfhe_ctx *c) {
     cc.digP = digits_of(cc.DQ);
     cc.digN = digits_of((Q - cc.DQ) % Q);
     u128 cM = 1 % Q;
-    for (int i = 0; i < NPR; i++) cM = (cM * c->primes[i]) % Q;  // < 2^94 * 2^30
+    for (int i = 0; i < NPR; i++) cM = (cM * c->primes[i]) % Q;  // < 2^94 * 2^29
     for (int i = 0; i < NPR; i++) {
         u128 ci = 1 % Q;
         for (int j = 0; j < NPR; j++)
@@ -750,7 +750,7 @@ int32_t key_transform_host(sgfhe_ctx *c, const uint64_t *canon, uint32_t npolys,
 
 extern "C" {
 
-const char *sgfhe_version(void) { return "sgfhe_hip 0.1.0 gfx950"; }
+const char *sgfhe_version(void) { return "sgfhe_hip 0.2.0 gfx950"; }
 
 const char *sgfhe_last_error_string(const sgfhe_ctx *ctx) {
     return ctx ? ctx->err.c_str() : "null context";

@@ -502,7 +502,7 @@ k_crt_acc(const uint32_t *__restrict__ yres, uint64_t *__restrict__ dig,
 // (bootstrap, prime) walks through 4 forward and 2 inverse transforms.  Here the same work is cut
 // into 4 + 2 independent workgroups per (bootstrap, prime), three launches per iteration:
 //   k_fwd_phase   (bootstrap, prime, key row ph)  digit plane -> forward NTT -> products with the
-//                 two key polynomials of that row, reduced to [0, 2p)      -> zpart
+//                 two key polynomials of that row, |.| < 0.72 * 2^29        -> zpart
 //   k_inv_column  (bootstrap, prime, column c)    sum of the four partial products -> inverse NTT
 //                 -> (x^j - 1) rotation -> residues                         -> yres
 //   k_crt_acc     as before.
@@ -753,7 +753,7 @@ k_flatten_canon(const ulonglong2 *__restrict__ in, uint64_t *__restrict__ dig,
 //   1. n bootstraps (trivial encryption of 1, bit_i), AND branch, un-reduced      (k-loop above)
 //   2. k_pack_flatten: as_i = polynomial of the i-th LWE coefficients (fhe.jl:675-677), flattened
 //   3. k_shortprod:   for a group of slices i: sum_i flatten(as_i) * C_i[2:4, :]  in the NTT domain
-//                     (exact integers stay below M / 8 for `G` slices per group), inverse NTT
+//                     (exact integers stay below 0.4 M for `G` slices per group), inverse NTT
 //   4. k_pack_finish: CRT of every group, sum mod Q, w = ModRed(-W), v = ModRed(b - V)
 // ==================================================================================================
 

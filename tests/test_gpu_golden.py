@@ -340,7 +340,7 @@ def test_pack_params512_decrypts(S, oc):
 
 @pytest.mark.parametrize("n", [64, 512])
 def test_device_keygen_equals_oracle_keygen(S, oc, n):
-    """Same SplitMix64 seed -> the device-generated key is byte-identical (in device form) to the
+    """Same 32-byte seed (ChaCha20 streams) -> the device-generated key is byte-identical (in device form) to the
     oracle's key uploaded through sgfhe_bkey_upload, and bootstraps with it decrypt correctly."""
     import torch
     params = S.Params(n)
