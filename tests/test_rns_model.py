@@ -171,6 +171,46 @@ def test_pipeline_matches_oracle_randomised():
         assert acc_b == trace[k][1]
 
 
+def test_model_at_the_exactness_bound():
+    """Digits at +-B/2, key residues at +-Q/2, j = m (x^m - 1 = -2) on a ring whose 5 m B Q sits
+    just under the product of three primes: |D| reaches 0.39 M, the edge of what crt_value's float
+    estimate of alpha is sized for.  (tests/test_gpu_worstcase.py does the same on the device at
+    the real parameter sets.)"""
+    import math
+    n, m, B = 8, 64, 1 << 27
+    primes = RM.rns_primes()[:3]
+    have = sum(math.log2(p) for p in primes)
+    Q = BO.find_modulus(2 * m, int(2 ** (have - math.log2(5.0) - 6 - 27 - 0.02)))
+    while math.log2(5.0) + 6 + 27 + math.log2(Q) + 0.001 >= have:
+        Q = BO.find_modulus(2 * m, Q // 2)
+    E = RM.EngineModel(n, m, Q, B, Q // 8)
+    C = E.C
+    assert C.npr == 3 and 2 * m * B * Q / C.Mrns > 0.36
+    s_ = C.s
+    top = ((((Q - 1) // B) - 1) * B + (B - 1) - C.off) % Q
+    bot = (0 - C.off) % Q
+    kpos, kneg = (Q - 1) // 2, (Q + 1) // 2
+    G = [[1, 0], [B, 0], [0, 1], [0, B]]
+    for a, b, Ck, j in (([top] * m, [top] * m, [[[kpos] * m] * 2] * 4, m),
+                        ([bot] * m, [top] * m, [[[kpos] * m, [kneg] * m]] * 4, m),
+                        ([top if i & 1 else bot for i in range(m)], [bot] * m,
+                         [[[kneg if i & 1 else kpos for i in range(m)], [kpos] * m]] * 4, 2 * m - 1)):
+        A = []
+        for row in range(4):
+            Arow = []
+            for col in range(2):
+                x = BO.mul_by_xj_minus_one(Ck[row][col], j, Q)
+                x[0] = (x[0] + G[row][col]) % Q
+                Arow.append(x)
+            A.append(Arow)
+        want = BO.external_product(a, b, A, B, 2, Q)
+        key = [[E.key_transform(Ck[rc // 2][rc % 2], pi) for rc in range(8)] for pi in range(C.npr)]
+        dig_a, dig_b = [C.digits_of(v) for v in a], [C.digits_of(v) for v in b]
+        ys = E.extprod(dig_a, dig_b, key, j)
+        got = (E.acc_from_digits(E.crt_acc(ys[0], dig_a)), E.acc_from_digits(E.crt_acc(ys[1], dig_b)))
+        assert got[0] == want[0] and got[1] == want[1]
+
+
 def test_exactness_bound_reference_params():
     """5 m B Q < product of the RNS primes for every reference parameter set (20 m B Q when the
     ctx is created for the randomised flatten): prime counts the engine ends up with."""
