@@ -52,7 +52,9 @@ typedef const PrimeK *__restrict__ PrimeSet;
 struct CrtConst {
     u128 Q, B;
     u128 c[NPR_MAX];     // (M / p_i) mod Q
-    u128 T[NPR_MAX + 1]; // (-alpha * M - H') mod Q,  H' = (M / p_last) * (p_last - 1) / 2
+    u128 T[2 * NPR_MAX + 2]; // (-alpha * M - H') mod Q,  H' = (M / p_last) * (p_last - 1) / 2;
+                             // alpha < 2 npr + 1: the residues are non-negative representatives
+                             // below 1.52 p (2.02 p for the last prime), not canonical ones
     u128 offneg;         // (Q - off) mod Q, off = (1 + B) s mod Q
     u128 offneg_rnd;     // the same with s + xmax in place of s (randomised flatten)
     uint64_t xmax;       // v_i uniform in [-xmax, xmax], xmax = 3 (B / 2) (utils.jl:210-214)
@@ -63,8 +65,8 @@ struct CrtConst {
     // 32-bit limb / double views of the same constants for k_crt_acc's 96-bit arithmetic
     uint32_t c32[NPR_MAX][3];
     uint32_t Q32[3];
-    alignas(16) uint32_t T32[NPR_MAX + 1][4];
-    double cd[NPR_MAX], Td[NPR_MAX + 1], Bd;
+    alignas(16) uint32_t T32[2 * NPR_MAX + 2][4];
+    double cd[NPR_MAX], Td[2 * NPR_MAX + 2], Bd;
     float invp[NPR_MAX];
     uint32_t npr;        // number of primes in use
     uint32_t logr;
@@ -205,7 +207,8 @@ __device__ __forceinline__ int32_t digit_reduce(uint64_t e, const Mod &md, int32
 //   dig    [chunk][2][2][m]     digit planes (see above)
 //   keyk   [NPR][4][2][m]       NTT-domain key slice of iteration k (slot order, scaled by kappa,
 //                               centred residues as int32)
-//   yres   [chunk][2][NPR][m]   output residues y_i = (M/p_i)^-1 * D mod p_i (+ hoff), in [0, p_i)
+//   yres   [chunk][2][NPR][m]   output residues y_i = (M/p_i)^-1 * D mod p_i (+ hoff): non-negative
+//                               representatives below 1.52 p_i (2.02 p_i for the last prime)
 //   ua     [chunk][n]           j = u.a[k] of every bootstrap (fhe.jl:566,580)
 // The four digit polynomials u = [a_lo, a_hi, b_lo, b_hi] (fhe.jl:524-526) go through the forward
 // NTT one at a time (phase = key row); the two product polynomials through the inverse NTT one at
@@ -349,7 +352,7 @@ k_extprod(const uint64_t *__restrict__ dig, const int32_t *__restrict__ keyk,
     lds_store<LOGM, 2, LOGE, G::STOP>(z, lds, tid);
     SGFHE_SYNC();
     // Source index of output coefficient i = tid + T e is s_e = (i - j) mod 2m = s_0 + T e:
-    // the swizzled low part is computed once per thread.  Residues leave in [0, p).
+    // the swizzled low part is computed once per thread.
     {
         constexpr uint32_t LOWMASK = (1u << G::STOP) - 1u;
         const uint32_t s0 = ((uint32_t)tid - j) & (2 * M - 1);
@@ -365,8 +368,9 @@ k_extprod(const uint64_t *__restrict__ dig, const int32_t *__restrict__ keyk,
             for (int c = 0; c < 2; c++) {
                 const int32_t v = (int32_t)lds[c * M + addr];
                 const int32_t vs = (he & E) ? -v : v;  // x^m = -1
-                uint32_t y = sfull(vs - z[c][e], md);  // |vs - z| < 2.8 * 2^29 -> [0, p)
-                if (P.hoff) y = condsub(y + P.hoff, (uint32_t)P.p);  // wave-uniform: only the last prime
+                // |vs - z| < 2.8 * 2^29 -> a non-negative representative below 1.52 p; + (p - 1) / 2
+                // for the last prime (hoff is 0 for the others): k_crt_acc takes any such residues
+                const uint32_t y = spos(vs - z[c][e], md) + P.hoff;
                 // streamed out: the residues are not read again by this launch, so they should
                 // not displace the digit planes the other prime-workgroups still want from L2
                 __builtin_nontemporal_store(y, &yb[(size_t)c * npr * M + tid + T * e]);
@@ -379,7 +383,9 @@ k_extprod(const uint64_t *__restrict__ dig, const int32_t *__restrict__ keyk,
 // One thread per (bootstrap, c, coefficient).  With y'_i = (D + H') (M/p_i)^-1 mod p_i:
 //   D + H' = sum_i y'_i (M/p_i) - alpha M,  alpha = floor(sum_i y'_i / p_i)
 // and |D| <= 0.4 M (5 m B Q <= M is checked at ctx creation) puts the fractional part of the sum
-// within 0.5 +- 0.4, so alpha is exact in float (the estimate is off by < 10^-6).  Then x'_new = (x'_old + D) mod Q and the new digits are
+// within 0.5 +- 0.4, so alpha is exact in float (the estimate is off by < 10^-6).  The identity
+// holds for any non-negative representatives y'_i = y_i + t p_i (alpha grows by t): k_extprod
+// hands over residues below 1.52 p_i (2.02 p_i for the last prime), so alpha <= 2 npr.  Then x'_new = (x'_old + D) mod Q and the new digits are
 // (x'_new mod B, x'_new / B)  (flatten, utils.jl:155-189).
 //
 // Arithmetic: S = sum_i y'_i c_i + T[alpha] + x'_old < 2^33 Q.  Its quotient by Q is estimated in
@@ -599,9 +605,7 @@ k_inv_column(const int32_t *__restrict__ zpart, uint32_t *__restrict__ yres,
         const uint32_t addr = hipart ^ lowswz ^ (G::STOP >= 9 ? 0u : swz_bits<LE>(hipart));
         const int32_t v = (int32_t)lds[addr];
         const int32_t vs = (he & E) ? -v : v;  // x^m = -1
-        uint32_t y = sfull(vs - z[0][e], md);
-        if (P.hoff) y = condsub(y + P.hoff, (uint32_t)P.p);
-        yb[tid + T * e] = y;
+        yb[tid + T * e] = spos(vs - z[0][e], md) + P.hoff;
     }
 }
 
