@@ -597,12 +597,12 @@ int32_t build_constants(sgfhe_ctx *c) {
     }
     const uint32_t plast = c->primes[NPR - 1];
     const u128 cH = (cc.c[NPR - 1] * ((plast - 1) / 2)) % Q;
-    for (int a = 0; a < 2 * NPR + 2; a++) cc.T[a] = (Q - (((u128)a * cM) % Q + cH) % Q) % Q;
+    for (int a = 0; a < 6 * NPR + 2; a++) cc.T[a] = (Q - (((u128)a * cM) % Q + cH) % Q) % Q;
     auto limbs = [](u128 v, uint32_t *w, int n) {
         for (int i = 0; i < n; i++) w[i] = (uint32_t)(v >> (32 * i));
     };
     for (int i = 0; i < NPR; i++) { limbs(cc.c[i], cc.c32[i], 3); cc.cd[i] = u128_dbl(cc.c[i]); }
-    for (int a = 0; a < 2 * NPR + 2; a++) { limbs(cc.T[a], cc.T32[a], 4); cc.Td[a] = u128_dbl(cc.T[a]); }
+    for (int a = 0; a < 6 * NPR + 2; a++) { limbs(cc.T[a], cc.T32[a], 4); cc.Td[a] = u128_dbl(cc.T[a]); }
     limbs(Q, cc.Q32, 3);
     cc.Bd = u128_dbl(B);
 

@@ -48,13 +48,15 @@ __device__ __forceinline__ Mod mod_of(const PrimeK &P) { return Mod{P.p, -P.p, P
 // index of the workgroup.
 typedef const PrimeK *__restrict__ PrimeSet;
 
+constexpr int CRT_ALPHA_MAX = 6 * NPR_MAX + 2;  // entries of the alpha-indexed CRT correction table
+
 // CRT / flatten constants, resident in device memory.
 struct CrtConst {
     u128 Q, B;
     u128 c[NPR_MAX];     // (M / p_i) mod Q
-    u128 T[2 * NPR_MAX + 2]; // (-alpha * M - H') mod Q,  H' = (M / p_last) * (p_last - 1) / 2;
-                             // alpha < 2 npr + 1: the residues are non-negative representatives
-                             // below 1.52 p (2.02 p for the last prime), not canonical ones
+    u128 T[CRT_ALPHA_MAX];   // (-alpha * M - H') mod Q,  H' = (M / p_last) * (p_last - 1) / 2;
+                             // alpha < 6 npr + 1: the residues are non-negative representatives
+                             // below 5.7 p (6.2 p for the last prime), not canonical ones
     u128 offneg;         // (Q - off) mod Q, off = (1 + B) s mod Q
     u128 offneg_rnd;     // the same with s + xmax in place of s (randomised flatten)
     uint64_t xmax;       // v_i uniform in [-xmax, xmax], xmax = 3 (B / 2) (utils.jl:210-214)
@@ -65,8 +67,8 @@ struct CrtConst {
     // 32-bit limb / double views of the same constants for k_crt_acc's 96-bit arithmetic
     uint32_t c32[NPR_MAX][3];
     uint32_t Q32[3];
-    alignas(16) uint32_t T32[2 * NPR_MAX + 2][4];
-    double cd[NPR_MAX], Td[2 * NPR_MAX + 2], Bd;
+    alignas(16) uint32_t T32[CRT_ALPHA_MAX][4];
+    double cd[NPR_MAX], Td[CRT_ALPHA_MAX], Bd;
     float invp[NPR_MAX];
     uint32_t npr;        // number of primes in use
     uint32_t logr;
@@ -208,7 +210,7 @@ __device__ __forceinline__ int32_t digit_reduce(uint64_t e, const Mod &md, int32
 //   keyk   [NPR][4][2][m]       NTT-domain key slice of iteration k (slot order, scaled by kappa,
 //                               centred residues as int32)
 //   yres   [chunk][2][NPR][m]   output residues y_i = (M/p_i)^-1 * D mod p_i (+ hoff): non-negative
-//                               representatives below 1.52 p_i (2.02 p_i for the last prime)
+//                               representatives below 5.7 p_i (6.2 p_i for the last prime)
 //   ua     [chunk][n]           j = u.a[k] of every bootstrap (fhe.jl:566,580)
 // The four digit polynomials u = [a_lo, a_hi, b_lo, b_hi] (fhe.jl:524-526) go through the forward
 // NTT one at a time (phase = key row); the two product polynomials through the inverse NTT one at
@@ -349,6 +351,7 @@ k_extprod(const uint64_t *__restrict__ dig, const int32_t *__restrict__ keyk,
         return;
     }
     const uint32_t j = ua[(size_t)b * n + k];
+    const uint32_t yoff = 3u * (uint32_t)P.p + P.hoff;
     lds_store<LOGM, 2, LOGE, G::STOP>(z, lds, tid);
     SGFHE_SYNC();
     // Source index of output coefficient i = tid + T e is s_e = (i - j) mod 2m = s_0 + T e:
@@ -368,9 +371,10 @@ k_extprod(const uint64_t *__restrict__ dig, const int32_t *__restrict__ keyk,
             for (int c = 0; c < 2; c++) {
                 const int32_t v = (int32_t)lds[c * M + addr];
                 const int32_t vs = (he & E) ? -v : v;  // x^m = -1
-                // |vs - z| < 2.8 * 2^29 -> a non-negative representative below 1.52 p; + (p - 1) / 2
-                // for the last prime (hoff is 0 for the others): k_crt_acc takes any such residues
-                const uint32_t y = spos(vs - z[c][e], md) + P.hoff;
+                // |vs - z| < 2.7 p: + 3 p makes a non-negative representative below 5.7 p (no
+                // reduction at all: k_crt_acc takes any such residues); + (p - 1) / 2 for the last
+                // prime, folded into the same wave-uniform constant
+                const uint32_t y = (uint32_t)(vs - z[c][e]) + yoff;
                 // streamed out: the residues are not read again by this launch, so they should
                 // not displace the digit planes the other prime-workgroups still want from L2
                 __builtin_nontemporal_store(y, &yb[(size_t)c * npr * M + tid + T * e]);
@@ -385,10 +389,10 @@ k_extprod(const uint64_t *__restrict__ dig, const int32_t *__restrict__ keyk,
 // and |D| <= 0.4 M (5 m B Q <= M is checked at ctx creation) puts the fractional part of the sum
 // within 0.5 +- 0.4, so alpha is exact in float (the estimate is off by < 10^-6).  The identity
 // holds for any non-negative representatives y'_i = y_i + t p_i (alpha grows by t): k_extprod
-// hands over residues below 1.52 p_i (2.02 p_i for the last prime), so alpha <= 2 npr.  Then x'_new = (x'_old + D) mod Q and the new digits are
+// hands over residues below 5.7 p_i (6.2 p_i for the last prime), so alpha < 6 npr + 1.  Then x'_new = (x'_old + D) mod Q and the new digits are
 // (x'_new mod B, x'_new / B)  (flatten, utils.jl:155-189).
 //
-// Arithmetic: S = sum_i y'_i c_i + T[alpha] + x'_old < 2^33 Q.  Its quotient by Q is estimated in
+// Arithmetic: S = sum_i y'_i c_i + T[alpha] + x'_old < 2^35 Q.  Its quotient by Q is estimated in
 // double precision (error < 1), the remainder is formed modulo 2^96 in three 32-bit limbs
 // (v_mad_u64_u32 chains) and corrected by at most one +-Q; same scheme for the division by B.
 struct U96 {
@@ -592,6 +596,7 @@ k_inv_column(const int32_t *__restrict__ zpart, uint32_t *__restrict__ yres,
     // y = x^j P - P  (as in k_extprod)
     uint32_t *yb = yres + (((size_t)b * 2 + c) * npr + pi) * M;
     const uint32_t j = ua[(size_t)b * n + k];
+    const uint32_t yoff = 3u * (uint32_t)P.p + P.hoff;  // as in k_extprod
     lds_store<LOGM, 1, LE, G::STOP>(z, lds, tid);  // own addresses: the thread's last loads
     SGFHE_SYNC();
     constexpr uint32_t LOWMASK = (1u << G::STOP) - 1u;
@@ -605,7 +610,7 @@ k_inv_column(const int32_t *__restrict__ zpart, uint32_t *__restrict__ yres,
         const uint32_t addr = hipart ^ lowswz ^ (G::STOP >= 9 ? 0u : swz_bits<LE>(hipart));
         const int32_t v = (int32_t)lds[addr];
         const int32_t vs = (he & E) ? -v : v;  // x^m = -1
-        yb[tid + T * e] = spos(vs - z[0][e], md) + P.hoff;
+        yb[tid + T * e] = (uint32_t)(vs - z[0][e]) + yoff;
     }
 }
 

@@ -58,14 +58,6 @@ __device__ __forceinline__ int32_t sred(int32_t x, const Mod &md) {
     return x - q * md.p;
 }
 
-// Range reduction to a NON-NEGATIVE representative, for residues handed to the CRT kernel (which
-// takes any non-negative representatives): same cost as sred, no sign fix-up afterwards.
-//   q = round(x / 2^29) - 1,  r = x - q p  in  (0.48 * 2^29, 1.52 * 2^29)   for |x| < 3.5 * 2^29.
-__device__ __forceinline__ uint32_t spos(int32_t x, const Mod &md) {
-    const int32_t q = (x - (1 << 28)) >> 29;
-    return (uint32_t)(x - q * md.p);
-}
-
 // x in (-p, p) -> the canonical representative in [0, p).
 __device__ __forceinline__ uint32_t scanon(int32_t x, const Mod &md) {
     return (uint32_t)(x + ((x >> 31) & md.p));

@@ -96,7 +96,7 @@ class Consts:
         plast = self.primes[-1]
         cM = prod % Q
         cH = self.c[-1] * ((plast - 1) // 2) % Q
-        self.T = [(Q - (a * cM + cH) % Q) % Q for a in range(2 * NPR + 2)]
+        self.T = [(Q - (a * cM + cH) % Q) % Q for a in range(6 * NPR + 2)]
         self.pk = []
         for i, p in enumerate(self.primes):
             psi = None
@@ -181,16 +181,6 @@ def scanon(x, P):
 
 def sfull(x, P):
     return scanon(sred(x, P), P)
-
-
-def spos(x, P):
-    """Non-negative representative in (0.48, 1.52) * 2^29 (rns_arith.h spos)."""
-    x = i32(x)
-    i32(x - (1 << 28))
-    q = (x - (1 << 28)) >> 29
-    r = x - q * np.int64(P["p"])
-    assert int(r.min()) > 0 and int(r.max()) < int(1.52 * 2 ** 29)
-    return r
 
 
 def scentre(x, P):
@@ -473,7 +463,9 @@ class EngineModel:
                 s = (i - j) & (2 * M - 1)
                 v = Pn[s & (M - 1)]
                 v = np.where((s & M) != 0, -v, v)
-                ys[c][pi] = spos(i32(v - Pn), P) + P["hoff"]      # non-canonical, non-negative
+                y = i32(v - Pn) + 3 * p + P["hoff"]               # non-canonical, non-negative
+                assert int(y.min()) > 0 and int(y.max()) < (1 << 32)
+                ys[c][pi] = y
         return ys
 
     def crt_value(self, y, x_old=0):
