@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def kernel_body(asm, pattern):
-    m = re.search(r"^_ZN5sgfhe9%s[^:\n]*:.*?\n(.*?)\n\s*s_endpgm" % pattern, asm, re.S | re.M)
+    m = re.search(r"^_ZN5sgfhe9%s[^:\n]*:.*?\n(.*?)\n\.Lfunc_end" % pattern, asm, re.S | re.M)
     if not m:
         raise SystemExit("kernel %s not found in the assembly" % pattern)
     return m.group(1)
