@@ -350,14 +350,19 @@ k_extprod(const uint64_t *__restrict__ dig, const int32_t *__restrict__ keyk,
     SGFHE_SYNC();  // every thread has taken its z_1 out of the buffer the exchanges now reuse
     ntt_inverse<LOGM, 2, LOGE>(z, lds, P.twi, tid, md);  // |z| < 1.4 * 2^29
 
-    uint32_t *yb = yres + ((size_t)b * 2 * npr + pi) * M;
+    // Output addressing as for the digit loads: two wave-uniform bases (one per column), the
+    // coefficient stride a compile-time constant, one 32-bit lane offset.
+    char *const yb0 = reinterpret_cast<char *>(yres + ((size_t)b * 2 * npr + pi) * M);
+    char *const yb1 = yb0 + (size_t)npr * M * 4u;
+    const uint32_t vout = 4u * (uint32_t)tid;
     // 5. y = x^j P - P  (mul_by_xj_minus_one, fhe.jl:554-556, applied to the product)
     if (mode & MODE_PLAIN) {
 #pragma unroll
         for (int c = 0; c < 2; c++)
 #pragma unroll
             for (int e = 0; e < E; e++)
-                yb[(size_t)c * npr * M + tid + T * e] = condsub(sfull(z[c][e], md) + P.hoff, (uint32_t)P.p);
+                *reinterpret_cast<uint32_t *>((c ? yb1 : yb0) + (size_t)(4 * T * e) + vout) =
+                    condsub(sfull(z[c][e], md) + P.hoff, (uint32_t)P.p);
         return;
     }
     const uint32_t j = ua[(size_t)b * n + k];
@@ -377,17 +382,22 @@ k_extprod(const uint64_t *__restrict__ dig, const int32_t *__restrict__ keyk,
             const uint32_t hipart = (he & (E - 1)) << G::STOP;
             // swz is XOR-linear; for m = 8192 the e bits lie above every bit it reads
             const uint32_t addr = hipart ^ lowswz ^ (G::STOP >= 9 ? 0u : swz_bits<LOGE>(hipart));
+            // x^m = -1: the source is negated when bit LOGE of he is set.  -v = (v ^ -1) + 1, so
+            // with smask = 0 / -1 the output is (v ^ smask) + (yoff - smask - z): one subtract and
+            // one xor-add per residue, the per-e constants shared by both columns.
+            const uint32_t smask = 0u - ((he >> LOGE) & 1u);
+            const uint32_t yoe = yoff - smask;
 #pragma unroll
             for (int c = 0; c < 2; c++) {
-                const int32_t v = (int32_t)lds[c * M + addr];
-                const int32_t vs = (he & E) ? -v : v;  // x^m = -1
-                // |vs - z| < 2.7 p: + 3 p makes a non-negative representative below 5.7 p (no
+                const uint32_t v = lds[c * M + addr];
+                // |+-v - z| < 2.7 p: + 3 p makes a non-negative representative below 5.7 p (no
                 // reduction at all: k_crt_acc takes any such residues); + (p - 1) / 2 for the last
                 // prime, folded into the same wave-uniform constant
-                const uint32_t y = (uint32_t)(vs - z[c][e]) + yoff;
+                const uint32_t y = (v ^ smask) + (yoe - (uint32_t)z[c][e]);
                 // streamed out: the residues are not read again by this launch, so they should
                 // not displace the digit planes the other prime-workgroups still want from L2
-                __builtin_nontemporal_store(y, &yb[(size_t)c * npr * M + tid + T * e]);
+                __builtin_nontemporal_store(
+                    y, reinterpret_cast<uint32_t *>((c ? yb1 : yb0) + (size_t)(4 * T * e) + vout));
             }
         }
     }
