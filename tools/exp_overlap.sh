@@ -1,0 +1,10 @@
+# two-stream overlap of k_crt_acc with k_extprod: does a 104-VGPR k_extprod (SGFHE_ACC0_32) leave
+# room for the CRT waves on the same SIMDs?   usage (GPU box): bash tools/exp_overlap.sh
+B="python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-host-io"
+P='import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d["roofline"]; print("RESULT", sys.argv[1], round(d["value"],1), "ext_us", round(r["launch_ms"]*1e3,1), "crt_us", round(r["pair_launch_ms"]*1e3,1))'
+for i in 1 2; do
+$B --lanes 1 | python -c "$P" acc64_lanes1_$i
+$B --lanes 2 | python -c "$P" acc64_lanes2_$i
+SGFHE_HIP_LIB=$PWD/tools/abl/lib_acc32.so $B --lanes 1 | python -c "$P" acc32_lanes1_$i
+SGFHE_HIP_LIB=$PWD/tools/abl/lib_acc32.so $B --lanes 2 | python -c "$P" acc32_lanes2_$i
+done
