@@ -140,6 +140,11 @@ int32_t fail(sgfhe_ctx *ctx, int32_t code, const std::string &msg) {
 }
 
 size_t lds_bytes(int logm, int npoly) { return (size_t)npoly * ((size_t)4 << logm); }
+// points per thread of k_extprod: 16, or 8 where 16 would leave half a wavefront idle (m <= 512)
+#ifndef SGFHE_EXT_LE3_MAX
+#define SGFHE_EXT_LE3_MAX 9
+#endif
+template <int LOGM> constexpr int ext_loge() { return LOGM <= SGFHE_EXT_LE3_MAX ? 3 : LOGE; }
 template <int LOGM> constexpr int threads_of() { return NttGeom<LOGM, LOGE>::T; }
 
 // ---- per-LOGM dispatch ------------------------------------------------------------------------
@@ -151,11 +156,12 @@ int32_t launch_extprod_t(sgfhe_ctx *c, const sgfhe_ctx::Lane &L, const int32_t *
                          uint32_t cpad, uint32_t k, uint32_t mode, hipStream_t st) {
     const size_t lds = lds_bytes(LOGM, 2);  // exchange buffer + z1 accumulator
     if (!(c->attr_done & ATTR_EXTPROD)) {
-        HIPCHK(c, hipFuncSetAttribute((const void *)k_extprod<LOGM>,
+        HIPCHK(c, hipFuncSetAttribute((const void *)k_extprod<LOGM, ext_loge<LOGM>()>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         c->attr_done |= ATTR_EXTPROD;
     }
-    hipLaunchKernelGGL(k_extprod<LOGM>, dim3(cpad * c->npr), dim3(threads_of<LOGM>()), lds, st, L.dig,
+    hipLaunchKernelGGL((k_extprod<LOGM, ext_loge<LOGM>()>), dim3(cpad * c->npr),
+                       dim3(NttGeom<LOGM, ext_loge<LOGM>()>::T), lds, st, L.dig,
                        keyk, L.yres, L.ua, c->d_primes, k, c->n, mode);
     HIPCHK(c, hipGetLastError());
     return SGFHE_OK;

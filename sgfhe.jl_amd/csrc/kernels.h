@@ -218,12 +218,13 @@ __device__ __forceinline__ int32_t digit_reduce(uint64_t e, const Mod &md, int32
 #ifndef SGFHE_EXT_WAVES
 #define SGFHE_EXT_WAVES 4
 #endif
-template <int LOGM>
-__global__ void __launch_bounds__((NttGeom<LOGM, LOGE>::T), (NttGeom<LOGM, LOGE>::T >= 256 ? SGFHE_EXT_WAVES : 1))
+// LE: points per thread (2^LE); 16 wherever that leaves a full wavefront, 8 for m <= 512
+template <int LOGM, int LE>
+__global__ void __launch_bounds__((NttGeom<LOGM, LE>::T), (NttGeom<LOGM, LE>::T >= 256 ? SGFHE_EXT_WAVES : 1))
 k_extprod(const uint64_t *__restrict__ dig, const int32_t *__restrict__ keyk,
           uint32_t *__restrict__ yres, const uint32_t *__restrict__ ua, PrimeSet PS, uint32_t k,
           uint32_t n, uint32_t mode) {
-    using G = NttGeom<LOGM, LOGE>;
+    using G = NttGeom<LOGM, LE>;
     constexpr int M = G::M, T = G::T, E = G::E;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     int32_t *const z1 = reinterpret_cast<int32_t *>(lds) + M + threadIdx.x;  // z1[e * T]: private to the thread, conflict-free
@@ -302,9 +303,9 @@ k_extprod(const uint64_t *__restrict__ dig, const int32_t *__restrict__ keyk,
             }
         };
         if constexpr (KEY_EARLY) {
-            ntt_forward<LOGM, 1, LOGE>(x, lds, P.twf, tid, md, load_key);
+            ntt_forward<LOGM, 1, LE>(x, lds, P.twf, tid, md, load_key);
         } else {
-            ntt_forward<LOGM, 1, LOGE>(x, lds, P.twf, tid, md);
+            ntt_forward<LOGM, 1, LE>(x, lds, P.twf, tid, md);
             load_key();
         }
 
@@ -348,7 +349,7 @@ k_extprod(const uint64_t *__restrict__ dig, const int32_t *__restrict__ keyk,
         z[1][e] = sred(z1[e * T], md);           // four phases: < 2.9 * 2^29
     }
     SGFHE_SYNC();  // every thread has taken its z_1 out of the buffer the exchanges now reuse
-    ntt_inverse<LOGM, 2, LOGE>(z, lds, P.twi, tid, md);  // |z| < 1.4 * 2^29
+    ntt_inverse<LOGM, 2, LE>(z, lds, P.twi, tid, md);  // |z| < 1.4 * 2^29
 
     // Output addressing as for the digit loads: two wave-uniform bases (one per column), the
     // coefficient stride a compile-time constant, one 32-bit lane offset.
@@ -367,25 +368,25 @@ k_extprod(const uint64_t *__restrict__ dig, const int32_t *__restrict__ keyk,
     }
     const uint32_t j = ua[(size_t)b * n + k];
     const uint32_t yoff = 3u * (uint32_t)P.p + P.hoff;
-    lds_store<LOGM, 2, LOGE, G::STOP>(z, lds, tid);
+    lds_store<LOGM, 2, LE, G::STOP>(z, lds, tid);
     SGFHE_SYNC();
     // Source index of output coefficient i = tid + T e is s_e = (i - j) mod 2m = s_0 + T e:
     // the swizzled low part is computed once per thread.
     {
         constexpr uint32_t LOWMASK = (1u << G::STOP) - 1u;
         const uint32_t s0 = ((uint32_t)tid - j) & (2 * M - 1);
-        const uint32_t lowswz = swz<LOGE>(s0 & LOWMASK);
+        const uint32_t lowswz = swz<LE>(s0 & LOWMASK);
         const uint32_t h0 = s0 >> G::STOP;
 #pragma unroll
         for (int e = 0; e < E; e++) {
             const uint32_t he = h0 + e;
             const uint32_t hipart = (he & (E - 1)) << G::STOP;
             // swz is XOR-linear; for m = 8192 the e bits lie above every bit it reads
-            const uint32_t addr = hipart ^ lowswz ^ (G::STOP >= 9 ? 0u : swz_bits<LOGE>(hipart));
-            // x^m = -1: the source is negated when bit LOGE of he is set.  -v = (v ^ -1) + 1, so
+            const uint32_t addr = hipart ^ lowswz ^ (G::STOP >= 9 ? 0u : swz_bits<LE>(hipart));
+            // x^m = -1: the source is negated when bit LE of he is set.  -v = (v ^ -1) + 1, so
             // with smask = 0 / -1 the output is (v ^ smask) + (yoff - smask - z): one subtract and
             // one xor-add per residue, the per-e constants shared by both columns.
-            const uint32_t smask = 0u - ((he >> LOGE) & 1u);
+            const uint32_t smask = 0u - ((he >> LE) & 1u);
             const uint32_t yoe = yoff - smask;
 #pragma unroll
             for (int c = 0; c < 2; c++) {
