@@ -1,6 +1,8 @@
 # two-stream overlap of k_crt_acc with k_extprod: does a 104-VGPR k_extprod (SGFHE_ACC0_32) leave
 # room for the CRT waves on the same SIMDs?   usage (GPU box): bash tools/exp_overlap.sh
 B="python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-host-io"
+# variant library (build here, it travels with gpurun; tools/abl/ is git-ignored):
+#   mkdir -p tools/abl && (cd sgfhe.jl_amd/csrc && hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DSGFHE_ACC0_32 -shared -o ../../tools/abl/lib_acc32.so engine.hip)
 P='import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d["roofline"]; print("RESULT", sys.argv[1], round(d["value"],1), "ext_us", round(r["launch_ms"]*1e3,1), "crt_us", round(r["pair_launch_ms"]*1e3,1))'
 for i in 1 2; do
 $B --lanes 1 | python -c "$P" acc64_lanes1_$i
