@@ -247,8 +247,8 @@ def dry_run(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", default="params1024")
     ap.add_argument("--batch", type=int, default=0,
                     help="bootstraps per GPU per step (default 4096; 8192 on 8 GPUs = config 5)")
