@@ -436,7 +436,9 @@ __device__ __forceinline__ U96 crt_reduce(const uint32_t (&y)[NP], const CrtCons
 #pragma unroll
     for (int q = 0; q < NP; q++) {
         f += (float)y[q] * CC->invp[q];
+#ifndef SGFHE_ABL_CRT_NOSD  // (timing-only build without the double-precision sum: wrong results)
         Sd += (double)y[q] * CC->cd[q];
+#endif
     }
     const int alpha = (int)f;
     const uint4 tv = *reinterpret_cast<const uint4 *>(CC->T32[alpha]);
@@ -453,7 +455,9 @@ __device__ __forceinline__ U96 crt_reduce(const uint32_t (&y)[NP], const CrtCons
         a.w0 = (uint32_t)p0;
         a.w1 = (uint32_t)p1;
         a.w2 += h1 * b1 + (uint32_t)(p1 >> 32);
+#ifndef SGFHE_ABL_CRT_NOSD
         Sd += (double)d.y * CC->Bd + (double)d.x;
+#endif
     }
     // subtract q1 Q, q1 = floor(S / Q) +- 1
     {
@@ -506,6 +510,15 @@ k_crt_acc(const uint32_t *__restrict__ yres, uint64_t *__restrict__ dig,
     for (int q = 0; q < NP; q++) y[q] = ld_off<uint32_t>(yres, yo + ((uint32_t)(4 * q) << logm));
     const bool have_old = !(mode & MODE_NOACC);
     const ulonglong2 d = have_old ? load_digits(dig, bc, i, M) : make_ulonglong2(0, 0);
+#ifdef SGFHE_ABL_CRT_MEMONLY  // timing-only build: every load and store, no arithmetic (wrong results)
+    {
+        uint32_t acc = 0;
+#pragma unroll
+        for (int q = 0; q < NP; q++) acc ^= y[q];
+        store_digits(dig, bc, i, M, d.x ^ acc, d.y + acc);
+        return;
+    }
+#endif
     const U96 a = crt_reduce(y, CC, have_old, d);
     const uint64_t xlo = ((uint64_t)a.w1 << 32) | a.w0;
     if (mode & MODE_CANON) {  // canonical residues, interleaved {lo, hi} words
