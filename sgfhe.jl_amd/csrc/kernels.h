@@ -242,7 +242,7 @@ k_extprod(const uint64_t *__restrict__ dig, const int32_t *__restrict__ keyk,
 #ifdef SGFHE_ACC0_32
     int32_t acc0[E];  // column 0 summed like column 1, Montgomery-reduced per phase (< 2.9 * 2^29)
 #else
-    int64_t acc0[E];  // 64-bit NTT-domain sum of column 0 over the four phases (|.| < 2^61)
+    int64_t acc0[E];  // 64-bit NTT-domain sum of column 0 over the four phases (|.| < 1.85 * 2^60)
 #endif
 #pragma unroll
     for (int e = 0; e < E; e++) { acc0[e] = 0; z1[e * T] = 0; }
@@ -309,13 +309,13 @@ k_extprod(const uint64_t *__restrict__ dig, const int32_t *__restrict__ keyk,
             load_key();
         }
 
-        // 3. pointwise: z_c += U * K[ph][c]   (fhe.jl:527-528 in the NTT domain), |U| < 3.5 * 2^29,
+        // 3. pointwise: z_c += U * K[ph][c]   (fhe.jl:527-528 in the NTT domain), |U| < 3.7 * 2^29,
         //    |K| <= p / 2
         //    column 0: 64-bit multiply-accumulate (one v_mad_i64_i32 per product), reduced once after
         //              the loop.  (SGFHE_ACC0_32: Montgomery-reduced per phase into 16 registers
         //              instead of 32 -- 104 VGPRs and no spills, but 2 more multiplies per product:
         //              measured 230.8 against 225.1 us per launch, profiles/r02_acc32_* vs r02_v1_*.)
-        //    column 1: Montgomery-reduced (|.| < 0.72 * 2^29) and added to the LDS accumulator
+        //    column 1: Montgomery-reduced (|.| < 0.74 * 2^29) and added to the LDS accumulator
 #pragma unroll
         for (int h = 0; h < E / 4; h++) {
             const int4 a = ka4[h], bq = kb4[h];
@@ -344,9 +344,9 @@ k_extprod(const uint64_t *__restrict__ dig, const int32_t *__restrict__ keyk,
 #ifdef SGFHE_ACC0_32
         z[0][e] = sred(acc0[e], md);
 #else
-        z[0][e] = sred(sredc(acc0[e], md), md);  // |REDC| < 1.4 * 2^29
+        z[0][e] = sred(sredc(acc0[e], md), md);  // |REDC| < 1.43 * 2^29
 #endif
-        z[1][e] = sred(z1[e * T], md);           // four phases: < 2.9 * 2^29
+        z[1][e] = sred(z1[e * T], md);           // four phases: < 2.95 * 2^29
     }
     SGFHE_SYNC();  // every thread has taken its z_1 out of the buffer the exchanges now reuse
     ntt_inverse<LOGM, 2, LE>(z, lds, P.twi, tid, md);  // |z| < 1.4 * 2^29
@@ -546,7 +546,7 @@ k_crt_acc(const uint32_t *__restrict__ yres, uint64_t *__restrict__ dig,
 // (bootstrap, prime) walks through 4 forward and 2 inverse transforms.  Here the same work is cut
 // into 4 + 2 independent workgroups per (bootstrap, prime), three launches per iteration:
 //   k_fwd_phase   (bootstrap, prime, key row ph)  digit plane -> forward NTT -> products with the
-//                 two key polynomials of that row, |.| < 0.72 * 2^29        -> zpart
+//                 two key polynomials of that row, |.| < 0.74 * 2^29        -> zpart
 //   k_inv_column  (bootstrap, prime, column c)    sum of the four partial products -> inverse NTT
 //                 -> (x^j - 1) rotation -> residues                         -> yres
 //   k_crt_acc     as before.
@@ -589,7 +589,7 @@ k_fwd_phase(const uint64_t *__restrict__ dig, const int32_t *__restrict__ keyk,
 #pragma unroll
         for (int t = 0; t < 4; t++) {
             const int32_t u = x[0][4 * h + t];
-            r0[t] = smont(u, ka[t], md);  // |.| < 0.72 * 2^29
+            r0[t] = smont(u, ka[t], md);  // |.| < 0.74 * 2^29
             r1[t] = smont(u, kb[t], md);
         }
         reinterpret_cast<int4 *>(zp)[h] = make_int4(r0[0], r0[1], r0[2], r0[3]);
@@ -620,7 +620,7 @@ k_inv_column(const int32_t *__restrict__ zpart, uint32_t *__restrict__ yres,
 #pragma unroll
         for (int ph = 0; ph < 4; ph++) {
             const int4 v = reinterpret_cast<const int4 *>(zp + (size_t)ph * 2 * M)[h];
-            acc[0] += v.x; acc[1] += v.y; acc[2] += v.z; acc[3] += v.w;  // < 2.9 * 2^29
+            acc[0] += v.x; acc[1] += v.y; acc[2] += v.z; acc[3] += v.w;  // < 2.95 * 2^29
         }
 #pragma unroll
         for (int t = 0; t < 4; t++) z[0][4 * h + t] = sred(acc[t], md);
@@ -1092,7 +1092,7 @@ k_polymul_s(const ulonglong2 *__restrict__ acan, const int32_t *__restrict__ sha
     }
     ntt_forward<LOGM, 1, LOGE>(x, lds, P.twf, tid, md);
 #pragma unroll
-    for (int e = 0; e < E; e++)  // |x| < 3.5 * 2^29, |shat| <= p / 2: |product R^-1| < 0.72 * 2^29
+    for (int e = 0; e < E; e++)  // |x| < 3.7 * 2^29, |shat| <= p / 2: |product R^-1| < 0.74 * 2^29
         x[0][e] = smont(x[0][e], shat[(size_t)pi * M + E * tid + e], md);
     __syncthreads();
     ntt_inverse<LOGM, 1, LOGE>(x, lds, P.twi, tid, md);
@@ -1162,7 +1162,7 @@ k_key_transform(const ulonglong2 *__restrict__ canon, int32_t *__restrict__ keyh
     for (int h = 0; h < E / 4; h++) {
         int32_t o[4];
 #pragma unroll
-        for (int t = 0; t < 4; t++) o[t] = scentre(sred(x[0][4 * h + t], md), md);  // [-(p-1)/2, (p-1)/2]
+        for (int t = 0; t < 4; t++) o[t] = scentre(sred(sred_floor(x[0][4 * h + t], md), md), md);  // [-(p-1)/2, (p-1)/2]
         reinterpret_cast<int4 *>(dst)[h] = make_int4(o[0], o[1], o[2], o[3]);
     }
 }
@@ -1219,7 +1219,7 @@ k_debug_ntt(const uint32_t *__restrict__ in, uint32_t *__restrict__ out, PrimeSe
         for (int e = 0; e < E; e++) x[0][e] = (int32_t)in[tid + T * e];  // [0, p)
         ntt_forward<LOGM, 1, LOGE>(x, lds, P.twf, tid, md);
 #pragma unroll
-        for (int e = 0; e < E; e++) out[E * tid + e] = sfull(x[0][e], md);
+        for (int e = 0; e < E; e++) out[E * tid + e] = sfull(sred_floor(x[0][e], md), md);
     } else {
 #pragma unroll
         for (int e = 0; e < E; e++) x[0][e] = sred((int32_t)in[E * tid + e], md);

@@ -153,13 +153,14 @@ __device__ __forceinline__ void fwd_stages(int32_t (&x)[NP][1 << LOGE],
     if constexpr (BHI > BLO) fwd_stages<NP, LOGE, BHI - 1, BLO>(x, t, md);
 }
 // The X inputs of the first stage of a full pass (register index bit LOGE-1 clear) are pulled back
-// to about (-p/2, p/2); the stages of the pass then add at most 0.72 * 2^29 each.
+// to [0, 2^29] (`sred_floor`: any int32 in, three instructions); the stages of the pass then add at
+// most 0.73 * 2^29 each, so a transform hands out |x| < 3.7 * 2^29 (tests/rns_model.py RangeModel).
 template <int NP, int LOGE>
 __device__ __forceinline__ void fwd_reduce_x(int32_t (&x)[NP][1 << LOGE], const Mod &md) {
 #pragma unroll
     for (int q = 0; q < NP; q++)
 #pragma unroll
-        for (int e = 0; e < (1 << (LOGE - 1)); e++) x[q][e] = sred(x[q][e], md);
+        for (int e = 0; e < (1 << (LOGE - 1)); e++) x[q][e] = sred_floor(x[q][e], md);
 }
 // stages B = BLO, BLO+1, ..., BHI (inverse order).  The sums of a Gentleman-Sande stage double in
 // size, so they are range-reduced in every second stage of a pass (counted from its first stage
@@ -281,7 +282,7 @@ struct InvPasses {
 };
 
 // Forward transform.  In: x[q][e] = coefficient tid + T e of polynomial q, |x| <= 1.01 * 2^29.
-// Out: x[q][e] = slot E tid + e, |x| < 3.5 * 2^29.  `lds` must hold NP * m words.
+// Out: x[q][e] = slot E tid + e, |x| < 3.7 * 2^29.  `lds` must hold NP * m words.
 template <int LOGM, int NP, int LOGE, class F = NoHook>
 __device__ __forceinline__ void ntt_forward(int32_t (&x)[NP][1 << LOGE], uint32_t *lds,
                                             const int32_t *tw, int tid, const Mod &md,

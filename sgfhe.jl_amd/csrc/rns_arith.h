@@ -10,7 +10,8 @@
 // any conditional correction and without the +2p offsets an unsigned lazy form needs.  Products go
 // through a signed Montgomery reduction whose result is already centred (|t| < 0.75 p), and a
 // value is pulled back to about (-p/2, p/2) by `sred` only where the range analysis below calls
-// for it (once per radix-16 pass in the forward transform, every second stage in the inverse).
+// for it (once per radix-16 pass in the forward transform -- there in the cheaper floor form
+// `sred_floor`, to [0, p] -- and every second stage in the inverse).
 // Measured on MI355X (tools/ubench_bfly.hip, profiles/r02_ubench_bfly.txt): 0.75 x the time of the
 // unsigned 30-bit Harvey butterfly of round 1 in the forward pass, 0.78 x in the inverse.
 //
@@ -57,6 +58,12 @@ __device__ __forceinline__ int32_t sred(int32_t x, const Mod &md) {
     const int32_t q = (x + (1 << 28)) >> 29;
     return x - q * md.p;
 }
+
+// Floor form for ANY int32 x:  q = floor(x / 2^29) in [-4, 3],  r = x - q p = (x mod 2^29) + q delta
+// with delta = 2^29 - p:  r in [-4 delta, 2^29 + 3 delta).  One instruction less than `sred`
+// (shift, multiply, subtract) and no precondition; the price is a bound of 1.0 instead of 0.51.
+// Used where the next operations only add to the value (the forward transform).
+__device__ __forceinline__ int32_t sred_floor(int32_t x, const Mod &md) { return x - (x >> 29) * md.p; }
 
 // x in (-p, p) -> the canonical representative in [0, p).
 __device__ __forceinline__ uint32_t scanon(int32_t x, const Mod &md) {

@@ -173,6 +173,15 @@ def sred(x, P):
     return i32(x - q * np.int64(P["p"]))
 
 
+def sred_floor(x, P):
+    """rns_arith.h sred_floor: x - floor(x / 2^29) p for any int32 x; result in [-4 delta, 2^29 + 3 delta)."""
+    x = i32(x)
+    r = i32(x - (x >> 29) * np.int64(P["p"]))
+    d = (1 << 29) - P["p"]
+    assert int(r.min()) >= -4 * d and int(r.max()) < (1 << 29) + 3 * d
+    return r
+
+
 def scanon(x, P):
     x = i32(x)
     assert int(np.max(np.abs(x))) < P["p"]
@@ -268,7 +277,7 @@ class NttModel:
         while S >= 0:
             self.store(x, lds, sprev)
             x = self.load(lds, S)
-            x[:, :self.E // 2] = sred(x[:, :self.E // 2], P)         # fwd_reduce_x
+            x[:, :self.E // 2] = sred_floor(x[:, :self.E // 2], P)   # fwd_reduce_x
             for B in range(self.LOGE - 1, -1, -1):
                 self.stage(x, tw, P, B, S, True)
             sprev, S = S, S - self.LOGE
@@ -334,7 +343,8 @@ class RangeModel:
             b = self._chk(b + b / 16 + 0.5)
         passes = (N.SFIRST // N.LOGE + 1) if N.SFIRST >= 0 else 0
         for _ in range(passes):
-            x = self.sred(b)                                 # X inputs of the first stage
+            self._chk(b)                                     # sred_floor takes any int32
+            x = 1.0 + 3 * self.delta                         # X inputs of the first stage: [-4 delta, 1 + 3 delta)
             y = b                                            # Y inputs: any int32
             for _s in range(N.LOGE):
                 t = y / 16 + 0.5
@@ -420,7 +430,7 @@ class EngineModel:
         P = self.C.pk[pi]
         vals = smont(self.limbs_mod_p(canon_poly, P), P["kappaR"], P)
         x = self.ntt.forward(self.ntt.to_regs(vals), P["twf"], P)
-        return scentre(sred(x, P), P).reshape(-1)          # slot E tid + e, centred
+        return scentre(sred(sred_floor(x, P), P), P).reshape(-1)   # slot E tid + e, centred
 
     def extprod(self, dig_a, dig_b, keyslice, j, plain=False, random=False):
         """k_extprod for one bootstrap: dig_* lists of (lo, hi) stored digits; keyslice[pi][row*2+col]

@@ -34,7 +34,7 @@ def test_ntt_model(logm, loge):
     p = P["p"]
     poly = np.random.default_rng(logm).integers(0, p, size=m, dtype=np.uint64)
     x = N.forward(N.to_regs(poly), P["twf"], P)               # i32() inside checks the int32 range
-    assert int(np.abs(x).max()) < 3.5 * 2 ** 29
+    assert int(np.abs(x).max()) < 3.7 * 2 ** 29
     got = [int(v) % p for v in x.reshape(-1)]
     Rinv = pow(1 << 32, p - 2, p)
     plain = np.array([int(w) * Rinv % p for w in P["twf"]], dtype=np.uint64)
@@ -57,7 +57,7 @@ def test_worst_case_ranges(logm, loge):
     <= 0.75 * 2^29)."""
     for p in RM.rns_primes():
         R = RM.RangeModel(logm, loge, p)
-        assert R.forward(1.01) < 3.5         # pointwise products assume |U| < 3.5 * 2^29
+        assert R.forward(1.01) < 3.7         # pointwise products assume |U| < 3.7 * 2^29
         assert R.inverse(0.75) < 1.4         # the rotate-and-subtract epilogue assumes < 1.4 * 2^29
         assert R.peak < 3.99
 
@@ -75,7 +75,7 @@ def test_adversarial_ranges_on_data():
                         np.where(np.arange(m) & 1, big, -big),
                         np.where(np.arange(m) < m // 2, big, -big)):
             x = N.forward(N.to_regs(pattern.astype(np.int64)), P["twf"], P)
-            z = RM.sred(x, P)
+            z = RM.sred(RM.sred_floor(x, P), P)
             N.inverse(z, P["twi"], P)
             lim = int(0.75 * 2 ** 29)
             for pat2 in (np.full(m, lim), np.where(np.arange(m) & 1, lim, -lim)):
