@@ -130,7 +130,8 @@ __device__ __forceinline__ void fwd_stage(int32_t (&x)[NP][1 << LOGE],
                 bfly_fwd(x[q][e0], x[q][e0 | (1 << B)], t[NG - 1 + g], md);
             }
 }
-template <int NP, int LOGE, int B, bool RED>
+// REDMASK: bit e0 set = the sum X' of the butterfly whose X sits in register e0 is range-reduced
+template <int NP, int LOGE, int B, uint32_t REDMASK>
 __device__ __forceinline__ void inv_stage(int32_t (&x)[NP][1 << LOGE],
                                           const int32_t (&t)[(1 << LOGE) - 1], const Mod &md) {
     constexpr int NG = 1 << (LOGE - 1 - B);
@@ -141,7 +142,7 @@ __device__ __forceinline__ void inv_stage(int32_t (&x)[NP][1 << LOGE],
 #pragma unroll
             for (int l = 0; l < (1 << B); l++) {
                 const int e0 = (g << (B + 1)) | l;
-                bfly_inv<RED>(x[q][e0], x[q][e0 | (1 << B)], t[NG - 1 + g], md);
+                bfly_inv(x[q][e0], x[q][e0 | (1 << B)], t[NG - 1 + g], md, ((REDMASK >> e0) & 1u) != 0);
             }
 }
 
@@ -163,14 +164,38 @@ __device__ __forceinline__ void fwd_reduce_x(int32_t (&x)[NP][1 << LOGE], const 
         for (int e = 0; e < (1 << (LOGE - 1)); e++) x[q][e] = sred_floor(x[q][e], md);
 }
 // stages B = BLO, BLO+1, ..., BHI (inverse order).  The sums of a Gentleman-Sande stage double in
-// size, so they are range-reduced in every second stage of a pass (counted from its first stage
-// BFIRST) and, when LASTRED, in its last stage: a full pass then hands at most 0.67 * 2^29 to the
-// next one (see the range model in tests/rns_model.py).
-template <int NP, int LOGE, int BLO, int BHI, int BFIRST, bool LASTRED>
+// size while the twiddled differences come back below 0.75 * 2^29, so which sums need a range
+// reduction depends on the history of the register: bit k of its index says whether it left
+// stage k as a sum (0) or as a product (1).
+//  * a full radix-16 pass (LOGE = 4, stages 0..3, inputs <= 0.75 * 2^29) reduces 14 of its 32 sums --
+//    stage 1: the sums of sums (bit 0 clear); stage 2: the registers that were products in stage 0
+//    and skipped in stage 1 (bit 0 set, bit 1 clear); stage 3: all -- and hands at most
+//    0.68 * 2^29 to the next pass.  (Exhaustive search over the 2^15 reduction patterns:
+//    14 is the fewest that avoids int32 overflow, keeps every `sred` input below 3.5 * 2^29
+//    and returns to the input bound; tests/rns_model.py RangeModel re-derives the bounds.)
+//  * the same pass as the LAST step of a transform (LASTRED = 2: its outputs only have to stay
+//    below 1.4 * 2^29 for the epilogues) reduces 9: in stage 3 only registers 0, 2 and 3.
+//  * any other run of stages reduces every sum of every second stage (counted from its first
+//    stage BFIRST) and, when LASTRED, of its last stage.
+template <int LOGE, int B, int BLO, int BHI, int BFIRST, int LASTRED>
+constexpr uint32_t inv_red_mask() {
+    if (LOGE == 4 && BFIRST == 0 && BHI == 3 && LASTRED) {
+        uint32_t m = 0;
+        for (int e0 = 0; e0 < 16; e0++) {
+            if (e0 & (1 << B)) continue;  // not an X register of this stage
+            const bool red = B == 1 ? (e0 & 1) == 0
+                           : B == 2 ? (e0 & 3) == 1
+                           : B == 3 ? (LASTRED == 2 ? (e0 == 0 || e0 == 2 || e0 == 3) : true) : false;
+            if (red) m |= 1u << e0;
+        }
+        return m;
+    }
+    return ((((B - BFIRST) & 1) != 0) || (LASTRED && B == BHI)) ? 0xFFFFFFFFu : 0u;
+}
+template <int NP, int LOGE, int BLO, int BHI, int BFIRST, int LASTRED>
 __device__ __forceinline__ void inv_stages(int32_t (&x)[NP][1 << LOGE],
                                            const int32_t (&t)[(1 << LOGE) - 1], const Mod &md) {
-    constexpr bool RED = (((BLO - BFIRST) & 1) != 0) || (LASTRED && BLO == BHI);
-    inv_stage<NP, LOGE, BLO, RED>(x, t, md);
+    inv_stage<NP, LOGE, BLO, inv_red_mask<LOGE, BLO, BLO, BHI, BFIRST, LASTRED>()>(x, t, md);
     if constexpr (BLO < BHI) inv_stages<NP, LOGE, BLO + 1, BHI, BFIRST, LASTRED>(x, t, md);
 }
 
@@ -263,12 +288,13 @@ struct FwdPasses {
 };
 // inverse passes S = SCUR, SCUR + LOGE, ..., SLAST; data arrives in registers in layout SCUR and
 // the twiddles of pass SCUR in t
-template <int LOGM, int NP, int LOGE, int SCUR, int SLAST>
+// FINAL: the pass S = SLAST is the last step of the transform (no partial pass follows)
+template <int LOGM, int NP, int LOGE, int SCUR, int SLAST, bool FINAL = false>
 struct InvPasses {
     static __device__ __forceinline__ void run(int32_t (&x)[NP][1 << LOGE], uint32_t *lds,
                                                const int32_t *tw, int tid, const Mod &md,
                                                const int32_t (&t)[(1 << LOGE) - 1]) {
-        inv_stages<NP, LOGE, 0, LOGE - 1, 0, true>(x, t, md);
+        inv_stages<NP, LOGE, 0, LOGE - 1, 0, (FINAL && SCUR == SLAST) ? 2 : 1>(x, t, md);
         if constexpr (SCUR < SLAST) {
             int32_t tn[(1 << LOGE) - 1];
             load_twiddles<LOGM, LOGE, SCUR + LOGE, LOGE - 1, 0>(tn, tw,
@@ -276,7 +302,7 @@ struct InvPasses {
             lds_store<LOGM, NP, LOGE, SCUR>(x, lds, tid);
             exchange_sync<LOGE, SCUR>();
             lds_load<LOGM, NP, LOGE, SCUR + LOGE>(x, lds, tid);
-            InvPasses<LOGM, NP, LOGE, SCUR + LOGE, SLAST>::run(x, lds, tw, tid, md, tn);
+            InvPasses<LOGM, NP, LOGE, SCUR + LOGE, SLAST, FINAL>::run(x, lds, tw, tid, md, tn);
         }
     }
 };
@@ -308,7 +334,7 @@ __device__ __forceinline__ void ntt_inverse(int32_t (&x)[NP][1 << LOGE], uint32_
     if constexpr (G::RHO == 0) {
         int32_t t[(1 << LOGE) - 1];
         load_twiddles<LOGM, LOGE, 0, LOGE - 1, 0>(t, tw, (uint32_t)tid);
-        InvPasses<LOGM, NP, LOGE, 0, G::STOP>::run(x, lds, tw, tid, md, t);
+        InvPasses<LOGM, NP, LOGE, 0, G::STOP, true>::run(x, lds, tw, tid, md, t);
     } else {
         int32_t tp[(1 << LOGE) - 1];
         if constexpr (G::SLAST_INV >= 0) {
@@ -322,7 +348,7 @@ __device__ __forceinline__ void ntt_inverse(int32_t (&x)[NP][1 << LOGE], uint32_
         } else {
             load_twiddles<LOGM, LOGE, G::STOP, LOGE - 1, LOGE - G::RHO>(tp, tw, 0u);
         }
-        inv_stages<NP, LOGE, LOGE - G::RHO, LOGE - 1, LOGE - G::RHO, false>(x, tp, md);
+        inv_stages<NP, LOGE, LOGE - G::RHO, LOGE - 1, LOGE - G::RHO, 0>(x, tp, md);
     }
 }
 

@@ -98,11 +98,11 @@ __device__ __forceinline__ void bfly_fwd(int32_t &X, int32_t &Y, int32_t wM, con
 
 // Inverse (Gentleman-Sande) butterfly: X' = X + Y (range-reduced when RED), Y' = w (X - Y).
 // Needs |X| + |Y| < 2^31 (and < 3.5 * 2^29 when RED).
-template <bool RED>
-__device__ __forceinline__ void bfly_inv(int32_t &X, int32_t &Y, int32_t wM, const Mod &md) {
+// (red is a compile-time constant at every call site)
+__device__ __forceinline__ void bfly_inv(int32_t &X, int32_t &Y, int32_t wM, const Mod &md, bool red) {
     const int32_t s = X + Y;
     const int32_t d = X - Y;
-    X = RED ? sred(s, md) : s;
+    X = red ? sred(s, md) : s;
     Y = smont(d, wM, md);
 }
 

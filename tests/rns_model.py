@@ -223,6 +223,23 @@ def swz(idx, loge=LOGE):
             ^ (((idx >> 8) & 1) * 0x18))
 
 
+def inv_red_mask(loge, B, bfirst, bhi, lastred):
+    """ntt.h inv_red_mask: the set of X registers e0 whose sum is range-reduced in inverse stage B."""
+    E = 1 << loge
+    if loge == 4 and bfirst == 0 and bhi == 3 and lastred:
+        out = set()
+        for e0 in range(E):
+            if e0 & (1 << B):
+                continue
+            red = ((e0 & 1) == 0) if B == 1 else ((e0 & 3) == 1) if B == 2 else \
+                ((e0 in (0, 2, 3)) if lastred == 2 else True) if B == 3 else False
+            if red:
+                out.add(e0)
+        return out
+    allred = bool((B - bfirst) & 1) or (lastred and B == bhi)
+    return {e0 for e0 in range(E) if not e0 & (1 << B)} if allred else set()
+
+
 class NttModel:
     """x has shape [T, E] (one polynomial); lds is a flat array of M words."""
 
@@ -252,7 +269,7 @@ class NttModel:
             x[:, e] = lds[self.lds_addr(S, e)]
         return x
 
-    def stage(self, x, tw, P, B, S, fwd, red=False):
+    def stage(self, x, tw, P, B, S, fwd, red=()):
         """butterflies on local bit B of the pass over [S, S + LOGE)."""
         hi = self.tid >> S
         base = (1 << (self.LOGM - 1 - S - B)) + (hi << (self.LOGE - 1 - B))
@@ -264,7 +281,7 @@ class NttModel:
                 if fwd:
                     x[:, e0], x[:, e1] = bfly_fwd(x[:, e0], x[:, e1], w, P)
                 else:
-                    x[:, e0], x[:, e1] = bfly_inv(x[:, e0], x[:, e1], w, P, red)
+                    x[:, e0], x[:, e1] = bfly_inv(x[:, e0], x[:, e1], w, P, e0 in red)
 
     def forward(self, x, tw, P):
         """x[tid, e] = coefficient tid + T e -> slot E tid + e."""
@@ -285,8 +302,7 @@ class NttModel:
 
     def inv_stages(self, x, tw, P, S, blo, bhi, lastred):
         for B in range(blo, bhi + 1):
-            red = bool((B - blo) & 1) or (lastred and B == bhi)
-            self.stage(x, tw, P, B, S, False, red)
+            self.stage(x, tw, P, B, S, False, inv_red_mask(self.LOGE, B, blo, bhi, lastred))
 
     def inverse(self, x, tw, P):
         """slots E tid + e -> coefficient tid + T e (unscaled)."""
@@ -295,7 +311,8 @@ class NttModel:
         if self.SLAST_INV >= 0:
             S = 0
             while True:
-                self.inv_stages(x, tw, P, S, 0, self.LOGE - 1, True)
+                final = (not self.RHO) and S >= self.SLAST_INV     # InvPasses<..., FINAL>
+                self.inv_stages(x, tw, P, S, 0, self.LOGE - 1, 2 if final else 1)
                 if S >= self.SLAST_INV:
                     break
                 self.store(x, lds, S)
@@ -305,7 +322,7 @@ class NttModel:
             if self.SLAST_INV >= 0:
                 self.store(x, lds, self.SLAST_INV)
                 x = self.load(lds, self.STOP)
-            self.inv_stages(x, tw, P, self.STOP, self.LOGE - self.RHO, self.LOGE - 1, False)
+            self.inv_stages(x, tw, P, self.STOP, self.LOGE - self.RHO, self.LOGE - 1, 0)
         return x
 
     def to_regs(self, poly):
@@ -359,12 +376,13 @@ class RangeModel:
 
         def run(bv, blo, bhi, lastred):
             for B in range(blo, bhi + 1):
-                red = bool((B - blo) & 1) or (lastred and B == bhi)
+                mask = inv_red_mask(N.LOGE, B, blo, bhi, lastred)
                 nb = list(bv)
                 for e0 in range(E):
                     if e0 & (1 << B):
                         continue
                     e1 = e0 | (1 << B)
+                    red = e0 in mask
                     s = self._chk(bv[e0] + bv[e1], 3.5 if red else 4.0)
                     nb[e0] = (0.5 + 4 * self.delta) if red else s
                     nb[e1] = s / 16 + 0.5
@@ -373,8 +391,9 @@ class RangeModel:
 
         bv = [b_in] * E
         full = (N.SLAST_INV // N.LOGE + 1) if N.SLAST_INV >= 0 else 0
-        for _ in range(full):
-            bv = [max(run(bv, 0, N.LOGE - 1, True))] * E
+        for i in range(full):
+            final = (not N.RHO) and i == full - 1
+            bv = [max(run(bv, 0, N.LOGE - 1, 2 if final else 1))] * E
         if N.RHO:
             bv = run(bv, N.LOGE - N.RHO, N.LOGE - 1, False)
         return max(bv)
