@@ -339,17 +339,26 @@ k_extprod(const uint64_t *__restrict__ dig, const int32_t *__restrict__ keyk,
     //    exchange buffer is the LDS area that held z_1):
     //    P_c = (M/p)^-1 * sum_row u_row (*) C_row[c]  mod p
     int32_t z[2][E];
+    // With 16 points per thread the first inverse pass takes column 0 as the Montgomery step
+    // leaves it (|.| < 1.43 * 2^29) and reduces six more of its sums instead (ntt.h inv_red_mask).
+#ifdef SGFHE_ACC0_32
+    constexpr bool WIDE0 = false;
+#else
+    constexpr bool WIDE0 = LE == 4 && NttGeom<LOGM, LE>::SLAST_INV >= 0 &&
+                           !(NttGeom<LOGM, LE>::RHO == 0 && NttGeom<LOGM, LE>::STOP == 0);
+#endif
 #pragma unroll
     for (int e = 0; e < E; e++) {
 #ifdef SGFHE_ACC0_32
         z[0][e] = sred(acc0[e], md);
 #else
-        z[0][e] = sred(sredc(acc0[e], md), md);  // |REDC| < 1.43 * 2^29
+        const int32_t r0 = sredc(acc0[e], md);   // |REDC| < 1.43 * 2^29
+        z[0][e] = WIDE0 ? r0 : sred(r0, md);
 #endif
         z[1][e] = sred(z1[e * T], md);           // four phases: < 2.95 * 2^29
     }
     SGFHE_SYNC();  // every thread has taken its z_1 out of the buffer the exchanges now reuse
-    ntt_inverse<LOGM, 2, LE>(z, lds, P.twi, tid, md);  // |z| < 1.4 * 2^29
+    ntt_inverse<LOGM, 2, LE, WIDE0>(z, lds, P.twi, tid, md);  // |z| < 1.4 * 2^29
 
     // Output addressing as for the digit loads: two wave-uniform bases (one per column), the
     // coefficient stride a compile-time constant, one 32-bit lane offset.

@@ -131,7 +131,8 @@ __device__ __forceinline__ void fwd_stage(int32_t (&x)[NP][1 << LOGE],
             }
 }
 // REDMASK: bit e0 set = the sum X' of the butterfly whose X sits in register e0 is range-reduced
-template <int NP, int LOGE, int B, uint32_t REDMASK>
+// (REDMASK0: the same for polynomial 0, which may arrive with a different bound)
+template <int NP, int LOGE, int B, uint32_t REDMASK, uint32_t REDMASK0>
 __device__ __forceinline__ void inv_stage(int32_t (&x)[NP][1 << LOGE],
                                           const int32_t (&t)[(1 << LOGE) - 1], const Mod &md) {
     constexpr int NG = 1 << (LOGE - 1 - B);
@@ -142,7 +143,8 @@ __device__ __forceinline__ void inv_stage(int32_t (&x)[NP][1 << LOGE],
 #pragma unroll
             for (int l = 0; l < (1 << B); l++) {
                 const int e0 = (g << (B + 1)) | l;
-                bfly_inv(x[q][e0], x[q][e0 | (1 << B)], t[NG - 1 + g], md, ((REDMASK >> e0) & 1u) != 0);
+                bfly_inv(x[q][e0], x[q][e0 | (1 << B)], t[NG - 1 + g], md,
+                         (((q == 0 ? REDMASK0 : REDMASK) >> e0) & 1u) != 0);
             }
 }
 
@@ -175,6 +177,9 @@ __device__ __forceinline__ void fwd_reduce_x(int32_t (&x)[NP][1 << LOGE], const 
 //    and returns to the input bound; tests/rns_model.py RangeModel re-derives the bounds.)
 //  * the same pass as the LAST step of a transform (LASTRED = 2: its outputs only have to stay
 //    below 1.4 * 2^29 for the epilogues) reduces 9: in stage 3 only registers 0, 2 and 3.
+//  * the same pass as the FIRST step with inputs up to 1.45 * 2^29 (LASTRED = 3: k_extprod's
+//    column 0 straight out of its Montgomery reduction, without the input `sred`) reduces 20:
+//    stage 0 all, stage 1 none, stage 2 the registers with bit 1 clear, stage 3 all.
 //  * any other run of stages reduces every sum of every second stage (counted from its first
 //    stage BFIRST) and, when LASTRED, of its last stage.
 template <int LOGE, int B, int BLO, int BHI, int BFIRST, int LASTRED>
@@ -183,20 +188,25 @@ constexpr uint32_t inv_red_mask() {
         uint32_t m = 0;
         for (int e0 = 0; e0 < 16; e0++) {
             if (e0 & (1 << B)) continue;  // not an X register of this stage
-            const bool red = B == 1 ? (e0 & 1) == 0
-                           : B == 2 ? (e0 & 3) == 1
-                           : B == 3 ? (LASTRED == 2 ? (e0 == 0 || e0 == 2 || e0 == 3) : true) : false;
+            bool red = false;
+            if (LASTRED == 3)
+                red = B == 0 || B == 3 || (B == 2 && (e0 & 2) == 0);
+            else
+                red = B == 1 ? (e0 & 1) == 0
+                    : B == 2 ? (e0 & 3) == 1
+                    : B == 3 ? (LASTRED == 2 ? (e0 == 0 || e0 == 2 || e0 == 3) : true) : false;
             if (red) m |= 1u << e0;
         }
         return m;
     }
     return ((((B - BFIRST) & 1) != 0) || (LASTRED && B == BHI)) ? 0xFFFFFFFFu : 0u;
 }
-template <int NP, int LOGE, int BLO, int BHI, int BFIRST, int LASTRED>
+template <int NP, int LOGE, int BLO, int BHI, int BFIRST, int LASTRED, int LASTRED0 = LASTRED>
 __device__ __forceinline__ void inv_stages(int32_t (&x)[NP][1 << LOGE],
                                            const int32_t (&t)[(1 << LOGE) - 1], const Mod &md) {
-    inv_stage<NP, LOGE, BLO, inv_red_mask<LOGE, BLO, BLO, BHI, BFIRST, LASTRED>()>(x, t, md);
-    if constexpr (BLO < BHI) inv_stages<NP, LOGE, BLO + 1, BHI, BFIRST, LASTRED>(x, t, md);
+    inv_stage<NP, LOGE, BLO, inv_red_mask<LOGE, BLO, BLO, BHI, BFIRST, LASTRED>(),
+              inv_red_mask<LOGE, BLO, BLO, BHI, BFIRST, LASTRED0>()>(x, t, md);
+    if constexpr (BLO < BHI) inv_stages<NP, LOGE, BLO + 1, BHI, BFIRST, LASTRED, LASTRED0>(x, t, md);
 }
 
 // ---- LDS exchange ------------------------------------------------------------------------
@@ -288,13 +298,16 @@ struct FwdPasses {
 };
 // inverse passes S = SCUR, SCUR + LOGE, ..., SLAST; data arrives in registers in layout SCUR and
 // the twiddles of pass SCUR in t
-// FINAL: the pass S = SLAST is the last step of the transform (no partial pass follows)
-template <int LOGM, int NP, int LOGE, int SCUR, int SLAST, bool FINAL = false>
+// FINAL: the pass S = SLAST is the last step of the transform (no partial pass follows);
+// WIDE0: polynomial 0 enters the first pass with |x| <= 1.45 * 2^29 instead of 0.75 (LOGE = 4 only)
+template <int LOGM, int NP, int LOGE, int SCUR, int SLAST, bool FINAL = false, bool WIDE0 = false>
 struct InvPasses {
     static __device__ __forceinline__ void run(int32_t (&x)[NP][1 << LOGE], uint32_t *lds,
                                                const int32_t *tw, int tid, const Mod &md,
                                                const int32_t (&t)[(1 << LOGE) - 1]) {
-        inv_stages<NP, LOGE, 0, LOGE - 1, 0, (FINAL && SCUR == SLAST) ? 2 : 1>(x, t, md);
+        constexpr int MODE = (FINAL && SCUR == SLAST) ? 2 : 1;
+        static_assert(!WIDE0 || (LOGE == 4 && !(FINAL && SLAST == 0)), "wide first pass: radix 16, not the final pass");
+        inv_stages<NP, LOGE, 0, LOGE - 1, 0, MODE, (WIDE0 && SCUR == 0) ? 3 : MODE>(x, t, md);
         if constexpr (SCUR < SLAST) {
             int32_t tn[(1 << LOGE) - 1];
             load_twiddles<LOGM, LOGE, SCUR + LOGE, LOGE - 1, 0>(tn, tw,
@@ -302,7 +315,7 @@ struct InvPasses {
             lds_store<LOGM, NP, LOGE, SCUR>(x, lds, tid);
             exchange_sync<LOGE, SCUR>();
             lds_load<LOGM, NP, LOGE, SCUR + LOGE>(x, lds, tid);
-            InvPasses<LOGM, NP, LOGE, SCUR + LOGE, SLAST, FINAL>::run(x, lds, tw, tid, md, tn);
+            InvPasses<LOGM, NP, LOGE, SCUR + LOGE, SLAST, FINAL, WIDE0>::run(x, lds, tw, tid, md, tn);
         }
     }
 };
@@ -324,23 +337,24 @@ __device__ __forceinline__ void ntt_forward(int32_t (&x)[NP][1 << LOGE], uint32_
         before_last();
 }
 
-// Inverse transform (unscaled).  In: slots E tid + e, |x| <= 0.75 * 2^29.  Out: coefficient
+// Inverse transform (unscaled).  In: slots E tid + e, |x| <= 0.75 * 2^29 (WIDE0: polynomial 0 up
+// to 1.45 * 2^29; needs LOGE = 4 and at least one full pass).  Out: coefficient
 // tid + T e, |x| < 1.4 * 2^29, in registers; the last LDS accesses of every thread were loads in
 // layout STOP.
-template <int LOGM, int NP, int LOGE>
+template <int LOGM, int NP, int LOGE, bool WIDE0 = false>
 __device__ __forceinline__ void ntt_inverse(int32_t (&x)[NP][1 << LOGE], uint32_t *lds,
                                             const int32_t *tw, int tid, const Mod &md) {
     using G = NttGeom<LOGM, LOGE>;
     if constexpr (G::RHO == 0) {
         int32_t t[(1 << LOGE) - 1];
         load_twiddles<LOGM, LOGE, 0, LOGE - 1, 0>(t, tw, (uint32_t)tid);
-        InvPasses<LOGM, NP, LOGE, 0, G::STOP, true>::run(x, lds, tw, tid, md, t);
+        InvPasses<LOGM, NP, LOGE, 0, G::STOP, true, WIDE0>::run(x, lds, tw, tid, md, t);
     } else {
         int32_t tp[(1 << LOGE) - 1];
         if constexpr (G::SLAST_INV >= 0) {
             int32_t t[(1 << LOGE) - 1];
             load_twiddles<LOGM, LOGE, 0, LOGE - 1, 0>(t, tw, (uint32_t)tid);
-            InvPasses<LOGM, NP, LOGE, 0, G::SLAST_INV>::run(x, lds, tw, tid, md, t);
+            InvPasses<LOGM, NP, LOGE, 0, G::SLAST_INV, false, WIDE0>::run(x, lds, tw, tid, md, t);
             load_twiddles<LOGM, LOGE, G::STOP, LOGE - 1, LOGE - G::RHO>(tp, tw, 0u);
             lds_store<LOGM, NP, LOGE, G::SLAST_INV>(x, lds, tid);
             SGFHE_SYNC();

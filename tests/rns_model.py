@@ -231,8 +231,11 @@ def inv_red_mask(loge, B, bfirst, bhi, lastred):
         for e0 in range(E):
             if e0 & (1 << B):
                 continue
-            red = ((e0 & 1) == 0) if B == 1 else ((e0 & 3) == 1) if B == 2 else \
-                ((e0 in (0, 2, 3)) if lastred == 2 else True) if B == 3 else False
+            if lastred == 3:        # first pass, inputs up to 1.45 * 2^29
+                red = B == 0 or B == 3 or (B == 2 and (e0 & 2) == 0)
+            else:
+                red = ((e0 & 1) == 0) if B == 1 else ((e0 & 3) == 1) if B == 2 else \
+                    ((e0 in (0, 2, 3)) if lastred == 2 else True) if B == 3 else False
             if red:
                 out.add(e0)
         return out
@@ -304,15 +307,22 @@ class NttModel:
         for B in range(blo, bhi + 1):
             self.stage(x, tw, P, B, S, False, inv_red_mask(self.LOGE, B, blo, bhi, lastred))
 
-    def inverse(self, x, tw, P):
-        """slots E tid + e -> coefficient tid + T e (unscaled)."""
+    def wide_ok(self):
+        """k_extprod's WIDE0: column 0 may enter the inverse transform un-reduced (|.| < 1.45 * 2^29)."""
+        return self.LOGE == 4 and self.SLAST_INV >= 0 and not (self.RHO == 0 and self.STOP == 0)
+
+    def inverse(self, x, tw, P, wide=False):
+        """slots E tid + e -> coefficient tid + T e (unscaled).  wide: ntt_inverse<..., WIDE0> for
+        this polynomial."""
+        assert not wide or self.wide_ok()
         x = np.asarray(x, dtype=np.int64).copy()
         lds = np.zeros(self.M, dtype=np.int64)
         if self.SLAST_INV >= 0:
             S = 0
             while True:
                 final = (not self.RHO) and S >= self.SLAST_INV     # InvPasses<..., FINAL>
-                self.inv_stages(x, tw, P, S, 0, self.LOGE - 1, 2 if final else 1)
+                mode = 3 if (wide and S == 0) else (2 if final else 1)
+                self.inv_stages(x, tw, P, S, 0, self.LOGE - 1, mode)
                 if S >= self.SLAST_INV:
                     break
                 self.store(x, lds, S)
@@ -370,9 +380,10 @@ class RangeModel:
             b = x
         return b
 
-    def inverse(self, b_in):
+    def inverse(self, b_in, wide=False):
         N = self.N
         E = N.E
+        assert not wide or N.wide_ok()
 
         def run(bv, blo, bhi, lastred):
             for B in range(blo, bhi + 1):
@@ -393,7 +404,7 @@ class RangeModel:
         full = (N.SLAST_INV // N.LOGE + 1) if N.SLAST_INV >= 0 else 0
         for i in range(full):
             final = (not N.RHO) and i == full - 1
-            bv = [max(run(bv, 0, N.LOGE - 1, 2 if final else 1))] * E
+            bv = [max(run(bv, 0, N.LOGE - 1, 3 if (wide and i == 0) else (2 if final else 1)))] * E
         if N.RHO:
             bv = run(bv, N.LOGE - N.RHO, N.LOGE - 1, False)
         return max(bv)
@@ -475,7 +486,10 @@ class EngineModel:
                 if c == 0:
                     # column 0: 64-bit accumulation over the four phases, one reduction
                     acc = sum(U[row] * keyslice[pi][row * 2] for row in range(4))
-                    z = sred(sredc(acc, P), P)
+                    z = sredc(acc, P)
+                    assert int(np.max(np.abs(z))) < 1.45 * 2 ** 29
+                    if not self.ntt.wide_ok():
+                        z = sred(z, P)
                 else:
                     # column 1: Montgomery product per phase (|.| < 0.72 * 2^29), summed in the LDS
                     # accumulator over the four phases, one sred
@@ -483,7 +497,7 @@ class EngineModel:
                     for row in range(4):
                         z = i32(z + smont(U[row], keyslice[pi][row * 2 + 1], P))
                     z = sred(z, P)
-                z = self.ntt.inverse(z.reshape(T, self.ntt.E), P["twi"], P)
+                z = self.ntt.inverse(z.reshape(T, self.ntt.E), P["twi"], P, wide=(c == 0 and self.ntt.wide_ok()))
                 Pn = self.ntt.from_regs(z)                         # natural order, |.| < 1.4 * 2^29
                 if plain:
                     ys[c][pi] = (sfull(Pn, P) + P["hoff"]) % p

@@ -59,6 +59,8 @@ def test_worst_case_ranges(logm, loge):
         R = RM.RangeModel(logm, loge, p)
         assert R.forward(1.01) < 3.7         # pointwise products assume |U| < 3.7 * 2^29
         assert R.inverse(0.75) < 1.4         # the rotate-and-subtract epilogue assumes < 1.4 * 2^29
+        if R.N.wide_ok():                    # k_extprod's column 0: no input reduction, 16 points per thread
+            assert R.inverse(1.45, wide=True) < 1.4
         assert R.peak < 3.99
 
 
