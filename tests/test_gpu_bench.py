@@ -1,0 +1,52 @@
+"""The bench.py contract on the GPU box: one JSON line with the metric, the `roofline` and
+`cpu_baseline` objects and the host-I/O leg, from a small configuration (Params(64)) so that it
+finishes in seconds.  Run with `pytest -m gpu`."""
+
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(*extra):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "params64",
+                        "--batch", "256", "--steps", "2", "--warmup", "1", *extra],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "rank 0 prints exactly one JSON line"
+    return json.loads(lines[0])
+
+
+def test_bench_line_contract():
+    d = _run()
+    assert d["metric"] == "bootstraps/sec" and d["unit"] == "bootstraps/sec"
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1
+    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["dtype"] == "i32" and d["data"] == "synthetic"
+    assert d["value"] > 0 and abs(d["value"] - 256 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    assert "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert r["achieved"] > 0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert r["launch_samples"] > 0 and r["launch_ms"] > 0
+    # the committed counters are those of Params(1024): not quoted for another configuration
+    assert r["traffic"] is None and r["traffic_note"]
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1 and c["cores_available"] >= c["cores"]
+    assert c["opt"]["value"] > c["value"]            # 6 NTTs per iteration against 24
+    h = d["host_io"]
+    assert h["value"] > 0 and h["equals_device_resident_output"] is True
+
+
+def test_bench_flags():
+    d = _run("--no-cpu-baseline", "--no-host-io", "--flatten", "random")
+    assert "cpu_baseline" not in d and "host_io" not in d
+    assert "random flatten" in d["config"]["workload"] and d["value"] > 0
