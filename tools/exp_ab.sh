@@ -1,9 +1,12 @@
+# Same-box A/B of two builds of libsgfhe_hip.so at Params(1024), batch 4096 (3 steps each, twice):
+#   cp sgfhe.jl_amd/csrc/libsgfhe_hip.so tools/abl/lib_base.so     # before the change
+#   make -C sgfhe.jl_amd/csrc                                        # after the change
+#   gpurun -- 'bash tools/exp_ab.sh > gpurun_out/exp_ab.txt 2>&1'
+# (boxes differ by 2-3 %: only numbers from one call are comparable; tools/abl/ is git-ignored)
 B="python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-host-io"
 P='import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d["roofline"]; print("RESULT", sys.argv[1], round(d["value"],1), "ext_us", round(r["launch_ms"]*1e3,1), "crt_us", round(r["pair_launch_ms"]*1e3,1))'
 for i in 1 2; do
-SGFHE_HIP_LIB=$PWD/tools/abl/lib_v7.so $B | python -c "$P" v8_$i
-$B | python -c "$P" wide0_$i
+SGFHE_HIP_LIB=$PWD/tools/abl/lib_base.so $B | python -c "$P" base_$i
+$B | python -c "$P" new_$i
 done
-SGFHE_HIP_LIB=$PWD/tools/abl/lib_v7.so $B --config params512 | python -c "$P" p512_v8
-$B --config params512 | python -c "$P" p512_new
 python -m pytest tests -q -m gpu -x 2>&1 | tail -3
