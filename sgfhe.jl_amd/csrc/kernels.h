@@ -123,6 +123,32 @@ template <class T>
 __device__ __forceinline__ void st_off(void *base, uint32_t byte_off, T v) {
     *reinterpret_cast<T *>(reinterpret_cast<char *>(base) + byte_off) = v;
 }
+// Buffer-descriptor addressing (MI355X guide, T8 / T20): the 128-bit resource lives in SGPRs, a
+// load or store takes a 32-bit per-lane byte offset (VGPR), a wave-uniform byte offset (SGPR,
+// formed on the scalar ALU) and a 12-bit immediate -- no 64-bit address arithmetic on the vector
+// ALU, which is what bounds k_extprod.  Everything that builds a descriptor or an soffset must be
+// provably wave-uniform (kernel arguments, blockIdx, loop counters), or hipcc wraps the access in
+// a waterfall loop.  Accesses beyond `bytes` read 0 / are dropped by the hardware range check.
+typedef __amdgpu_buffer_rsrc_t BufRsrc;
+__device__ __forceinline__ BufRsrc make_rsrc(const void *base, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), (short)0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ uint32_t buf_ld_u32(BufRsrc r, uint32_t voff, uint32_t soff) {
+    return (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0);
+}
+__device__ __forceinline__ uint32_t buf_ld_u16(BufRsrc r, uint32_t voff, uint32_t soff) {
+    return (uint16_t)__builtin_amdgcn_raw_buffer_load_b16(r, (int)voff, (int)soff, 0);
+}
+__device__ __forceinline__ int4 buf_ld_i4(BufRsrc r, uint32_t voff, uint32_t soff) {
+    typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+    const v4u v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0);
+    return make_int4((int)v.x, (int)v.y, (int)v.z, (int)v.w);
+}
+// aux = 2: non-temporal (streamed out, as __builtin_nontemporal_store)
+__device__ __forceinline__ void buf_st_u32_nt(BufRsrc r, uint32_t voff, uint32_t soff, uint32_t v) {
+    __builtin_amdgcn_raw_buffer_store_b32(v, r, (int)voff, (int)soff, 2);
+}
+
 __device__ __forceinline__ const uint32_t *digit_lo_plane(const uint64_t *dig, size_t bc, uint32_t M) {
     return reinterpret_cast<const uint32_t *>(dig + bc * 2 * M);
 }
@@ -237,6 +263,12 @@ k_extprod(const uint64_t *__restrict__ dig, const int32_t *__restrict__ keyk,
     const uint32_t pi = slot % npr;
     const PrimeK P = PS[pi];
     const Mod md = mod_of(P);
+    // Buffer descriptors over this launch's digit planes, key slice and residues (all below 4 GiB:
+    // checked when the chunk size is set).  Built from kernel arguments and gridDim only.
+    const uint32_t cpad = gridDim.x / npr;  // bootstraps of the (padded) chunk
+    const BufRsrc rdig = make_rsrc(dig, cpad * 32u * (uint32_t)M);
+    const BufRsrc rkey = make_rsrc(keyk, npr * 32u * (uint32_t)M);
+    const BufRsrc ryres = make_rsrc(yres, cpad * npr * 8u * (uint32_t)M);
 
     const int32_t sRd = (mode & MODE_RANDOM) ? P.sRr : P.sR;  // digit offset of the flatten mode
 #ifdef SGFHE_ACC0_32
@@ -259,37 +291,38 @@ k_extprod(const uint64_t *__restrict__ dig, const int32_t *__restrict__ keyk,
         const int tid = (int)threadIdx.x + (int)opaque_zero();
         // 1. digits -> residues (flatten_poly, utils.jl:253-264, lifted to signed integers)
         int32_t x[1][E];
-        // Uniform base pointers + one 32-bit lane offset per plane, the per-coefficient strides as
-        // compile-time constants: hipcc shares a few 64-bit bases among the 32 loads and reaches
-        // the rest through the 13-bit immediate (70 fewer vector instructions per phase than with
-        // indexed pointers, and the last two spilled registers are gone).
-        const char *const dlo = reinterpret_cast<const char *>(dig) +
-                                ((size_t)(b * 2 + (uint32_t)(ph >> 1)) * 16u * M + (size_t)(ph & 1) * 4u * M);
-        const char *const dhi = reinterpret_cast<const char *>(dig) +
-                                ((size_t)(b * 2 + (uint32_t)(ph >> 1)) * 16u * M + 8u * (size_t)M + (size_t)(ph & 1) * 2u * M);
+        // Buffer loads: the lane supplies one 32-bit offset per plane (4 tid / 2 tid); record,
+        // plane and coefficient stride go into the scalar offset (SALU) -- no vector instruction
+        // is spent on addresses (the flat form cost 23 per phase).
+        const uint32_t srec = (b * 2u + (uint32_t)(ph >> 1)) * 16u * (uint32_t)M;  // byte offset of the record
+        const uint32_t slo = srec + (uint32_t)(ph & 1) * 4u * (uint32_t)M;
+        const uint32_t shi = srec + 8u * (uint32_t)M + (uint32_t)(ph & 1) * 2u * (uint32_t)M;
         const uint32_t vlo = 4u * (uint32_t)tid, vhi = 2u * (uint32_t)tid;
 #pragma unroll
         for (int e = 0; e < E; e++) {
 #ifdef SGFHE_ABL_NO_DIG
             x[0][e] = digit_reduce((uint64_t)(tid + e) * 0x9E3779B97F4Aull, md, sRd);  // timing-only build
 #else
-            const uint32_t lo = *reinterpret_cast<const uint32_t *>(dlo + (size_t)(4 * T * e) + vlo);
-            const uint32_t hi = *reinterpret_cast<const uint16_t *>(dhi + (size_t)(2 * T * e) + vhi);
+            const uint32_t lo = buf_ld_u32(rdig, vlo, slo + (uint32_t)(4 * T * e));
+            const uint32_t hi = buf_ld_u16(rdig, vhi, shi + (uint32_t)(2 * T * e));
             x[0][e] = digit_reduce(lo | ((uint64_t)hi << 32), md, sRd);
 #endif
         }
         // the exchange buffer is reused: every wave must have finished the previous phase's loads
         SGFHE_SYNC();
 
-        // 2. forward NTT of u[ph].  At m = 8192 the key slice rows of this phase are requested
-        //    before the last pass of the transform, so they have arrived (from L2) when the
-        //    products start; at smaller m the extra live registers cost more than the wait.
-#ifdef SGFHE_NO_KEY_EARLY
-        constexpr bool KEY_EARLY = false;
-#else
+        // 2. forward NTT of u[ph].  The key slice rows of this phase (from L2: every bootstrap of
+        //    the launch reads the same slice) are requested after the transform.  Requesting them
+        //    before its last pass (-DSGFHE_KEY_EARLY) keeps 32 more registers live through that
+        //    pass: at the 128-register budget hipcc then spills or shuffles the accumulators, and
+        //    the kernel is slower (profiles/r02_exp_buffer_addressing.txt).
+#ifdef SGFHE_KEY_EARLY
         constexpr bool KEY_EARLY = LOGM >= 13;
+#else
+        constexpr bool KEY_EARLY = false;
 #endif
-        const int32_t *kp = keyk + ((size_t)pi * 8 + ph * 2) * M + E * tid;
+        const uint32_t skey = (pi * 8u + (uint32_t)ph * 2u) * 4u * (uint32_t)M;  // byte offset of key row ph, column 0
+        const uint32_t vkey = 4u * (uint32_t)E * (uint32_t)tid;
         int4 ka4[E / 4], kb4[E / 4];
         auto load_key = [&]() {
 #pragma unroll
@@ -297,8 +330,8 @@ k_extprod(const uint64_t *__restrict__ dig, const int32_t *__restrict__ keyk,
 #ifdef SGFHE_ABL_NO_KEY
                 ka4[h] = make_int4(tid, h, ph, 7), kb4[h] = make_int4(h, tid, 5, ph);  // timing-only
 #else
-                ka4[h] = reinterpret_cast<const int4 *>(kp)[h];
-                kb4[h] = reinterpret_cast<const int4 *>(kp + M)[h];
+                ka4[h] = buf_ld_i4(rkey, vkey, skey + 16u * (uint32_t)h);
+                kb4[h] = buf_ld_i4(rkey, vkey, skey + 4u * (uint32_t)M + 16u * (uint32_t)h);
 #endif
             }
         };
@@ -316,6 +349,7 @@ k_extprod(const uint64_t *__restrict__ dig, const int32_t *__restrict__ keyk,
         //              instead of 32 -- 104 VGPRs and no spills, but 2 more multiplies per product:
         //              measured 230.8 against 225.1 us per launch, profiles/r02_acc32_* vs r02_v1_*.)
         //    column 1: Montgomery-reduced (|.| < 0.74 * 2^29) and added to the LDS accumulator
+        const Mod &mdp = md;
 #pragma unroll
         for (int h = 0; h < E / 4; h++) {
             const int4 a = ka4[h], bq = kb4[h];
@@ -326,12 +360,12 @@ k_extprod(const uint64_t *__restrict__ dig, const int32_t *__restrict__ keyk,
                 const int e = 4 * h + t;
                 const int32_t u = x[0][e];
 #ifdef SGFHE_ACC0_32
-                acc0[e] += smont(u, ka[t], md);
+                acc0[e] += smont(u, ka[t], mdp);
 #else
                 acc0[e] += (int64_t)u * ka[t];
 #endif
                 int32_t *zp = reinterpret_cast<int32_t *>(lds) + M + e * T + tid;
-                *zp += smont(u, kb[t], md);
+                *zp += smont(u, kb[t], mdp);
             }
         }
     }
@@ -360,10 +394,10 @@ k_extprod(const uint64_t *__restrict__ dig, const int32_t *__restrict__ keyk,
     SGFHE_SYNC();  // every thread has taken its z_1 out of the buffer the exchanges now reuse
     ntt_inverse<LOGM, 2, LE, WIDE0>(z, lds, P.twi, tid, md);  // |z| < 1.4 * 2^29
 
-    // Output addressing as for the digit loads: two wave-uniform bases (one per column), the
-    // coefficient stride a compile-time constant, one 32-bit lane offset.
-    char *const yb0 = reinterpret_cast<char *>(yres + ((size_t)b * 2 * npr + pi) * M);
-    char *const yb1 = yb0 + (size_t)npr * M * 4u;
+    // Output addressing as for the digit loads: scalar offsets per column and coefficient, one
+    // 32-bit lane offset.
+    const uint32_t sy0 = (b * 2u * npr + pi) * 4u * (uint32_t)M;
+    const uint32_t sy1 = sy0 + npr * 4u * (uint32_t)M;
     const uint32_t vout = 4u * (uint32_t)tid;
     // 5. y = x^j P - P  (mul_by_xj_minus_one, fhe.jl:554-556, applied to the product)
     if (mode & MODE_PLAIN) {
@@ -371,8 +405,8 @@ k_extprod(const uint64_t *__restrict__ dig, const int32_t *__restrict__ keyk,
         for (int c = 0; c < 2; c++)
 #pragma unroll
             for (int e = 0; e < E; e++)
-                *reinterpret_cast<uint32_t *>((c ? yb1 : yb0) + (size_t)(4 * T * e) + vout) =
-                    condsub(sfull(z[c][e], md) + P.hoff, (uint32_t)P.p);
+                buf_st_u32_nt(ryres, vout, (c ? sy1 : sy0) + (uint32_t)(4 * T * e),
+                              condsub(sfull(z[c][e], md) + P.hoff, (uint32_t)P.p));
         return;
     }
     const uint32_t j = ua[(size_t)b * n + k];
@@ -406,8 +440,7 @@ k_extprod(const uint64_t *__restrict__ dig, const int32_t *__restrict__ keyk,
                 const uint32_t y = (v ^ smask) + (yoe - (uint32_t)z[c][e]);
                 // streamed out: the residues are not read again by this launch, so they should
                 // not displace the digit planes the other prime-workgroups still want from L2
-                __builtin_nontemporal_store(
-                    y, reinterpret_cast<uint32_t *>((c ? yb1 : yb0) + (size_t)(4 * T * e) + vout));
+                buf_st_u32_nt(ryres, vout, (c ? sy1 : sy0) + (uint32_t)(4 * T * e), y);
             }
         }
     }

@@ -290,8 +290,13 @@ struct FwdPasses {
         lds_store<LOGM, NP, LOGE, SPREV>(x, lds, tid);
         exchange_sync<LOGE, SCUR>();
         lds_load<LOGM, NP, LOGE, SCUR>(x, lds, tid);
-        fwd_reduce_x<NP, LOGE>(x, md);
-        fwd_stages<NP, LOGE, LOGE - 1, 0>(x, t, md);
+        // -p re-enters every pass through an opaque scalar move: hipcc otherwise hoists its 64-bit
+        // sign extension out of the caller's loop, and instruction selection (per basic block) then
+        // no longer sees the 32 x 32 -> 64 multiply-add of `sredc` and emulates a 64 x 64 one.
+        Mod mdl = md;
+        mdl.negp += (int32_t)opaque_zero_s();
+        fwd_reduce_x<NP, LOGE>(x, mdl);
+        fwd_stages<NP, LOGE, LOGE - 1, 0>(x, t, mdl);
         if constexpr (SCUR >= LOGE)
             FwdPasses<LOGM, NP, LOGE, SCUR, SCUR - LOGE>::run(x, lds, tw, tid, md, before_last);
     }
