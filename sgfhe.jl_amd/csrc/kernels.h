@@ -303,8 +303,10 @@ k_extprod(const uint64_t *__restrict__ dig, const int32_t *__restrict__ keyk,
 #ifdef SGFHE_ABL_NO_DIG
             x[0][e] = digit_reduce((uint64_t)(tid + e) * 0x9E3779B97F4Aull, md, sRd);  // timing-only build
 #else
-            const uint32_t lo = buf_ld_u32(rdig, vlo, slo + (uint32_t)(4 * T * e));
-            const uint32_t hi = buf_ld_u16(rdig, vhi, shi + (uint32_t)(2 * T * e));
+            // (the part of the stride below 4096 goes into the instruction's immediate offset)
+            const uint32_t OL = (uint32_t)(4 * T * e), OH = (uint32_t)(2 * T * e);  // constants after unrolling
+            const uint32_t lo = buf_ld_u32(rdig, vlo + (OL & 4095u), slo + (OL & ~4095u));
+            const uint32_t hi = buf_ld_u16(rdig, vhi + (OH & 4095u), shi + (OH & ~4095u));
             x[0][e] = digit_reduce(lo | ((uint64_t)hi << 32), md, sRd);
 #endif
         }
@@ -330,8 +332,8 @@ k_extprod(const uint64_t *__restrict__ dig, const int32_t *__restrict__ keyk,
 #ifdef SGFHE_ABL_NO_KEY
                 ka4[h] = make_int4(tid, h, ph, 7), kb4[h] = make_int4(h, tid, 5, ph);  // timing-only
 #else
-                ka4[h] = buf_ld_i4(rkey, vkey, skey + 16u * (uint32_t)h);
-                kb4[h] = buf_ld_i4(rkey, vkey, skey + 4u * (uint32_t)M + 16u * (uint32_t)h);
+                ka4[h] = buf_ld_i4(rkey, vkey + 16u * (uint32_t)h, skey);
+                kb4[h] = buf_ld_i4(rkey, vkey + 16u * (uint32_t)h, skey + 4u * (uint32_t)M);
 #endif
             }
         };
@@ -405,7 +407,8 @@ k_extprod(const uint64_t *__restrict__ dig, const int32_t *__restrict__ keyk,
         for (int c = 0; c < 2; c++)
 #pragma unroll
             for (int e = 0; e < E; e++)
-                buf_st_u32_nt(ryres, vout, (c ? sy1 : sy0) + (uint32_t)(4 * T * e),
+                buf_st_u32_nt(ryres, vout + ((uint32_t)(4 * T * e) & 4095u),
+                              (c ? sy1 : sy0) + ((uint32_t)(4 * T * e) & ~4095u),
                               condsub(sfull(z[c][e], md) + P.hoff, (uint32_t)P.p));
         return;
     }
@@ -440,7 +443,8 @@ k_extprod(const uint64_t *__restrict__ dig, const int32_t *__restrict__ keyk,
                 const uint32_t y = (v ^ smask) + (yoe - (uint32_t)z[c][e]);
                 // streamed out: the residues are not read again by this launch, so they should
                 // not displace the digit planes the other prime-workgroups still want from L2
-                buf_st_u32_nt(ryres, vout, (c ? sy1 : sy0) + (uint32_t)(4 * T * e), y);
+                buf_st_u32_nt(ryres, vout + ((uint32_t)(4 * T * e) & 4095u),
+                              (c ? sy1 : sy0) + ((uint32_t)(4 * T * e) & ~4095u), y);
             }
         }
     }
