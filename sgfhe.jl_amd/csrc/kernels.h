@@ -268,7 +268,11 @@ k_extprod(const uint64_t *__restrict__ dig, const int32_t *__restrict__ keyk,
     const uint32_t cpad = gridDim.x / npr;  // bootstraps of the (padded) chunk
     const BufRsrc rdig = make_rsrc(dig, cpad * 32u * (uint32_t)M);
     const BufRsrc rkey = make_rsrc(keyk, npr * 32u * (uint32_t)M);
+#ifdef SGFHE_ABL_NO_YRES  // timing-only build: zero records, the range check drops every residue store
+    const BufRsrc ryres = make_rsrc(yres, 0u);
+#else
     const BufRsrc ryres = make_rsrc(yres, cpad * npr * 8u * (uint32_t)M);
+#endif
 
     const int32_t sRd = (mode & MODE_RANDOM) ? P.sRr : P.sR;  // digit offset of the flatten mode
 #ifdef SGFHE_ACC0_32
@@ -553,7 +557,11 @@ k_crt_acc(const uint32_t *__restrict__ yres, uint64_t *__restrict__ dig,
     const uint32_t yo = 4u * ((bc * NP << logm) + i);  // byte offset
     uint32_t y[NP];
 #pragma unroll
+#ifdef SGFHE_ABL_NO_YRES  // timing-only build: no residue loads (wrong results)
+    for (int q = 0; q < NP; q++) y[q] = (t * 2654435761u + (uint32_t)q * 40503u) >> 3;
+#else
     for (int q = 0; q < NP; q++) y[q] = ld_off<uint32_t>(yres, yo + ((uint32_t)(4 * q) << logm));
+#endif
     const bool have_old = !(mode & MODE_NOACC);
     const ulonglong2 d = have_old ? load_digits(dig, bc, i, M) : make_ulonglong2(0, 0);
 #ifdef SGFHE_ABL_CRT_MEMONLY  // timing-only build: every load and store, no arithmetic (wrong results)
