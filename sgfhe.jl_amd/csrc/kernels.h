@@ -144,9 +144,12 @@ __device__ __forceinline__ int4 buf_ld_i4(BufRsrc r, uint32_t voff, uint32_t sof
     const v4u v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0);
     return make_int4((int)v.x, (int)v.y, (int)v.z, (int)v.w);
 }
-// aux = 2: non-temporal (streamed out, as __builtin_nontemporal_store)
-__device__ __forceinline__ void buf_st_u32_nt(BufRsrc r, uint32_t voff, uint32_t soff, uint32_t v) {
-    __builtin_amdgcn_raw_buffer_store_b32(v, r, (int)voff, (int)soff, 2);
+// Plain (write-back) stores: the Infinity Cache keeps up to 256 MB of written data for the next
+// kernel's reads, and a non-temporal store (aux = 2) writes more slowly (tools/ubench_mall.hip:
+// 4.0 against 5.9 TB/s); in the pipeline plain stores are 1.6 % faster
+// (profiles/r02_exp_plain_vs_nt_stores.txt).
+__device__ __forceinline__ void buf_st_u32(BufRsrc r, uint32_t voff, uint32_t soff, uint32_t v) {
+    __builtin_amdgcn_raw_buffer_store_b32(v, r, (int)voff, (int)soff, 0);
 }
 
 __device__ __forceinline__ const uint32_t *digit_lo_plane(const uint64_t *dig, size_t bc, uint32_t M) {
@@ -411,7 +414,7 @@ k_extprod(const uint64_t *__restrict__ dig, const int32_t *__restrict__ keyk,
         for (int c = 0; c < 2; c++)
 #pragma unroll
             for (int e = 0; e < E; e++)
-                buf_st_u32_nt(ryres, vout + ((uint32_t)(4 * T * e) & 4095u),
+                buf_st_u32(ryres, vout + ((uint32_t)(4 * T * e) & 4095u),
                               (c ? sy1 : sy0) + ((uint32_t)(4 * T * e) & ~4095u),
                               condsub(sfull(z[c][e], md) + P.hoff, (uint32_t)P.p));
         return;
@@ -445,9 +448,7 @@ k_extprod(const uint64_t *__restrict__ dig, const int32_t *__restrict__ keyk,
                 // reduction at all: k_crt_acc takes any such residues); + (p - 1) / 2 for the last
                 // prime, folded into the same wave-uniform constant
                 const uint32_t y = (v ^ smask) + (yoe - (uint32_t)z[c][e]);
-                // streamed out: the residues are not read again by this launch, so they should
-                // not displace the digit planes the other prime-workgroups still want from L2
-                buf_st_u32_nt(ryres, vout + ((uint32_t)(4 * T * e) & 4095u),
+                buf_st_u32(ryres, vout + ((uint32_t)(4 * T * e) & 4095u),
                               (c ? sy1 : sy0) + ((uint32_t)(4 * T * e) & ~4095u), y);
             }
         }
