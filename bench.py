@@ -253,8 +253,7 @@ def main():
     ap.add_argument("--batch", type=int, default=0,
                     help="bootstraps per GPU per step (default 4096; 8192 on 8 GPUs = config 5)")
     ap.add_argument("--chunk", type=int, default=0, help="lock-step chunk (0 = engine default)")
-    ap.add_argument("--lanes", type=int, default=2,
-                    help="2 (engine default) = pairs of chunks on two streams, 1 = chunks in sequence")
+    ap.add_argument("--lanes", type=int, default=1, help="1 = chunks in sequence, 2 = two streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-io", action="store_true",
                     help="skip the extra step timed through host pointers (sgfhe_bootstrap_batch)")
@@ -398,10 +397,6 @@ def main():
                          "traffic": ctr["k_extprod"].get("traffic_bytes_per_launch") if ctr else None,
                          "traffic_note": None if ctr else why,
                          "launch_ms": tm["extprod_ms"], "launch_samples": tm["extprod_samples"],
-                         # with two lanes a k_extprod launch shares the device with the other
-                         # chunk's kernels: its duration (HIP events, as rocprofv3 sees it) is
-                         # that of half the machine, so `frac` halves while `whole_job_frac` rises
-                         "concurrent_lanes": args.lanes if B > chunk else 1,
                          "algorithmic_bytes_per_launch": launch_bytes,
                          "pair_kernel": "k_crt_acc", "pair_launch_ms": tm["crt_ms"],
                          "pair_achieved": pair, "pair_frac": pair / PEAK_HBM_GBS,

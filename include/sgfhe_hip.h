@@ -81,11 +81,10 @@ int32_t sgfhe_ctx_destroy(sgfhe_ctx *ctx);
 const char *sgfhe_last_error_string(const sgfhe_ctx *ctx);
 
 /* Batch-scheduling knobs.  chunk: bootstraps that move through the k-loop in lock-step
- * (0 = default; rounded up to a multiple of 8; a chunk's buffers must stay below 4 GiB).  lanes: 2 (default) runs
- * pairs of chunks on two HIP streams, each half the size a single lane would take (measured 2 %
- * faster at Params(1024): the memory-bound CRT kernel of one chunk runs beside the external
- * product of the other); 1 runs the chunks of a batch one after the other.  Every setting gives
- * bit-identical results, in both flatten modes. */
+ * (0 = default; rounded up to a multiple of 8; a chunk's buffers must stay below 4 GiB).  lanes: 1 (default) runs the
+ * chunks of a batch one after the other; 2 runs pairs of chunks on two HIP streams (measured
+ * within 2 % of one stream with twice the chunk).  Every setting gives bit-identical results, in
+ * both flatten modes. */
 int32_t sgfhe_set_chunk(sgfhe_ctx *ctx, uint32_t chunk);
 /* Chunks of at most this many bootstraps (default 24, 0 = never, at most 256) run the k-loop in
  * its small-batch form: 6 workgroups per (bootstrap, RNS prime) and three launches per iteration

@@ -90,7 +90,7 @@ struct sgfhe_ctx {
     size_t key_bytes = 0;
     bool have_key = false;
     // work buffers: two lanes, each sized for `cap` bootstraps
-    uint32_t chunk = 0, cap = 0, lanes = 2;
+    uint32_t chunk = 0, cap = 0, lanes = 1;
     // randomised flatten (rng != nothing, utils.jl:198-241)
     bool rnd = false, rnd_ok = false;
     uint64_t rnd_seed = 0;
@@ -322,19 +322,16 @@ size_t per_bootstrap_bytes(const sgfhe_ctx *c) {
     return (size_t)2 * c->M * sizeof(ulonglong2) + (size_t)2 * c->npr * c->M * 4 + (size_t)c->n * 4;
 }
 
-// Default chunk: the per-iteration working set (digits + residues) of the chunks in flight stays
-// near the size of the 256 MiB Infinity Cache (which keeps the plain-stored residues and digit
-// planes for the kernel that reads them next) while a launch is long enough to amortise its
-// ramp-up and drain.  Measured at Params(1024), bootstraps/s (profiles/r02_exp_lanes.txt): one lane
-// with chunks of 448 / 512 / 576 / 1024: 1846 / 1893 / 1796 / 1784; two lanes (the default: the
-// memory-bound k_crt_acc of one chunk runs beside the power-bound k_extprod of the other) with
-// chunks of 192 / 256 / 320: 1934 / 1943 / 1857.
+// Default chunk: the per-iteration working set (digits + residues) of a chunk stays near the size
+// of the 256 MiB Infinity Cache while a launch is long enough to amortise its ramp-up and drain
+// (about 9 us per k_extprod launch).  Measured at Params(1024) (tools/chunk_sweep.py, us of
+// k_extprod per bootstrap and iteration): chunk 256 0.568, 408 0.553, 512 0.547, 608 0.572,
+// 816 0.575.
 uint32_t default_chunk(const sgfhe_ctx *c) {
     size_t budget = (size_t)320 << 20;
     size_t k = budget / per_bootstrap_bytes(c);
     if (k >= 256) k = (k / 256) * 256;
     else k = (k / 8) * 8;
-    if (c->lanes == 2) k = (k / 2 + 7) / 8 * 8;  // the budget is shared by the two chunks in flight
     if (k < 8) k = 8;
     if (k > 4096) k = 4096;
     return (uint32_t)k;

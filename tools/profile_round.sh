@@ -2,17 +2,14 @@
 # Run on the GPU box (through gpurun): kernel-trace stats of the default bench, then separate PMC
 # passes (never combined with other trace domains) on a one-chunk batch.  Results land in
 # gpurun_out/prof_$TAG; tools/summarize_profile.py turns them into the files kept under profiles/.
-#   usage: tools/profile_round.sh TAG [BATCH] [CHUNK]
-# BATCH: the batch of the PMC passes = one pair of chunks on the two lanes (512 at Params(1024));
-# CHUNK: the bootstraps of one launch in that run (256), recorded with the counters.
+#   usage: tools/profile_round.sh TAG [CHUNK]
 set -e
 TAG=${1:-rXX}
-BATCH=${2:-512}
-CHUNK=${3:-256}
+CHUNK=${2:-512}   # one chunk of the engine default size at Params(1024)
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-ONE="--batch $BATCH --steps 1 --warmup 0 --no-cpu-baseline --no-host-io"
+ONE="--batch $CHUNK --steps 1 --warmup 0 --no-cpu-baseline --no-host-io"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o run -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-host-io > $OUT/bench_stats.log 2>&1
 echo "stats done"
 for C in FETCH_SIZE WRITE_SIZE; do

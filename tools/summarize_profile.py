@@ -45,7 +45,7 @@ def main():
         if lines:
             open(os.path.join(prof, "%s_bench_under_rocprof.json" % tag), "w").write(lines[-1])
     out = {"note": "rocprofv3 --pmc passes (one counter group per run, --kernel-trace only), "
-                   "bench.py --batch %d --steps 1 --warmup 0 = one pair of chunks of %d bootstraps on the two lanes, " % (2 * chunk, chunk) +
+                   "bench.py --batch %d --steps 1 --warmup 0 = one chunk of %d bootstraps, " % (chunk, chunk) +
                    "Params(1024); per-launch averages. FETCH_SIZE / WRITE_SIZE are reported in KB; "
                    "on gfx950 FETCH_SIZE counts half the bytes of wide coalesced reads "
                    "(MI355X_MICROARCH.md, HBM section): traffic = (2 FETCH_SIZE + WRITE_SIZE) * 1024 B.",
