@@ -398,7 +398,7 @@ def main():
                          "traffic_note": None if ctr else why,
                          "launch_ms": tm["extprod_ms"], "launch_samples": tm["extprod_samples"],
                          "algorithmic_bytes_per_launch": launch_bytes,
-                         "pair_kernel": "k_crt_acc", "pair_launch_ms": tm["crt_ms"],
+                         "pair_kernel": "k_crt_acc2", "pair_launch_ms": tm["crt_ms"],
                          "pair_achieved": pair, "pair_frac": pair / PEAK_HBM_GBS,
                          "whole_job_frac": per_boot * value / world / (PEAK_HBM_GBS * 1e9),
                          "valu": valu_roofline(ctr, ext_s)},

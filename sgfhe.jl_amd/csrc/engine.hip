@@ -299,8 +299,12 @@ int32_t launch_crt_raw(sgfhe_ctx *c, const uint32_t *yres, uint64_t *dig, uint32
     switch (c->npr) {
 #define X(NP)                                                                                     \
     case NP:                                                                                      \
-        hipLaunchKernelGGL(k_crt_acc<NP>, dim3((total + 255) / 256), dim3(256), 0, st, yres, dig, \
-                           c->d_crt, total, (uint32_t)c->logm, mode, ra, iter);                   \
+        if (mode == 0u) /* the k-loop's own case: two coefficients per thread */                 \
+            hipLaunchKernelGGL(k_crt_acc2<NP>, dim3((total / 2 + 255) / 256), dim3(256), 0, st,   \
+                               yres, dig, c->d_crt, total / 2, (uint32_t)c->logm);                \
+        else                                                                                      \
+            hipLaunchKernelGGL(k_crt_acc<NP>, dim3((total + 255) / 256), dim3(256), 0, st, yres,  \
+                               dig, c->d_crt, total, (uint32_t)c->logm, mode, ra, iter);          \
         break;
         SGFHE_FOR_NPR(X)
 #undef X

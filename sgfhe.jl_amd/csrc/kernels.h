@@ -596,6 +596,52 @@ k_crt_acc(const uint32_t *__restrict__ yres, uint64_t *__restrict__ dig,
     store_digits(dig, bc, i, M, (uint64_t)lo, hq);
 }
 
+// The k-loop's own case (deterministic flatten, previous accumulator present) with two adjacent
+// coefficients per thread: 8-byte residue and digit-word loads / stores and 4-byte loads / stores
+// of the 16-bit high words -- half the memory instructions for the same bytes.  Same arithmetic.
+template <int NP>
+__global__ void __launch_bounds__(256)
+k_crt_acc2(const uint32_t *__restrict__ yres, uint64_t *__restrict__ dig,
+           const CrtConst *__restrict__ CC, uint32_t pairs, uint32_t logm) {
+    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= pairs) return;
+    const uint32_t M = 1u << logm;
+    const uint32_t i = (2u * t) & (M - 1);  // even
+    const uint32_t bc = (2u * t) >> logm;
+    const uint32_t yo = 4u * ((bc * NP << logm) + i);
+    uint2 yv[NP];
+#pragma unroll
+    for (int q = 0; q < NP; q++) yv[q] = ld_off<uint2>(yres, yo + ((uint32_t)(4 * q) << logm));
+    const uint32_t rec = bc * 16u * M;
+    const uint32_t ol = rec + 4u * i, oh = rec + 8u * M + 2u * i;
+    const uint2 l0 = ld_off<uint2>(dig, ol), l1 = ld_off<uint2>(dig, ol + 4u * M);
+    const uint32_t h0 = ld_off<uint32_t>(dig, oh), h1 = ld_off<uint32_t>(dig, oh + 2u * M);
+    const uint64_t B = (uint64_t)CC->B;
+    uint32_t olo[2][2], ohi[2][2];  // [digit][coefficient]
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        uint32_t y[NP];
+#pragma unroll
+        for (int q = 0; q < NP; q++) y[q] = j ? yv[q].y : yv[q].x;
+        const uint32_t hw0 = j ? (h0 >> 16) : (h0 & 0xFFFFu), hw1 = j ? (h1 >> 16) : (h1 & 0xFFFFu);
+        const ulonglong2 d = make_ulonglong2((j ? l0.y : l0.x) | ((uint64_t)hw0 << 32),
+                                             (j ? l1.y : l1.x) | ((uint64_t)hw1 << 32));
+        const U96 a = crt_reduce(y, CC, true, d);
+        const uint64_t xlo = ((uint64_t)a.w1 << 32) | a.w0;
+        const double xd = (double)a.w2 * 18446744073709551616.0 + (double)xlo;
+        uint64_t hq = (uint64_t)(xd * CC->invB);
+        int64_t lo = (int64_t)(xlo - hq * B);
+        if (lo < 0) { lo += (int64_t)B; hq--; }
+        else if ((uint64_t)lo >= B) { lo -= (int64_t)B; hq++; }
+        olo[0][j] = (uint32_t)lo; ohi[0][j] = (uint32_t)((uint64_t)lo >> 32);
+        olo[1][j] = (uint32_t)hq; ohi[1][j] = (uint32_t)(hq >> 32);
+    }
+    st_off<uint2>(dig, ol, make_uint2(olo[0][0], olo[0][1]));
+    st_off<uint2>(dig, ol + 4u * M, make_uint2(olo[1][0], olo[1][1]));
+    st_off<uint32_t>(dig, oh, (ohi[0][0] & 0xFFFFu) | (ohi[0][1] << 16));
+    st_off<uint32_t>(dig, oh + 2u * M, (ohi[1][0] & 0xFFFFu) | (ohi[1][1] << 16));
+}
+
 // ---- small-batch ("latency") form of the external product --------------------------------------
 // A call with a handful of gates leaves most of the 256 CUs idle while one workgroup per
 // (bootstrap, prime) walks through 4 forward and 2 inverse transforms.  Here the same work is cut
