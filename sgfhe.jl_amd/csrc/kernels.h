@@ -144,12 +144,17 @@ __device__ __forceinline__ int4 buf_ld_i4(BufRsrc r, uint32_t voff, uint32_t sof
     const v4u v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0);
     return make_int4((int)v.x, (int)v.y, (int)v.z, (int)v.w);
 }
-// Plain (write-back) stores: the Infinity Cache keeps up to 256 MB of written data for the next
-// kernel's reads, and a non-temporal store (aux = 2) writes more slowly (tools/ubench_mall.hip:
-// 4.0 against 5.9 TB/s); in the pipeline plain stores are 1.6 % faster
-// (profiles/r02_exp_plain_vs_nt_stores.txt).
+// Cache policy of the residue stores (aux bits: 1 = sc0, 2 = nt, 16 = sc1), measured in the
+// pipeline (profiles/r02_exp_plain_vs_nt_stores_final.txt, r02_exp_store_policy.txt): non-temporal
+// 1863, plain 1893 (the Infinity Cache keeps up to 256 MB of written data for the next kernel's
+// reads, and a non-temporal store writes more slowly: tools/ubench_mall.hip, 4.0 against
+// 5.9 TB/s); on another box plain 1922, sc0 1924, sc1 1936, sc0 sc1 1935, sc0 nt 1903.  sc1
+// (write-through) it is.
+#ifndef SGFHE_YRES_AUX
+#define SGFHE_YRES_AUX 16
+#endif
 __device__ __forceinline__ void buf_st_u32(BufRsrc r, uint32_t voff, uint32_t soff, uint32_t v) {
-    __builtin_amdgcn_raw_buffer_store_b32(v, r, (int)voff, (int)soff, 0);
+    __builtin_amdgcn_raw_buffer_store_b32(v, r, (int)voff, (int)soff, SGFHE_YRES_AUX);
 }
 
 __device__ __forceinline__ const uint32_t *digit_lo_plane(const uint64_t *dig, size_t bc, uint32_t M) {
