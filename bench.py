@@ -92,36 +92,27 @@ def algorithmic_bytes_per_bootstrap(p, W, batch):
     return p.n * p.m * W * (4 + 8.0 / batch) + 40 * (p.n + 1)
 
 
-def source_hash():
-    """Hash of the kernel sources the loaded library was built from: profile counters are only
-    quoted when they were collected on the same code (tools/summarize_profile.py stamps them)."""
-    h = hashlib.sha256()
-    csrc = os.path.join(ROOT, "sgfhe.jl_amd", "csrc")
-    for f in sorted(os.listdir(csrc)):
-        if f.endswith((".h", ".hip")):
-            h.update(f.encode())
-            h.update(open(os.path.join(csrc, f), "rb").read())
-    return h.hexdigest()[:16]
-
-
-def _counters(config, chunk):
-    """Per-launch PMC averages of the newest committed profile (tools/profile_round.sh collects
-    them in separate profiler runs, not inside this process).  Returns (counters, reason)."""
+def _counters(config, chunk, build_id):
+    """Per-launch PMC averages and rocprofv3 kernel-trace durations of the newest committed
+    profile (tools/profile_round.sh collects them in separate profiler runs, not inside this
+    process).  They are quoted only when that profile was taken on a library with the same
+    sgfhe_build_id() as the one loaded here (hash of csrc/ plus any ablation flags).
+    Returns (counters, reason)."""
     if config != "params1024":
         return None, "counters are collected for the params1024 workload only"
-    want = source_hash()
     stale = None
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_counters.json")), reverse=True):
         with open(path) as f:
             d = json.load(f)
         if d.get("chunk", 256) != chunk:
             continue
-        if d.get("source_hash") != want:
+        if d.get("build_id", d.get("source_hash")) != build_id:
             stale = stale or os.path.basename(path)
             continue
-        return dict(d["kernels"], source=os.path.basename(path), valu_mix=d.get("valu_mix")), None
+        return dict(d["kernels"], source=os.path.basename(path), valu_mix=d.get("valu_mix"),
+                    rocprof_avg_us=d.get("rocprof_avg_us")), None
     if stale:
-        return None, "kernel sources changed since %s was collected (hash %s)" % (stale, want)
+        return None, "the loaded library (build id %s) is not the one %s was collected on" % (build_id, stale)
     return None, "no committed counters for chunk %d" % chunk
 
 
@@ -145,52 +136,75 @@ def valu_roofline(c, ext_s):
             "frac": ach / peak, "valu_insts_per_launch": insts, "mix": mix, "source": c["source"]}
 
 
-def cpu_baseline(p, sk, key_seed, cap, seconds_target=12.0):
-    """The CPU path timed on the host cores of this box, in the same run (BASELINE.md section 3).
-    Headline: oracle 'port' (oracle/sgfhe_oracle.c: reference-shaped, 128-bit Montgomery, 24 NTTs
-    per iteration -- what the Julia reference executes), one independent bootstrap per thread
-    (OpenMP over the batch, the sharding the GPUs use), over a k-loop truncated to about
-    `seconds_target` seconds and scaled to the full loop.  Beside it `opt`: the same arithmetic in
-    the GPU path's algebra (key in the NTT domain, 4 + 2 NTTs per iteration; bit-identical).
-    Test infrastructure used as a reported baseline only.  The key is the oracle's own generation
-    from the same seed (the same key as on the device)."""
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import oracle_c
+def _cpu_budget():
+    """(cores this process may run on, cgroup CPU quota in cores or None)."""
     try:
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
-    cores = max(1, min(cap, avail) if cap else avail)
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            quota = float(q) / float(per)
+    except (OSError, ValueError):
+        pass
+    return avail, quota
+
+
+def cpu_baseline(p, sk, key_seed, cap, seconds_target=8.0):
+    """The CPU path timed on the host cores of this box, in the same run (BASELINE.md section 3).
+    `port` = oracle/sgfhe_oracle.c, reference-shaped (128-bit Montgomery, 24 NTTs per iteration --
+    what the Julia reference executes), one independent bootstrap per thread (OpenMP over the
+    batch, the sharding the GPUs use), over a k-loop truncated to about `seconds_target` seconds
+    and scaled to the full loop; `opt` = the same arithmetic in the GPU path's algebra (key in the
+    NTT domain, 4 + 2 NTTs per iteration; bit-identical).  Timed twice: on every core this process
+    may use (the box's CPU rate: the headline `value`) and on one GPU's share of them (an eighth:
+    `share`).  Test infrastructure used as a reported baseline only.  The key is the oracle's own
+    generation from the same seed (the same key as on the device)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_c
+    avail, quota = _cpu_budget()
+    full = max(1, min(cap, avail) if cap else avail)
+    if quota:
+        full = max(1, min(full, int(quota + 0.5)))
+    share = max(1, avail // 8)
     o = oracle_c.Oracle.from_params(p)
     key = o.bootstrap_key(sk, key_seed)
+    khat = o.key_transform(key, threads=full) if o.uses_ntt else None
     rng = np.random.default_rng(7)
-    a = rng.integers(0, p.r, size=(2, cores, p.n), dtype=np.uint64)
-    b = rng.integers(0, p.r, size=(2, cores), dtype=np.uint64)
 
-    def timed(k, opt):
+    def timed(k, opt, cores):
+        a = rng.integers(0, p.r, size=(2, cores, p.n), dtype=np.uint64)
+        b = rng.integers(0, p.r, size=(2, cores), dtype=np.uint64)
         o.bootstrap_batch(k, a[0], b[0], a[1], b[1], n_iters=1, threads=cores, opt=opt)   # thread start-up
         t0 = time.perf_counter()
-        o.bootstrap_batch(k, a[0], b[0], a[1], b[1], n_iters=8, threads=cores, opt=opt)
-        per_iter = max((time.perf_counter() - t0) / 8, 1e-6)
+        o.bootstrap_batch(k, a[0], b[0], a[1], b[1], n_iters=4, threads=cores, opt=opt)
+        per_iter = max((time.perf_counter() - t0) / 4, 1e-6)
         iters = int(min(p.n, max(4, seconds_target / per_iter)))
         t0 = time.perf_counter()
         o.bootstrap_batch(k, a[0], b[0], a[1], b[1], n_iters=iters, threads=cores, opt=opt)
         dt = time.perf_counter() - t0
         return dt * p.n / iters, iters, dt
-    full, iters, dt = timed(key, False)
-    res = {"value": cores / full, "unit": "bootstraps/sec", "cores": cores,
-           "cores_available": avail, "cores_cap": cap or None, "kind": "port",
-           "per_core": 1.0 / full,
-           "sample": "%d bootstraps in parallel (one per thread), first %d of %d k-loop iterations "
-                     "(%.1f s), scaled x%.2f; reference-shaped C restatement"
-                     % (cores, iters, p.n, dt, p.n / iters)}
-    if o.uses_ntt:
-        khat = o.key_transform(key, threads=cores)
-        del key
-        ofull, oiters, odt = timed(khat, True)
-        res["opt"] = {"value": cores / ofull, "per_core": 1.0 / ofull,
-                      "sample": "same threads, GPU-path algebra (NTT-domain key, 6 NTTs per iteration "
-                                "instead of 24), first %d iterations (%.1f s)" % (oiters, odt)}
+
+    def leg(cores):
+        t, iters, dt = timed(key, False, cores)
+        r = {"value": cores / t, "unit": "bootstraps/sec", "cores": cores, "kind": "port",
+             "per_core": 1.0 / t,
+             "sample": "%d bootstraps in parallel (one per thread), first %d of %d k-loop iterations "
+                       "(%.1f s), scaled x%.2f; reference-shaped C restatement"
+                       % (cores, iters, p.n, dt, p.n / iters)}
+        if khat is not None:
+            ot, oiters, odt = timed(khat, True, cores)
+            r["opt"] = {"value": cores / ot, "per_core": 1.0 / ot,
+                        "sample": "same threads, GPU-path algebra (NTT-domain key, 6 NTTs per iteration "
+                                  "instead of 24), first %d iterations (%.1f s)" % (oiters, odt)}
+        return r
+    res = leg(full)
+    res.update({"cores_available": avail, "cores_cap": cap or None,
+                "cgroup_cpu_quota": quota})
+    if share != full:
+        res["share"] = dict(leg(share), note="one GPU's share of the host: cores_available / 8")
     return res
 
 
@@ -257,8 +271,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-io", action="store_true",
                     help="skip the extra step timed through host pointers (sgfhe_bootstrap_batch)")
-    ap.add_argument("--cpu-threads", type=int, default=16,
-                    help="cap on the cpu_baseline threads (0 = every core this process may use)")
+    ap.add_argument("--cpu-threads", type=int, default=0,
+                    help="cap on the cpu_baseline threads (0 = every core this process may use; "
+                         "the leg on an eighth of them is reported beside it)")
     ap.add_argument("--flatten", choices=["deterministic", "random"], default="deterministic",
                     help="random: the rng::AbstractRNG branch (src/utils.jl:198-241) on a ctx created "
                          "with SGFHE_CTX_RANDOM_FLATTEN (six primes at Params(1024)); not the headline")
@@ -372,13 +387,32 @@ def main():
         value = total / dt
         per_boot = algorithmic_bytes_per_bootstrap(p, W, B)
         chunk = tm["chunk"] or B
-        # one k_extprod launch = `chunk` bootstraps x one k-loop iteration = chunk / n bootstraps
+        # one k-loop iteration of a chunk = one k_extprod launch + one k_crt_acc2 launch
+        # = `chunk` bootstraps x one iteration = chunk / n bootstraps' worth of algorithmic bytes
         launch_bytes = per_boot * chunk / p.n
         ext_s = tm["extprod_ms"] * 1e-3
         crt_s = tm["crt_ms"] * 1e-3
-        achieved = launch_bytes / ext_s / 1e9 if ext_s > 0 else 0.0
+        ext_gbs = launch_bytes / ext_s / 1e9 if ext_s > 0 else 0.0
         pair = launch_bytes / (ext_s + crt_s) / 1e9 if ext_s + crt_s > 0 else 0.0
-        ctr, why = _counters(args.config, chunk)
+        build_id = eng.build_id()
+        ctr, why = _counters(args.config, chunk, build_id)
+        kern = {"k_extprod": {"launch_ms": tm["extprod_ms"], "launch_samples": tm["extprod_samples"],
+                              "kernel_achieved": ext_gbs, "kernel_frac": ext_gbs / PEAK_HBM_GBS},
+                "k_crt_acc2": {"launch_ms": tm["crt_ms"], "launch_samples": tm["crt_samples"]}}
+        traffic = None
+        rp_ms = None
+        if ctr:
+            t_ext = ctr.get("k_extprod", {}).get("traffic_bytes_per_launch")
+            t_crt = ctr.get("k_crt_acc", {}).get("traffic_bytes_per_launch")
+            kern["k_extprod"]["traffic"] = t_ext
+            kern["k_crt_acc2"]["traffic"] = t_crt
+            if t_ext is not None and t_crt is not None:
+                traffic = t_ext + t_crt
+            rp = ctr.get("rocprof_avg_us") or {}
+            if "k_extprod" in rp and "k_crt_acc2" in rp:
+                kern["k_extprod"]["launch_ms_rocprof"] = rp["k_extprod"] * 1e-3
+                kern["k_crt_acc2"]["launch_ms_rocprof"] = rp["k_crt_acc2"] * 1e-3
+                rp_ms = (rp["k_extprod"] + rp["k_crt_acc2"]) * 1e-3
         res = {
             "metric": "bootstraps/sec", "value": value, "unit": "bootstraps/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -391,15 +425,24 @@ def main():
                        "rns_primes": len(eng.primes()),
                        "key": "generated on the device from a seed (valid key)",
                        "keygen_s": round(keygen_s, 3), "key_bytes": eng.key_device_form_bytes(),
-                       "key_broadcast_s": round(bcast_s, 4)},
-            "roofline": {"bound": "hbm", "kernel": "k_extprod", "achieved": achieved,
-                         "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": achieved / PEAK_HBM_GBS,
-                         "traffic": ctr["k_extprod"].get("traffic_bytes_per_launch") if ctr else None,
-                         "traffic_note": None if ctr else why,
-                         "launch_ms": tm["extprod_ms"], "launch_samples": tm["extprod_samples"],
+                       "key_broadcast_s": round(bcast_s, 4), "build_id": build_id},
+            # The unit the roofline is stated for is one k-loop iteration of a chunk, i.e. the PAIR
+            # of launches k_extprod + k_crt_acc2: `achieved`, `frac`, `launch_ms` and `traffic` are
+            # the pair's.  The dominant kernel alone is under kernels.k_extprod (kernel_frac).
+            "roofline": {"bound": "hbm",
+                         "kernel": "k_extprod + k_crt_acc2 (one k-loop iteration of a %d-bootstrap chunk)" % chunk,
+                         "achieved": pair, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                         "frac": pair / PEAK_HBM_GBS,
+                         "traffic": traffic,
+                         "traffic_ratio": traffic / launch_bytes if traffic else None,
+                         "traffic_note": ("HBM bytes of both launches from the committed PMC passes (%s), "
+                                          "not measured in this run" % ctr["source"]) if ctr else why,
                          "algorithmic_bytes_per_launch": launch_bytes,
-                         "pair_kernel": "k_crt_acc2", "pair_launch_ms": tm["crt_ms"],
-                         "pair_achieved": pair, "pair_frac": pair / PEAK_HBM_GBS,
+                         "launch_ms": tm["extprod_ms"] + tm["crt_ms"],
+                         "launch_ms_source": "HIP events on the ctx stream around every 64th iteration "
+                                             "(they over-read by a few per cent; rocprofv3 is the authority)",
+                         "launch_ms_rocprof": rp_ms,
+                         "kernels": kern,
                          "whole_job_frac": per_boot * value / world / (PEAK_HBM_GBS * 1e9),
                          "valu": valu_roofline(ctr, ext_s)},
         }

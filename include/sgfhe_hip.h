@@ -10,7 +10,9 @@
  *   - every function returns an int32 status: 0 = OK, negative = sgfhe_status error
  *   - no exception crosses the boundary; sgfhe_last_error_string() explains the last failure
  *   - the caller owns every buffer it passes; the library owns device memory behind the handle
- *   - one ctx per device; a ctx is not thread-safe (one host thread, or an external lock)
+ *   - a ctx is bound to one device; any number of ctxs may share a device.  Every entry point
+ *     that takes a ctx locks it for the duration of the call, so a ctx may be shared by host
+ *     threads (calls on one ctx are serialised; calls on different ctxs run concurrently)
  *   - residues mod Q cross the boundary as canonical representatives in [0, Q), little-endian
  *     `limbs` x uint64 each, limbs = 2 (16 bytes, the reference's UInt128 storage width) unless
  *     stated otherwise; LWE words over Z_r are one uint64 each, exactly the memory of
@@ -51,7 +53,7 @@ typedef struct {
     uint64_t m;           /* bootstrap polynomial length, power of two, 2^6 .. 2^14 */
     uint64_t ell;         /* gadget decomposition length; must be 2 */
     uint64_t Q[2];        /* bootstrap modulus, Q < 2^94 */
-    uint64_t B[2];        /* gadget base, B^2 >= Q, B < 2^46 */
+    uint64_t B[2];        /* gadget base, B^2 >= Q, B < 2^47 */
     uint64_t DQ_tilde[2]; /* Q / 8 for Params(n) */
 } sgfhe_params;
 
@@ -64,6 +66,17 @@ typedef struct {
 
 /* Library / build information: "sgfhe_hip <version> gfx950". */
 const char *sgfhe_version(void);
+/* Revision of this header the library was built against.  A binding compares it with the
+ * SGFHE_ABI_VERSION it was written for and refuses a stale library (julia/SGFHEHip.jl __init__,
+ * sgfhe.jl_amd/_lib.py).  Bumped whenever a signature, a struct layout, a flag value or the
+ * meaning of an argument changes. */
+#define SGFHE_ABI_VERSION 3u
+uint32_t sgfhe_abi_version(void);
+/* Identity of the kernel sources the library was compiled from: the first 16 hex digits of the
+ * SHA-256 over csrc/{*.h, *.hip} (in file-name order), followed by "+<flags>" when the build used
+ * extra -D flags (timing-only ablation builds).  bench.py quotes profile counters only when they
+ * were collected on a library with the same id. */
+const char *sgfhe_build_id(void);
 
 /* Create an engine for one parameter set on HIP device `device`.
  * Replaces: the type-level set-up Julia does when `Params(n)` fixes MgModUInt{LargeType, Q}
@@ -192,8 +205,9 @@ int32_t sgfhe_debug_cmux(sgfhe_ctx *ctx, const uint64_t *a, const uint64_t *b, c
  *   out_w, out_v : [count][m] uint64 in [0, r)         (Ciphertext.rlwe.a / .b coefficients)
  * Runs count * n gate bootstraps (trivial encryption of 1 paired with every bit, AND branch,
  * un-reduced), then the n half-width external products against the key on the device.
- * Always the deterministic flatten (rng = nothing), whatever sgfhe_set_random_flatten selected
- * for gate bootstraps.  Host pointers; synchronous.
+ * Flatten mode: the one sgfhe_set_random_flatten selected for this ctx, for the gate bootstraps
+ * and for the flatten of every as_i alike (the reference passes the same `rng` to both,
+ * src/fhe.jl:673,683-684): deterministic by default.  Host pointers; synchronous.
  */
 int32_t sgfhe_pack_encrypted_bits(sgfhe_ctx *ctx, const uint64_t *a, const uint64_t *b,
                                   size_t count, uint64_t *out_w, uint64_t *out_v);

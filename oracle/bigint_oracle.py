@@ -384,6 +384,8 @@ def bootstrap_key(p, sk, seed, noise=None):
     (coefficient i from words 2 (i mod 8), + 1 of block i / 8 as a 64-bit value mod 2 noise + 1)."""
     key32 = seed_bytes(seed)
     noise = p.n if noise is None else noise
+    if not 0 <= noise < (1 << 30) or 2 * noise >= p.Q:            # the bound sgfhe_bkey_generate enforces
+        raise ValueError("noise must be below 2^30 and below Q / 2")
     ext_key = resize(sk, p.m)                                     # fhe.jl:185
     G = gadget_matrix(p)                                          # fhe.jl:190
     key = []

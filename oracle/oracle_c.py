@@ -188,7 +188,10 @@ class Oracle:
         """[n][4][2][m][2] uint64 canonical residues (fhe.jl:181-201)."""
         bkey = np.zeros((self.n, 4, 2, self.m, 2), dtype=np.uint64)
         sk = np.ascontiguousarray(sk, dtype=np.uint64)
-        lib().sgo_bootstrap_key(self._ctx, _p(sk), seed_bytes(seed), self.n if noise is None else noise,
+        noise = self.n if noise is None else int(noise)
+        if not 0 <= noise < (1 << 30) or 2 * noise >= self.Q:   # the bound sgfhe_bkey_generate enforces
+            raise ValueError("noise must be below 2^30 and below Q / 2")
+        lib().sgo_bootstrap_key(self._ctx, _p(sk), seed_bytes(seed), noise,
                                 _p(bkey), threads or os.cpu_count() or 1)
         return bkey
 

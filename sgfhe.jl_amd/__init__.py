@@ -6,7 +6,7 @@ libsgfhe_hip.so (hand-written HIP for gfx950; include/sgfhe_hip.h).  Import as
 `import sgfhe_jl_amd` (repo-root shim; the directory name contains a dot).
 """
 
-from ._lib import build, lib, LIB_PATH, EXPORTED_SYMBOLS
+from ._lib import build, lib, LIB_PATH, EXPORTED_SYMBOLS, ABI_VERSION, source_hash, embedded_build_id
 from .engine import Engine, SgfheError, FLAG_RAW_MODQ, CTX_RANDOM_FLATTEN
 from .params import Params, find_modulus, isprime
 from . import distributed
@@ -15,7 +15,7 @@ from .scheme import (PrivateKey, PublicKey, PublicEncryptedCiphertext, Bootstrap
                      bootstrap_batch, pack_encrypted_bits, encrypt_optimal, normalize_ciphertext,
                      PrivateEncryptedCiphertext, packbits, unpackbits, prng_expand)
 
-__all__ = ["distributed", "build", "lib", "LIB_PATH", "EXPORTED_SYMBOLS", "Engine", "SgfheError",
+__all__ = ["distributed", "build", "lib", "LIB_PATH", "EXPORTED_SYMBOLS", "ABI_VERSION", "source_hash", "embedded_build_id", "Engine", "SgfheError",
            "FLAG_RAW_MODQ", "CTX_RANDOM_FLATTEN", "Params", "find_modulus", "isprime", "PrivateKey", "BootstrapKey",
            "PublicKey", "PublicEncryptedCiphertext",
            "LWE", "RLWE", "EncryptedBit", "PackedCiphertext", "encrypt", "extract",

@@ -6,12 +6,15 @@ raises.
 """
 
 import ctypes
+import hashlib
 import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.environ.get("SGFHE_HIP_LIB") or os.path.join(CSRC, "libsgfhe_hip.so")
+
+ABI_VERSION = 3   # SGFHE_ABI_VERSION of include/sgfhe_hip.h this binding was written for
 
 _u64p = ctypes.POINTER(ctypes.c_uint64)
 _u32p = ctypes.POINTER(ctypes.c_uint32)
@@ -24,19 +27,40 @@ class SgfheParams(ctypes.Structure):
                 ("DQ_tilde", ctypes.c_uint64 * 2)]
 
 
-def _sources_newer():
-    if not os.path.exists(LIB_PATH):
-        return True
-    t = os.path.getmtime(LIB_PATH)
-    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))]
-    srcs.append(os.path.join(_HERE, "..", "include", "sgfhe_hip.h"))
-    return any(os.path.getmtime(s) > t for s in srcs if os.path.exists(s))
+def source_hash():
+    """Identity of the kernel sources: SHA-256 over csrc/{*.h, *.hip} in file-name order (what the
+    Makefile embeds in the library as sgfhe_build_id())."""
+    h = hashlib.sha256()
+    for f in sorted(f for f in os.listdir(CSRC) if f.endswith((".h", ".hip"))):
+        with open(os.path.join(CSRC, f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def embedded_build_id(path):
+    """sgfhe_build_id() of a library file, read without loading it (None if absent)."""
+    try:
+        with open(path, "rb") as fh:
+            data = fh.read()
+    except OSError:
+        return None
+    i = data.find(b"SGFHE_BUILD_ID=")
+    if i < 0:
+        return None
+    j = data.find(b"\0", i)
+    return data[i + 15:j].decode("ascii", "replace")
+
+
+def _stale():
+    """The in-tree library is missing or was not built from the sources next to it."""
+    return embedded_build_id(LIB_PATH) != source_hash()
 
 
 def build(force=False):
-    """Compile the HIP engine for gfx950 (hipcc cross-compiles without a GPU)."""
-    if force or _sources_newer():
-        subprocess.check_call(["make", "-C", CSRC] + (["-B"] if force else []) + ["libsgfhe_hip.so"])
+    """Compile the HIP engine for gfx950 (hipcc cross-compiles without a GPU).  A library whose
+    embedded build id differs from the sources in csrc/ is rebuilt."""
+    if force or _stale():
+        subprocess.check_call(["make", "-C", CSRC, "-B", "libsgfhe_hip.so"])
     return LIB_PATH
 
 
@@ -47,7 +71,12 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    if os.environ.get("SGFHE_HIP_LIB"):
+        # an explicitly chosen library (ablation builds of tools/exp_*.sh): loaded as it is; its
+        # sgfhe_build_id() tells bench.py that the committed profile counters are not its own
+        if not os.path.exists(LIB_PATH):
+            raise OSError("SGFHE_HIP_LIB=%s does not exist" % LIB_PATH)
+    elif _stale():
         build()
     try:
         # PyTorch-ROCm ships its own copy of the HIP runtime.  Loading it first makes this
@@ -60,6 +89,8 @@ def lib():
     vp, i32, u32, u64, sz = ctypes.c_void_p, ctypes.c_int32, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_size_t
     sig = {
         "sgfhe_version": (ctypes.c_char_p, []),
+        "sgfhe_abi_version": (u32, []),
+        "sgfhe_build_id": (ctypes.c_char_p, []),
         "sgfhe_ctx_create": (i32, [ctypes.POINTER(SgfheParams), ctypes.c_int, ctypes.POINTER(vp)]),
         "sgfhe_ctx_create_ex": (i32, [ctypes.POINTER(SgfheParams), ctypes.c_int, u32, ctypes.POINTER(vp)]),
         "sgfhe_ctx_destroy": (i32, [vp]),
@@ -93,12 +124,15 @@ def lib():
         fn = getattr(L, name)          # AttributeError if the library lacks a declared symbol
         fn.restype = res
         fn.argtypes = args
+    if L.sgfhe_abi_version() != ABI_VERSION:
+        raise OSError("%s implements ABI revision %d, this binding needs %d (stale library?)"
+                      % (LIB_PATH, L.sgfhe_abi_version(), ABI_VERSION))
     _lib = L
     return L
 
 
 EXPORTED_SYMBOLS = (
-    "sgfhe_version", "sgfhe_ctx_create", "sgfhe_ctx_create_ex", "sgfhe_ctx_destroy", "sgfhe_last_error_string",
+    "sgfhe_version", "sgfhe_abi_version", "sgfhe_build_id", "sgfhe_ctx_create", "sgfhe_ctx_create_ex", "sgfhe_ctx_destroy", "sgfhe_last_error_string",
     "sgfhe_set_chunk", "sgfhe_set_lanes", "sgfhe_set_small_batch_max", "sgfhe_set_random_flatten", "sgfhe_bkey_upload", "sgfhe_bkey_upload_rns2", "sgfhe_rns2_convert", "sgfhe_bkey_generate",
     "sgfhe_bkey_device_form_bytes", "sgfhe_bkey_export_device_form",
     "sgfhe_bkey_import_device_form", "sgfhe_bootstrap_batch", "sgfhe_bootstrap_batch_device",

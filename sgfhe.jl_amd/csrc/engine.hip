@@ -8,6 +8,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -73,6 +74,9 @@ struct sgfhe_ctx {
     uint32_t primes[NPR_MAX];
     uint32_t npr = 0;  // RNS primes in use: the fewest whose product covers the exactness bound
     std::string err;
+    // Every C-ABI entry point that takes a ctx holds this lock for the whole call: a ctx may be
+    // shared by host threads (their calls are serialised), different ctxs run concurrently.
+    mutable std::recursive_mutex mu;
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;  // second lane: chunk i+1 overlaps its memory-bound k_crt_acc
                                     // with the VALU-bound k_extprod of chunk i
@@ -121,6 +125,8 @@ struct sgfhe_ctx {
 enum : uint32_t { ATTR_EXTPROD = 1u, ATTR_SMALL = 2u, ATTR_SHORTPROD = 4u };
 
 namespace {
+
+#define SGFHE_LOCK(ctx) std::lock_guard<std::recursive_mutex> lock_((ctx)->mu)
 
 #define HIPCHK(ctx, call)                                                                         \
     do {                                                                                          \
@@ -584,8 +590,11 @@ int32_t build_constants(sgfhe_ctx *c) {
         const u128 stot = s + xmax;
         cc.xmax = (uint64_t)xmax;
         cc.offneg_rnd = (Q - (((1 + B) % Q) * (stot % Q)) % Q) % Q;
-        // |u| <= 2 B in that mode: the exactness bound needs 4 x more head-room
-        c->rnd_ok = (log_need + 2.0 <= log_have) && (B >> 46) == 0;
+        // |u| <= 2 B in that mode: the exactness bound needs 4 x more head-room.  Its reductions
+        // (random_digits, acc_from_digits, crt_reduce) divide values up to about 4 B^2 by Q with a
+        // double-precision quotient estimate, exact while the quotient stays below 2^50.
+        c->rnd_ok = (log_need + 2.0 <= log_have) && (B >> 46) == 0 &&
+                    (2.0 * u128_log2(B) + 2.0 - u128_log2(Q) < 50.0);
     }
     cc.DQ = ld128(c->par.DQ_tilde) % Q;
     cc.halfQ = Q / 2;
@@ -760,10 +769,28 @@ int32_t key_transform_host(sgfhe_ctx *c, const uint64_t *canon, uint32_t npolys,
 
 extern "C" {
 
-const char *sgfhe_version(void) { return "sgfhe_hip 0.2.0 gfx950"; }
+const char *sgfhe_version(void) { return "sgfhe_hip 0.3.0 gfx950"; }
 
+uint32_t sgfhe_abi_version(void) { return SGFHE_ABI_VERSION; }
+
+// The Makefile passes the hash of the kernel sources (and any extra -D flags of an ablation
+// build); the marker prefix lets tools find the id in the file without loading it.
+#ifndef SGFHE_BUILD_ID
+#define SGFHE_BUILD_ID "unknown"
+#endif
+const char *sgfhe_build_id(void) {
+    static const char id[] = "SGFHE_BUILD_ID=" SGFHE_BUILD_ID;
+    return id + 15;
+}
+
+// The message of the last failed call on this ctx, copied for the calling thread (the ctx may be
+// shared): valid until the same thread asks again.
 const char *sgfhe_last_error_string(const sgfhe_ctx *ctx) {
-    return ctx ? ctx->err.c_str() : "null context";
+    if (!ctx) return "null context";
+    static thread_local std::string copy;
+    SGFHE_LOCK(ctx);
+    copy = ctx->err;
+    return copy.c_str();
 }
 
 int32_t sgfhe_ctx_create(const sgfhe_params *p, int device, sgfhe_ctx **out) {
@@ -834,6 +861,7 @@ int32_t sgfhe_ctx_destroy(sgfhe_ctx *c) {
 
 int32_t sgfhe_set_chunk(sgfhe_ctx *c, uint32_t chunk) {
     if (!c) return SGFHE_ERR_INVALID_ARG;
+    SGFHE_LOCK(c);
     // the kernels index a chunk's planes with 32-bit byte offsets: residues [chunk][2][npr][m] x 4 B
     // and digit records [chunk][2] x 16 m B must stay below 4 GiB
     const uint64_t cap_y = 0xFFFFFFFFull / ((uint64_t)2 * c->npr * c->M * 4);
@@ -846,6 +874,7 @@ int32_t sgfhe_set_chunk(sgfhe_ctx *c, uint32_t chunk) {
 
 int32_t sgfhe_set_random_flatten(sgfhe_ctx *c, int enable, uint64_t seed) {
     if (!c) return SGFHE_ERR_INVALID_ARG;
+    SGFHE_LOCK(c);
     if (enable && !c->rnd_ok)
         return fail(c, SGFHE_ERR_UNSUPPORTED,
                     "randomised flatten: 20 m B Q exceeds the product of this ctx's RNS primes (or B >= 2^46); "
@@ -858,6 +887,7 @@ int32_t sgfhe_set_random_flatten(sgfhe_ctx *c, int enable, uint64_t seed) {
 
 int32_t sgfhe_set_small_batch_max(sgfhe_ctx *c, uint32_t max_bootstraps) {
     if (!c) return SGFHE_ERR_INVALID_ARG;
+    SGFHE_LOCK(c);
     if (max_bootstraps > 256)
         return fail(c, SGFHE_ERR_INVALID_ARG, "small-batch form: at most 256 bootstraps");
     (void)hipSetDevice(c->device);
@@ -870,12 +900,14 @@ int32_t sgfhe_set_small_batch_max(sgfhe_ctx *c, uint32_t max_bootstraps) {
 
 int32_t sgfhe_set_lanes(sgfhe_ctx *c, uint32_t lanes) {
     if (!c || lanes < 1 || lanes > 2) return SGFHE_ERR_INVALID_ARG;
+    SGFHE_LOCK(c);
     c->lanes = lanes;
     return SGFHE_OK;
 }
 
 int32_t sgfhe_bkey_upload(sgfhe_ctx *c, const uint64_t *canonical, size_t n_words) {
     if (!c || !canonical) return SGFHE_ERR_INVALID_ARG;
+    SGFHE_LOCK(c);
     (void)hipSetDevice(c->device);
     const size_t expect = (size_t)c->n * 8 * c->M * 2;
     if (n_words != expect) return fail(c, SGFHE_ERR_INVALID_ARG, "bkey_upload: n_words != n*8*m*2");
@@ -897,6 +929,7 @@ int32_t sgfhe_bkey_upload(sgfhe_ctx *c, const uint64_t *canonical, size_t n_word
 int32_t sgfhe_bkey_generate(sgfhe_ctx *c, const uint64_t *sk, size_t n_sk, const uint8_t *seed32,
                             uint32_t noise) {
     if (!c || !sk || !seed32) return SGFHE_ERR_INVALID_ARG;
+    SGFHE_LOCK(c);
     if (c->M < 8) return fail(c, SGFHE_ERR_UNSUPPORTED, "bkey_generate needs m >= 8");
     ChaChaKey ck;
     for (int i = 0; i < 8; i++)
@@ -904,6 +937,9 @@ int32_t sgfhe_bkey_generate(sgfhe_ctx *c, const uint64_t *sk, size_t n_sk, const
                   ((uint32_t)seed32[4 * i + 2] << 16) | ((uint32_t)seed32[4 * i + 3] << 24);
     if (n_sk != c->n) return fail(c, SGFHE_ERR_INVALID_ARG, "bkey_generate: secret key must hold n bits");
     if (c->Q < ((u128)1 << 16)) return fail(c, SGFHE_ERR_UNSUPPORTED, "bkey_generate needs Q >= 2^16");
+    // e in [-noise, noise] is formed in int32 and lifted as Q - |e| (k_keygen_draw / k_keygen_finish)
+    if (noise >= (1u << 30) || (u128)noise * 2 >= c->Q)
+        return fail(c, SGFHE_ERR_INVALID_ARG, "bkey_generate: noise must be below 2^30 and below Q / 2");
     (void)hipSetDevice(c->device);
     int32_t rc = key_alloc(c);
     if (rc) return rc;
@@ -981,6 +1017,7 @@ static int32_t rns2_configure(sgfhe_ctx *c, uint64_t m1, uint64_t m2) {
 int32_t sgfhe_bkey_upload_rns2(sgfhe_ctx *c, const uint64_t *pairs, size_t n_words, uint64_t m1,
                                uint64_t m2) {
     if (!c || !pairs) return SGFHE_ERR_INVALID_ARG;
+    SGFHE_LOCK(c);
     (void)hipSetDevice(c->device);
     const size_t expect = (size_t)c->n * 8 * c->M * 2;
     if (n_words != expect) return fail(c, SGFHE_ERR_INVALID_ARG, "bkey_upload_rns2: bad n_words");
@@ -1004,6 +1041,7 @@ int32_t sgfhe_bkey_upload_rns2(sgfhe_ctx *c, const uint64_t *pairs, size_t n_wor
 int32_t sgfhe_rns2_convert(sgfhe_ctx *c, int to_pairs, const uint64_t *in, size_t count, uint64_t m1,
                            uint64_t m2, uint64_t *out) {
     if (!c || !in || !out) return SGFHE_ERR_INVALID_ARG;
+    SGFHE_LOCK(c);
     if (count == 0) return SGFHE_OK;
     (void)hipSetDevice(c->device);
     int32_t rc = rns2_configure(c, m1, m2);
@@ -1039,12 +1077,14 @@ int32_t sgfhe_rns2_convert(sgfhe_ctx *c, int to_pairs, const uint64_t *in, size_
 
 int32_t sgfhe_bkey_device_form_bytes(const sgfhe_ctx *c, size_t *bytes) {
     if (!c || !bytes) return SGFHE_ERR_INVALID_ARG;
+    SGFHE_LOCK(c);
     *bytes = sizeof(KeyBlobHeader) + (size_t)c->n * c->npr * 8 * c->M * 4;
     return SGFHE_OK;
 }
 
 int32_t sgfhe_bkey_export_device_form(sgfhe_ctx *c, void *dst) {
     if (!c || !dst) return SGFHE_ERR_INVALID_ARG;
+    SGFHE_LOCK(c);
     if (!c->have_key) return fail(c, SGFHE_ERR_NO_KEY, "no bootstrap key uploaded");
     (void)hipSetDevice(c->device);
     const KeyBlobHeader h = blob_header(c);
@@ -1057,6 +1097,7 @@ int32_t sgfhe_bkey_export_device_form(sgfhe_ctx *c, void *dst) {
 
 int32_t sgfhe_bkey_import_device_form(sgfhe_ctx *c, const void *src) {
     if (!c || !src) return SGFHE_ERR_INVALID_ARG;
+    SGFHE_LOCK(c);
     (void)hipSetDevice(c->device);
     KeyBlobHeader got;
     HIPCHK(c, hipMemcpy(&got, src, sizeof got, hipMemcpyDeviceToHost));
@@ -1081,6 +1122,7 @@ int32_t sgfhe_bootstrap_batch_device(sgfhe_ctx *c, const uint64_t *a1, const uin
                                      const uint64_t *a2, const uint64_t *b2, size_t batch,
                                      uint64_t *out, uint32_t flags, void *stream) {
     if (!c || !a1 || !b1 || !a2 || !b2 || !out) return SGFHE_ERR_INVALID_ARG;
+    SGFHE_LOCK(c);
     if (batch == 0) return SGFHE_OK;
     (void)hipSetDevice(c->device);
     return bootstrap_device(c, a1, b1, a2, b2, batch, out, flags, c->n, nullptr,
@@ -1089,6 +1131,7 @@ int32_t sgfhe_bootstrap_batch_device(sgfhe_ctx *c, const uint64_t *a1, const uin
 
 int32_t sgfhe_sync(sgfhe_ctx *c) {
     if (!c) return SGFHE_ERR_INVALID_ARG;
+    SGFHE_LOCK(c);
     (void)hipSetDevice(c->device);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return SGFHE_OK;
@@ -1141,6 +1184,7 @@ int32_t sgfhe_bootstrap_batch(sgfhe_ctx *c, const uint64_t *a1, const uint64_t *
                               const uint64_t *a2, const uint64_t *b2, size_t batch, uint64_t *out,
                               uint32_t flags) {
     if (!c || !a1 || !b1 || !a2 || !b2 || !out) return SGFHE_ERR_INVALID_ARG;
+    SGFHE_LOCK(c);
     if (batch == 0) return SGFHE_OK;
     return bootstrap_host(c, a1, b1, a2, b2, batch, out, flags, c->n, nullptr);
 }
@@ -1149,6 +1193,7 @@ int32_t sgfhe_debug_accumulators(sgfhe_ctx *c, const uint64_t *a1, const uint64_
                                  const uint64_t *a2, const uint64_t *b2, size_t batch,
                                  uint64_t n_iters, uint64_t *acc) {
     if (!c || !a1 || !b1 || !a2 || !b2 || !acc) return SGFHE_ERR_INVALID_ARG;
+    SGFHE_LOCK(c);
     if (n_iters > c->n) return fail(c, SGFHE_ERR_INVALID_ARG, "n_iters > n");
     if (batch == 0) return SGFHE_OK;
     return bootstrap_host(c, a1, b1, a2, b2, batch, nullptr, 0, n_iters, acc);
@@ -1157,6 +1202,7 @@ int32_t sgfhe_debug_accumulators(sgfhe_ctx *c, const uint64_t *a1, const uint64_
 int32_t sgfhe_debug_digits(sgfhe_ctx *c, const uint64_t *a1, const uint64_t *b1, const uint64_t *a2,
                            const uint64_t *b2, size_t batch, uint64_t n_iters, uint64_t *digits) {
     if (!c || !a1 || !b1 || !a2 || !b2 || !digits) return SGFHE_ERR_INVALID_ARG;
+    SGFHE_LOCK(c);
     if (n_iters > c->n) return fail(c, SGFHE_ERR_INVALID_ARG, "n_iters > n");
     if (batch == 0) return SGFHE_OK;
     return bootstrap_host(c, a1, b1, a2, b2, batch, nullptr, 0, n_iters, nullptr, digits);
@@ -1164,6 +1210,7 @@ int32_t sgfhe_debug_digits(sgfhe_ctx *c, const uint64_t *a1, const uint64_t *b1,
 
 int32_t sgfhe_debug_flatten(sgfhe_ctx *c, const uint64_t *values, uint64_t *digits) {
     if (!c || !values || !digits) return SGFHE_ERR_INVALID_ARG;
+    SGFHE_LOCK(c);
     (void)hipSetDevice(c->device);
     const uint32_t M = c->M;
     int32_t rc = ensure_work(c, 8);
@@ -1196,6 +1243,7 @@ int32_t sgfhe_debug_flatten(sgfhe_ctx *c, const uint64_t *values, uint64_t *digi
 int32_t sgfhe_external_product(sgfhe_ctx *c, const uint64_t *a, const uint64_t *b,
                                const uint64_t *A, uint64_t *a_res, uint64_t *b_res) {
     if (!c || !a || !b || !A || !a_res || !b_res) return SGFHE_ERR_INVALID_ARG;
+    SGFHE_LOCK(c);
     (void)hipSetDevice(c->device);
     const uint32_t M = c->M;
     const uint32_t cpad = 8;
@@ -1233,6 +1281,7 @@ int32_t sgfhe_external_product(sgfhe_ctx *c, const uint64_t *a, const uint64_t *
 int32_t sgfhe_debug_cmux(sgfhe_ctx *c, const uint64_t *a, const uint64_t *b, const uint64_t *C,
                          uint64_t j, uint64_t *a_res, uint64_t *b_res) {
     if (!c || !a || !b || !C || !a_res || !b_res) return SGFHE_ERR_INVALID_ARG;
+    SGFHE_LOCK(c);
     if (j >= 2 * (uint64_t)c->M) return fail(c, SGFHE_ERR_INVALID_ARG, "debug_cmux: j must be in [0, 2 m)");
     (void)hipSetDevice(c->device);
     const uint32_t M = c->M;
@@ -1276,6 +1325,7 @@ int32_t sgfhe_debug_cmux(sgfhe_ctx *c, const uint64_t *a, const uint64_t *b, con
 int32_t sgfhe_pack_encrypted_bits(sgfhe_ctx *c, const uint64_t *a, const uint64_t *b, size_t count,
                                   uint64_t *out_w, uint64_t *out_v) {
     if (!c || !a || !b || !out_w || !out_v) return SGFHE_ERR_INVALID_ARG;
+    SGFHE_LOCK(c);
     if (count == 0) return SGFHE_OK;
     if (!c->have_key) return fail(c, SGFHE_ERR_NO_KEY, "no bootstrap key uploaded");
     (void)hipSetDevice(c->device);
@@ -1344,6 +1394,7 @@ int32_t sgfhe_pack_encrypted_bits(sgfhe_ctx *c, const uint64_t *a, const uint64_
 int32_t sgfhe_debug_ntt(sgfhe_ctx *c, uint32_t prime_index, int inverse, const uint32_t *in,
                         uint32_t *out) {
     if (!c || !in || !out || prime_index >= c->npr) return SGFHE_ERR_INVALID_ARG;
+    SGFHE_LOCK(c);
     (void)hipSetDevice(c->device);
     uint32_t *d = nullptr;
     HIPCHK(c, hipMalloc(&d, (size_t)2 * c->M * 4));
@@ -1363,6 +1414,7 @@ int32_t sgfhe_debug_ntt(sgfhe_ctx *c, uint32_t prime_index, int inverse, const u
 
 int32_t sgfhe_debug_primes(const sgfhe_ctx *c, uint32_t *count, uint32_t *primes) {
     if (!c || !count || !primes) return SGFHE_ERR_INVALID_ARG;
+    SGFHE_LOCK(c);
     *count = c->npr;
     for (uint32_t i = 0; i < c->npr; i++) primes[i] = c->primes[i];
     return SGFHE_OK;
@@ -1370,12 +1422,14 @@ int32_t sgfhe_debug_primes(const sgfhe_ctx *c, uint32_t *count, uint32_t *primes
 
 int32_t sgfhe_timing_enable(sgfhe_ctx *c, int enable) {
     if (!c) return SGFHE_ERR_INVALID_ARG;
+    SGFHE_LOCK(c);
     c->timing = enable != 0;
     return SGFHE_OK;
 }
 
 int32_t sgfhe_timing_read(sgfhe_ctx *c, double *stats, int reset) {
     if (!c || !stats) return SGFHE_ERR_INVALID_ARG;
+    SGFHE_LOCK(c);
     (void)hipSetDevice(c->device);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     timing_flush(c);

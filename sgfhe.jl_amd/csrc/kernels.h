@@ -621,6 +621,18 @@ k_crt_acc2(const uint32_t *__restrict__ yres, uint64_t *__restrict__ dig,
     const uint32_t ol = rec + 4u * i, oh = rec + 8u * M + 2u * i;
     const uint2 l0 = ld_off<uint2>(dig, ol), l1 = ld_off<uint2>(dig, ol + 4u * M);
     const uint32_t h0 = ld_off<uint32_t>(dig, oh), h1 = ld_off<uint32_t>(dig, oh + 2u * M);
+#ifdef SGFHE_ABL_CRT_MEMONLY  // timing-only build: every load and store, no arithmetic (wrong results)
+    {
+        uint32_t ax = 0, ay = 0;
+#pragma unroll
+        for (int q = 0; q < NP; q++) { ax ^= yv[q].x; ay += yv[q].y; }
+        st_off<uint2>(dig, ol, make_uint2(l0.x ^ ax, l0.y + ay));
+        st_off<uint2>(dig, ol + 4u * M, make_uint2(l1.x + ay, l1.y ^ ax));
+        st_off<uint32_t>(dig, oh, h0 ^ ax);
+        st_off<uint32_t>(dig, oh + 2u * M, h1 + ay);
+        return;
+    }
+#endif
     const uint64_t B = (uint64_t)CC->B;
     uint32_t olo[2][2], ohi[2][2];  // [digit][coefficient]
 #pragma unroll

@@ -261,6 +261,11 @@ class Engine:
     def timing_enable(self, on=True):
         self._chk(self._L.sgfhe_timing_enable(self._h, int(on)))
 
+    def build_id(self):
+        """sgfhe_build_id() of the loaded library: hash of the kernel sources it was compiled from
+        (+ ablation flags)."""
+        return self._L.sgfhe_build_id().decode()
+
     def timing_read(self, reset=True):
         st = (ctypes.c_double * 5)()
         self._chk(self._L.sgfhe_timing_read(self._h, st, int(reset)))

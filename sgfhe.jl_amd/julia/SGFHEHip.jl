@@ -19,6 +19,16 @@ using Random: AbstractRNG
 
 const libsgfhe_hip = get(ENV, "SGFHE_HIP_LIB", "libsgfhe_hip.so")
 
+# Revision of include/sgfhe_hip.h these ccalls were written for (SGFHE_ABI_VERSION): a library
+# built from another revision is refused when the module loads.
+const ABI_VERSION = UInt32(3)
+
+function __init__()
+    got = ccall((:sgfhe_abi_version, libsgfhe_hip), UInt32, ())
+    got == ABI_VERSION ||
+        error("$libsgfhe_hip implements ABI revision $got, SGFHEHip.jl needs $ABI_VERSION")
+end
+
 # struct sgfhe_params (include/sgfhe_hip.h)
 struct CParams
     n::UInt64

@@ -81,7 +81,7 @@ def test_two_rank_gloo_matches_single_process(tmp_path, oc):
         assert full.tobytes() == ref.tobytes()
 
 
-@pytest.mark.parametrize("gpus", [1, 2])
+@pytest.mark.parametrize("gpus", [1, 2, 8])
 def test_bench_self_launch_dry_run(gpus):
     """`python bench.py --gpus N` starts its own ranks (torch.distributed.run on 127.0.0.1) and
     relays exactly one JSON line from rank 0; N = 1 runs in-process.  --dry-run swaps the engine

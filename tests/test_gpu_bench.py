@@ -36,12 +36,27 @@ def test_bench_line_contract():
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert r["achieved"] > 0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
-    assert r["launch_samples"] > 0 and r["launch_ms"] > 0
+    # `frac` is the whole iteration (both launches of the k-loop), the dominant kernel alone is
+    # under kernels.k_extprod; whole_job_frac is the driver-timed figure
+    k = r["kernels"]
+    assert k["k_extprod"]["launch_samples"] > 0 and k["k_extprod"]["launch_ms"] > 0
+    assert k["k_crt_acc2"]["launch_samples"] > 0 and k["k_crt_acc2"]["launch_ms"] > 0
+    assert abs(r["launch_ms"] - k["k_extprod"]["launch_ms"] - k["k_crt_acc2"]["launch_ms"]) < 1e-9
+    assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["launch_ms"] * 1e-3) / 1e9) < 1e-6 * r["achieved"]
+    assert k["k_extprod"]["kernel_frac"] > r["frac"] > 0
+    assert r["whole_job_frac"] > 0
+    assert "HIP events" in r["launch_ms_source"]
     # the committed counters are those of Params(1024): not quoted for another configuration
-    assert r["traffic"] is None and r["traffic_note"]
+    assert r["traffic"] is None and r["traffic_ratio"] is None and r["traffic_note"]
+    assert r["launch_ms_rocprof"] is None
+    assert d["config"]["build_id"]
     c = d["cpu_baseline"]
-    assert c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1 and c["cores_available"] >= c["cores"]
+    assert c["kind"] == "port" and c["value"] > 0 and c["cores_available"] >= c["cores"] >= 1
     assert c["opt"]["value"] > c["value"]            # 6 NTTs per iteration against 24
+    if c["cores_available"] >= 16 and not c["cgroup_cpu_quota"]:
+        assert c["cores"] == c["cores_available"]    # the box's CPU rate ...
+        sh = c["share"]                               # ... and one GPU's share of it
+        assert sh["cores"] == c["cores_available"] // 8 and sh["value"] > 0 and sh["opt"]["value"] > 0
     h = d["host_io"]
     assert h["value"] > 0 and h["equals_device_resident_output"] is True
 

@@ -84,6 +84,102 @@ def test_two_ranks_on_one_gpu_equal_one_process(tmp_path, S):
         assert full.tobytes() == ref.tobytes()
 
 
+_GPU_CHILD = r"""
+import sys
+import numpy as np
+import torch
+sys.path.insert(0, sys.argv[1])
+import sgfhe_jl_amd as S
+mode, blob_path, rank, world, batch, out_path = sys.argv[2], sys.argv[3], int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6]), sys.argv[7]
+params = S.Params(64)
+eng = S.Engine(params, device=0)
+nbytes = eng.key_device_form_bytes()
+if mode == "export":          # rank 0 builds the key and exports the device-form blob
+    eng.generate_key(np.random.default_rng(5).integers(0, 2, size=params.n, dtype=np.uint64), 9)
+    blob = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    eng.export_key_device_form(blob.data_ptr())
+    torch.cuda.synchronize()
+    blob.cpu().numpy().tofile(blob_path)
+else:                         # a rank imports the broadcast blob (header verified) and runs its shard
+    blob = torch.from_numpy(np.fromfile(blob_path, dtype=np.uint8)).cuda()
+    assert blob.numel() == nbytes
+    eng.import_key_device_form(blob.data_ptr())
+    rng = np.random.default_rng(77)
+    a1 = rng.integers(0, params.r, size=(batch, params.n), dtype=np.uint64)
+    b1 = rng.integers(0, params.r, size=batch, dtype=np.uint64)
+    a2 = rng.integers(0, params.r, size=(batch, params.n), dtype=np.uint64)
+    b2 = rng.integers(0, params.r, size=batch, dtype=np.uint64)
+    lo, hi, out = S.distributed.bootstrap_sharded(eng.bootstrap_batch, a1, b1, a2, b2, rank, world)
+    assert (lo, hi) == S.distributed.shard_range(batch, rank, world)
+    np.save(out_path, out)
+eng.close()
+"""
+
+
+def _rank_of_eight(rank, world, port, tmpdir, batch, wave):
+    """One of 8 gloo ranks.  The pool admits at most 6 processes on a GPU at once, so a rank never
+    opens the GPU itself: its device work (export on rank 0, import + shard on every rank) runs in
+    a short-lived child, and the ranks take the GPU in waves of `wave`."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    import sgfhe_jl_amd as S
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    def child(mode, blob_path, out_path):
+        subprocess.run([sys.executable, "-c", _GPU_CHILD, root, mode, blob_path, str(rank), str(world),
+                        str(batch), out_path], check=True, timeout=600)
+    mine = os.path.join(tmpdir, "blob_%d.bin" % rank)
+    if rank == 0:
+        child("export", mine, "")
+        blob = torch.from_numpy(np.fromfile(mine, dtype=np.uint8))
+        size = torch.tensor([blob.numel()], dtype=torch.int64)
+    else:
+        size = torch.zeros(1, dtype=torch.int64)
+    dist.broadcast(size, src=0)
+    if rank != 0:
+        blob = torch.empty(int(size.item()), dtype=torch.uint8)
+    dist.broadcast(blob, src=0)                              # the one-time key broadcast (gloo here)
+    if rank != 0:
+        blob.numpy().tofile(mine)
+    out_path = os.path.join(tmpdir, "shard_%d.npy" % rank)
+    for w in range((world + wave - 1) // wave):
+        if rank // wave == w:
+            child("shard", mine, out_path)
+        dist.barrier()
+    full = S.distributed.gather_outputs(np.load(out_path), batch, world)
+    np.save(os.path.join(tmpdir, "full_%d.npy" % rank), full)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_eight_ranks_on_one_gpu_equal_one_process(tmp_path, S):
+    """World size 8 (BASELINE.json config 5's rank count) rehearsed on one GPU: rank 0 generates
+    the key and exports the device-form blob, the blob is broadcast to 7 peers, every rank imports
+    it (header check) and bootstraps its contiguous shard of a ragged batch (8 does not divide
+    203), the shards are all-gathered, and every rank's gathered bytes equal one process doing
+    the whole batch.  The 8 ranks share device 0 in waves of 4 short-lived GPU children (the
+    pool's process guard), and the broadcast runs over gloo; the RCCL / one-device-per-rank form
+    of the same flow is test_two_gpu_shards_equal_one_gpu."""
+    import torch.multiprocessing as mp
+    world, batch = 8, 203
+    mp.spawn(_rank_of_eight, args=(world, _free_port(), str(tmp_path), batch, 4), nprocs=world, join=True)
+    params = S.Params(64)
+    eng = S.Engine(params, device=0)
+    eng.generate_key(np.random.default_rng(5).integers(0, 2, size=params.n, dtype=np.uint64), 9)
+    ref = eng.bootstrap_batch(*_inputs(params, batch))
+    eng.close()
+    sizes = [S.distributed.shard_range(batch, r, world) for r in range(world)]
+    assert len({hi - lo for lo, hi in sizes}) == 2           # ragged: 25 and 26
+    for r in range(world):
+        full = np.load(os.path.join(str(tmp_path), "full_%d.npy" % r))
+        assert full.tobytes() == ref.tobytes()
+
+
 def test_two_gpu_shards_equal_one_gpu(tmp_path, S):
     import torch
     if torch.cuda.device_count() < 2:

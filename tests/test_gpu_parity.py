@@ -277,6 +277,70 @@ def test_synthetic_single_limb_1024(S, oc, form):
               form=form)
 
 
+def test_synthetic_single_limb_full_batch_4096(S, oc):
+    """BASELINE.json config 3 at its full batch: n = 1024 over a single-limb 64-bit prime, batch
+    4096 (8 chunks of 512 on the four-prime grid at m = 8192).  Four random LWE input pairs are
+    verified by the oracle on the synthetic key of the bench (`bench.random_key`), tiled 1024
+    times in a shuffled order: every one of the 4096 x 3 x 1025 output words is pinned to an
+    oracle word, across all chunks and batch positions.  (Synthetic ring: the parity target is the
+    oracle at the same parameters, not decryption)"""
+    import bench
+    params = bench.make_params(S, "synth64")
+    o = oc.Oracle.from_params(params)
+    key = bench.random_key(params, 31)
+    eng = S.Engine(params)
+    assert len(eng.primes()) == 4
+    eng.upload_key(key)
+    rng = np.random.default_rng(33)
+    a1 = rng.integers(0, params.r, size=(4, params.n), dtype=np.uint64)
+    a2 = rng.integers(0, params.r, size=(4, params.n), dtype=np.uint64)
+    b1 = rng.integers(0, params.r, size=4, dtype=np.uint64)
+    b2 = rng.integers(0, params.r, size=4, dtype=np.uint64)
+    ref = o.bootstrap_batch(key, a1, b1, a2, b2, threads=4)
+    del key
+    idx = np.random.default_rng(34).permutation(np.repeat(np.arange(4), 1024))
+    out = eng.bootstrap_batch(a1[idx], b1[idx], a2[idx], b2[idx])
+    assert out.shape == (4096, 3, params.n + 1)
+    assert np.array_equal(out, ref[idx])
+    eng.close()
+
+
+def test_config5_per_gpu_shards_of_65536(S, oc):
+    """BASELINE.json config 5 on the one GPU a box has: Params(1024), a logical batch of 65536
+    bootstraps cut into the 8 contiguous shards `shard_range(65536, g, 8)` that 8 ranks would
+    take (8192 each = 16 chunks of 512).  Every shard runs through Engine.bootstrap_batch as a
+    rank would run it and every one of its 8192 x 3 x 1025 words is pinned to an oracle word
+    (4 oracle-verified input pairs tiled in a shuffled order over the 65536 rows); the
+    concatenated shards equal one whole-batch call on the same rows (the batch independence of
+    src/fhe.jl:579-582 that the sharding relies on)."""
+    params = S.Params(1024)
+    o = oc.Oracle.from_params(params)
+    sk = o.private_key(21)
+    bkey = o.bootstrap_key(sk, 22)
+    eng = S.Engine(params)
+    eng.generate_key(sk, 22)
+    bits, a1, b1, a2, b2 = _inputs(o, sk, 4, 23)
+    ref = o.bootstrap_batch(bkey, a1, b1, a2, b2, threads=4)
+    del bkey
+    total, world = 65536, 8
+    idx = np.random.default_rng(25).permutation(np.repeat(np.arange(4), total // 4))
+    shards = []
+    for g in range(world):
+        lo, hi = S.distributed.shard_range(total, g, world)
+        assert hi - lo == 8192
+        rows = idx[lo:hi]
+        out = eng.bootstrap_batch(a1[rows], b1[rows], a2[rows], b2[rows])
+        assert out.shape == (8192, 3, params.n + 1)
+        assert np.array_equal(out, ref[rows]), "shard %d differs from the oracle" % g
+        shards.append(out)
+    whole = eng.bootstrap_batch(a1[idx], b1[idx], a2[idx], b2[idx])      # one call, 65536 rows
+    assert whole.tobytes() == np.concatenate(shards, axis=0).tobytes()
+    y1, y2 = bits[0::2], bits[1::2]
+    dec = o.lwe_decrypt_bits(sk, whole[::4096, 0, :params.n], whole[::4096, 0, params.n])
+    assert np.array_equal(dec, (y1 & y2)[idx[::4096]])
+    eng.close()
+
+
 def test_params64_soak_4096_random_bootstraps(S, oc):
     """4096 independent gate bootstraps at Params(64) with a device-generated key, every output
     word against the oracle (random LWE inputs and valid encryptions mixed), all three gates

@@ -40,10 +40,12 @@ def main():
     if stats:
         shutil.copy(stats[0], os.path.join(prof, "%s_kernel_stats.csv" % tag))
     log = os.path.join(src, "bench_stats.log")
+    bench_line = None
     if os.path.exists(log):
         lines = [l for l in open(log) if l.startswith("{")]
         if lines:
             open(os.path.join(prof, "%s_bench_under_rocprof.json" % tag), "w").write(lines[-1])
+            bench_line = json.loads(lines[-1])
     out = {"note": "rocprofv3 --pmc passes (one counter group per run, --kernel-trace only), "
                    "bench.py --batch %d --steps 1 --warmup 0 = one chunk of %d bootstraps, " % (chunk, chunk) +
                    "Params(1024); per-launch averages. FETCH_SIZE / WRITE_SIZE are reported in KB; "
@@ -51,8 +53,18 @@ def main():
                    "(MI355X_MICROARCH.md, HBM section): traffic = (2 FETCH_SIZE + WRITE_SIZE) * 1024 B.",
            "chunk": chunk, "kernels": {}}
     sys.path.insert(0, root)
-    import bench
-    out["source_hash"] = bench.source_hash()   # bench.py quotes these counters only for this code
+    import sgfhe_jl_amd
+    # bench.py quotes these numbers only beside a library with this sgfhe_build_id(): the id the
+    # profiled run itself reported, else the hash of the sources here
+    out["build_id"] = (bench_line or {}).get("config", {}).get("build_id") or sgfhe_jl_amd.source_hash()
+    if stats:   # rocprofv3 --kernel-trace --stats averages of the two k-loop kernels (the authority
+                # for launch durations; the HIP-event samples of bench.py over-read by a few per cent)
+        avg = {}
+        for r in csv.DictReader(open(stats[0])):
+            for k in ("k_extprod", "k_crt_acc2"):
+                if "::" + k + "<" in r["Name"]:
+                    avg[k] = float(r["AverageNs"]) / 1e3
+        out["rocprof_avg_us"] = avg
     try:
         out["valu_mix"] = json.loads(subprocess.check_output(
             [sys.executable, os.path.join(root, "tools", "valu_mix.py")]).decode())
