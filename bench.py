@@ -267,8 +267,11 @@ def main():
     ap.add_argument("--batch", type=int, default=0,
                     help="bootstraps per GPU per step (default 4096; 8192 on 8 GPUs = config 5)")
     ap.add_argument("--chunk", type=int, default=0, help="lock-step chunk (0 = engine default)")
-    ap.add_argument("--lanes", type=int, default=1, help="1 = chunks in sequence, 2 = two streams")
+    ap.add_argument("--lanes", type=int, default=0,
+                    help="0 = engine default (2: pairs of chunks on two streams), 1 = chunks in sequence")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-isolated", action="store_true",
+                    help="skip the extra untimed step that measures each kernel alone (lanes = 1)")
     ap.add_argument("--no-host-io", action="store_true",
                     help="skip the extra step timed through host pointers (sgfhe_bootstrap_batch)")
     ap.add_argument("--cpu-threads", type=int, default=0,
@@ -310,9 +313,10 @@ def main():
     eng = S.Engine(p, device=local_rank, random_flatten=rnd)
     if rnd:
         eng.set_random_flatten(True, 0x5EED + rank)
+    if args.lanes:
+        eng.set_lanes(args.lanes)
     if args.chunk:
         eng.set_chunk(args.chunk)
-    eng.set_lanes(args.lanes)
 
     # ---- bootstrap key: rank 0 generates, peers receive the device form over RCCL ---------------
     sk = np.random.default_rng(11).integers(0, 2, size=p.n, dtype=np.uint64)
@@ -360,6 +364,17 @@ def main():
         dt = float(tmax.item())
 
     tm = eng.timing_read(reset=True)
+    lanes = 2 if (args.lanes or 2) == 2 and B > (tm["chunk"] or B) else 1
+    iso = None
+    if lanes == 2 and not args.no_isolated:
+        # The kernels of the two lanes overlap, so their sampled durations are durations under
+        # co-execution.  One extra, untimed step with the same chunks in sequence gives the
+        # durations of each kernel alone on the device.
+        eng.set_lanes(1)
+        eng.set_chunk(tm["chunk"])
+        step()
+        iso = eng.timing_read(reset=True)
+        eng.set_lanes(2)
     eng.timing_enable(False)
 
     # ---- the metric as SURVEY.md 8(d) words it: host buffers in, host buffers out (PCIe inside) ----
@@ -387,32 +402,45 @@ def main():
         value = total / dt
         per_boot = algorithmic_bytes_per_bootstrap(p, W, B)
         chunk = tm["chunk"] or B
-        # one k-loop iteration of a chunk = one k_extprod launch + one k_crt_acc2 launch
-        # = `chunk` bootstraps x one iteration = chunk / n bootstraps' worth of algorithmic bytes
+        # The unit of the roofline: one k-loop iteration of one chunk = one k_extprod launch + one
+        # k_crt_lean launch = `chunk` bootstraps x one iteration = chunk / n bootstraps' worth of
+        # algorithmic bytes.  Its duration is the device wall time of the call (HIP events from the
+        # first to the last kernel of a step, both lanes) divided by the chunk-iterations in it:
+        # with two lanes the two kernels of different chunks overlap and per-kernel durations do
+        # not add up.
         launch_bytes = per_boot * chunk / p.n
+        iter_s = tm["call_ms"] * 1e-3 * chunk / (tm["call_batch"] * p.n) if tm["calls"] else 0.0
+        achieved = launch_bytes / iter_s / 1e9 if iter_s > 0 else 0.0
         ext_s = tm["extprod_ms"] * 1e-3
-        crt_s = tm["crt_ms"] * 1e-3
-        ext_gbs = launch_bytes / ext_s / 1e9 if ext_s > 0 else 0.0
-        pair = launch_bytes / (ext_s + crt_s) / 1e9 if ext_s + crt_s > 0 else 0.0
         build_id = eng.build_id()
         ctr, why = _counters(args.config, chunk, build_id)
+        how = ("overlapped with the other lane's kernels" if lanes == 2 else "alone on the device")
         kern = {"k_extprod": {"launch_ms": tm["extprod_ms"], "launch_samples": tm["extprod_samples"],
-                              "kernel_achieved": ext_gbs, "kernel_frac": ext_gbs / PEAK_HBM_GBS},
-                "k_crt_acc2": {"launch_ms": tm["crt_ms"], "launch_samples": tm["crt_samples"]}}
+                              "launch_ms_is": how},
+                "k_crt_lean": {"launch_ms": tm["crt_ms"], "launch_samples": tm["crt_samples"],
+                               "launch_ms_is": how}}
+        alone = iso or tm
+        for k, key in (("k_extprod", "extprod_ms"), ("k_crt_lean", "crt_ms")):
+            kern[k]["launch_ms_alone"] = alone[key]
+            kern[k]["kernel_achieved"] = launch_bytes / (alone[key] * 1e-3) / 1e9 if alone[key] > 0 else 0.0
+            kern[k]["kernel_frac"] = kern[k]["kernel_achieved"] / PEAK_HBM_GBS
         traffic = None
         rp_ms = None
         if ctr:
             t_ext = ctr.get("k_extprod", {}).get("traffic_bytes_per_launch")
-            t_crt = ctr.get("k_crt_acc", {}).get("traffic_bytes_per_launch")
+            t_crt = ctr.get("k_crt_lean", {}).get("traffic_bytes_per_launch")
             kern["k_extprod"]["traffic"] = t_ext
-            kern["k_crt_acc2"]["traffic"] = t_crt
+            kern["k_crt_lean"]["traffic"] = t_crt
             if t_ext is not None and t_crt is not None:
                 traffic = t_ext + t_crt
             rp = ctr.get("rocprof_avg_us") or {}
-            if "k_extprod" in rp and "k_crt_acc2" in rp:
-                kern["k_extprod"]["launch_ms_rocprof"] = rp["k_extprod"] * 1e-3
-                kern["k_crt_acc2"]["launch_ms_rocprof"] = rp["k_crt_acc2"] * 1e-3
-                rp_ms = (rp["k_extprod"] + rp["k_crt_acc2"]) * 1e-3
+            rpa = ctr.get("rocprof_alone_avg_us") or {}
+            for k in ("k_extprod", "k_crt_lean"):
+                if k in rp:
+                    kern[k]["launch_ms_rocprof"] = rp[k] * 1e-3
+                if k in rpa:
+                    kern[k]["launch_ms_alone_rocprof"] = rpa[k] * 1e-3
+            rp_ms = ctr.get("rocprof_iter_us") and ctr["rocprof_iter_us"] * 1e-3
         res = {
             "metric": "bootstraps/sec", "value": value, "unit": "bootstraps/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -421,30 +449,29 @@ def main():
             "config": {"workload": "%s gate bootstraps (AND/OR/XOR), batch %d per GPU, "
                                    "%s flatten" % (args.config, B, args.flatten),
                        "n": p.n, "m": p.m, "log2_Q": round(float(np.log2(float(p.Q))), 2),
-                       "batch_per_gpu": B, "chunk": chunk, "lanes": args.lanes,
+                       "batch_per_gpu": B, "chunk": chunk, "lanes": lanes,
                        "rns_primes": len(eng.primes()),
                        "key": "generated on the device from a seed (valid key)",
                        "keygen_s": round(keygen_s, 3), "key_bytes": eng.key_device_form_bytes(),
                        "key_broadcast_s": round(bcast_s, 4), "build_id": build_id},
-            # The unit the roofline is stated for is one k-loop iteration of a chunk, i.e. the PAIR
-            # of launches k_extprod + k_crt_acc2: `achieved`, `frac`, `launch_ms` and `traffic` are
-            # the pair's.  The dominant kernel alone is under kernels.k_extprod (kernel_frac).
             "roofline": {"bound": "hbm",
-                         "kernel": "k_extprod + k_crt_acc2 (one k-loop iteration of a %d-bootstrap chunk)" % chunk,
-                         "achieved": pair, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                         "frac": pair / PEAK_HBM_GBS,
+                         "kernel": "k_extprod + k_crt_lean (one k-loop iteration of a %d-bootstrap chunk%s)"
+                                   % (chunk, "; the two kernels of the two lanes' chunks overlap" if lanes == 2 else ""),
+                         "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                         "frac": achieved / PEAK_HBM_GBS,
                          "traffic": traffic,
                          "traffic_ratio": traffic / launch_bytes if traffic else None,
                          "traffic_note": ("HBM bytes of both launches from the committed PMC passes (%s), "
                                           "not measured in this run" % ctr["source"]) if ctr else why,
                          "algorithmic_bytes_per_launch": launch_bytes,
-                         "launch_ms": tm["extprod_ms"] + tm["crt_ms"],
-                         "launch_ms_source": "HIP events on the ctx stream around every 64th iteration "
-                                             "(they over-read by a few per cent; rocprofv3 is the authority)",
+                         "launch_ms": iter_s * 1e3,
+                         "launch_ms_source": "HIP events on the ctx stream around whole steps (first to last "
+                                             "kernel, both lanes) / chunk-iterations per step; per-kernel "
+                                             "samples (every 64th iteration) under `kernels`",
                          "launch_ms_rocprof": rp_ms,
                          "kernels": kern,
                          "whole_job_frac": per_boot * value / world / (PEAK_HBM_GBS * 1e9),
-                         "valu": valu_roofline(ctr, ext_s)},
+                         "valu": valu_roofline(ctr, (alone["extprod_ms"]) * 1e-3)},
         }
         if host_io:
             res["host_io"] = host_io

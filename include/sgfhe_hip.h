@@ -94,10 +94,12 @@ int32_t sgfhe_ctx_destroy(sgfhe_ctx *ctx);
 const char *sgfhe_last_error_string(const sgfhe_ctx *ctx);
 
 /* Batch-scheduling knobs.  chunk: bootstraps that move through the k-loop in lock-step
- * (0 = default; rounded up to a multiple of 8; a chunk's buffers must stay below 4 GiB).  lanes: 1 (default) runs the
- * chunks of a batch one after the other; 2 runs pairs of chunks on two HIP streams (measured
- * within 2 % of one stream with twice the chunk).  Every setting gives bit-identical results, in
- * both flatten modes. */
+ * (0 = default; rounded up to a multiple of 8; a chunk's buffers must stay below 4 GiB).
+ * lanes: 2 (default) runs pairs of chunks on two HIP streams, so that the memory-bound CRT kernel
+ * of one chunk runs beside the arithmetic-bound external product of the other (+2 ... 5 % at
+ * Params(1024), profiles/r03_exp_lanes_sweep.txt); 1 runs the chunks of a batch one after the
+ * other, with twice the default chunk.  Every setting gives bit-identical results, in both
+ * flatten modes. */
 int32_t sgfhe_set_chunk(sgfhe_ctx *ctx, uint32_t chunk);
 /* Chunks of at most this many bootstraps (default 24, 0 = never, at most 256) run the k-loop in
  * its small-batch form: 6 workgroups per (bootstrap, RNS prime) and three launches per iteration
@@ -243,10 +245,14 @@ int32_t sgfhe_debug_primes(const sgfhe_ctx *ctx, uint32_t *count, uint32_t *prim
 
 /*
  * Measurement hook for bench.py: HIP-event timings taken on the ctx stream around sampled
- * launches of the two per-iteration kernels since the last reset.
+ * launches of the two per-iteration kernels since the last reset (stats must hold 8 doubles).
  *   stats[0] = average external-product kernel time (ms)   stats[1] = its sampled launches
  *   stats[2] = average CRT/accumulate kernel time (ms)     stats[3] = its sampled launches
  *   stats[4] = bootstraps per external-product launch (chunk actually used)
+ *   stats[5] = average device time of a whole sgfhe_bootstrap_batch_device call (ms), from its
+ *              first to its last kernel on both lanes     stats[6] = calls   stats[7] = batch
+ * With two lanes the kernels of the lanes overlap: stats[0] and [2] are then durations under
+ * co-execution and do not add up to an iteration; stats[5] is the wall time.
  */
 int32_t sgfhe_timing_enable(sgfhe_ctx *ctx, int enable);
 int32_t sgfhe_timing_read(sgfhe_ctx *ctx, double *stats, int reset);

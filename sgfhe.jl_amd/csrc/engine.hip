@@ -87,6 +87,8 @@ struct sgfhe_ctx {
     uint32_t *d_bad = nullptr;  // set by k_key_transform when a key residue is >= Q
     int32_t *d_tw = nullptr;  // npr * 2 * M entries
     CrtConst h_crt;
+    CrtLean *d_lean = nullptr;  // constants of k_crt_lean (nl = 0: this parameter set keeps k_crt_acc)
+    CrtLean h_lean;
     uint32_t pack_G = 1, pack_G_rnd = 0;  // key slices per exact-accumulation group of the packing path
                                           // (deterministic / randomised flatten; 0 = not available)
     // key
@@ -94,7 +96,7 @@ struct sgfhe_ctx {
     size_t key_bytes = 0;
     bool have_key = false;
     // work buffers: two lanes, each sized for `cap` bootstraps
-    uint32_t chunk = 0, cap = 0, lanes = 1;
+    uint32_t chunk = 0, cap = 0, lanes = 2;
     // randomised flatten (rng != nothing, utils.jl:198-241)
     bool rnd = false, rnd_ok = false;
     uint64_t rnd_seed = 0;
@@ -109,6 +111,7 @@ struct sgfhe_ctx {
         uint32_t *ua = nullptr;
         int32_t *zpart = nullptr;  // small-batch form only: [cap_small][npr][4][2][m]
     } lane[2];
+    bool use_lean = true;     // SGFHE_CRT_LEAN=0 in the environment: keep k_crt_acc2 (A/B measurements)
     uint32_t small_max = 24;  // chunks of at most this many bootstraps take the small-batch form
                               // (measured crossover at Params(1024): 24 -> 32.3 vs 40.9 ms, 32 -> 44.0 vs 42.3 ms)
     // timing
@@ -118,6 +121,12 @@ struct sgfhe_ctx {
     double t_ext = 0, t_crt = 0;
     uint64_t n_ext = 0, n_crt = 0;
     uint32_t last_chunk = 0;
+    // whole bootstrap_device calls (fork ... join): the k-loop's wall time on the device when the
+    // kernels of two lanes overlap and per-kernel durations no longer add up
+    struct EvPair { hipEvent_t e0, e1; uint64_t batch; };
+    std::vector<EvPair> ev_call;
+    double t_call = 0;
+    uint64_t n_call = 0, boots_call = 0;
     // kernels whose dynamic-LDS limit has been raised on this ctx's device (hipFuncSetAttribute is
     // per device; a ctx is bound to one device and used by one host thread)
     uint32_t attr_done = 0;
@@ -300,12 +309,27 @@ int32_t launch_dbgntt(sgfhe_ctx *c, const uint32_t *in, uint32_t *out, uint32_t 
 
 // k_crt_acc is compiled once per prime count (its residue loops are unrolled)
 #define SGFHE_FOR_NPR(X) X(2) X(3) X(4) X(5) X(6) X(7)
+template <int NP>
+void launch_crt_lean_t(sgfhe_ctx *c, const uint32_t *yres, uint64_t *dig, uint32_t total, hipStream_t st) {
+    const dim3 grid((total / 4 + 255) / 256), block(256);
+    switch (c->h_lean.nl) {
+    case 2: hipLaunchKernelGGL((k_crt_lean<NP, 2>), grid, block, 0, st, yres, dig, c->d_lean, total / 4, (uint32_t)c->logm); break;
+    case 3: hipLaunchKernelGGL((k_crt_lean<NP, 3>), grid, block, 0, st, yres, dig, c->d_lean, total / 4, (uint32_t)c->logm); break;
+    default: hipLaunchKernelGGL((k_crt_lean<NP, 4>), grid, block, 0, st, yres, dig, c->d_lean, total / 4, (uint32_t)c->logm); break;
+    }
+}
 int32_t launch_crt_raw(sgfhe_ctx *c, const uint32_t *yres, uint64_t *dig, uint32_t total,
                        uint32_t mode, hipStream_t st, RndArgs ra, uint32_t iter) {
+    // the k-loop's own case (deterministic flatten, accumulator present): the integer-only kernel,
+    // four coefficients per thread; every other mode, and parameter sets outside its bounds
+    // (B < 2^12, Q < 2^30), the general one
+    const bool lean = mode == 0u && c->h_lean.nl != 0 && c->use_lean;
     switch (c->npr) {
 #define X(NP)                                                                                     \
     case NP:                                                                                      \
-        if (mode == 0u) /* the k-loop's own case: two coefficients per thread */                 \
+        if (lean)                                                                                 \
+            launch_crt_lean_t<NP>(c, yres, dig, total, st);                                       \
+        else if (mode == 0u) /* two coefficients per thread */                                   \
             hipLaunchKernelGGL(k_crt_acc2<NP>, dim3((total / 2 + 255) / 256), dim3(256), 0, st,   \
                                yres, dig, c->d_crt, total / 2, (uint32_t)c->logm);                \
         else                                                                                      \
@@ -338,7 +362,11 @@ size_t per_bootstrap_bytes(const sgfhe_ctx *c) {
 // k_extprod per bootstrap and iteration): chunk 256 0.568, 408 0.553, 512 0.547, 608 0.572,
 // 816 0.575.
 uint32_t default_chunk(const sgfhe_ctx *c) {
-    size_t budget = (size_t)320 << 20;
+    // Two lanes (the default): half the budget per lane, so that the working sets of both chunks
+    // stay near the Infinity Cache together.  Measured at Params(1024) with k_crt_lean
+    // (profiles/r03_exp_lanes_sweep.txt): two lanes of 128 / 192 / 256 / 320 / 384 give
+    // 1892 / 1916 / 1907 / 1825 / 1814 bootstraps/s against 1864 for one lane of 512.
+    size_t budget = (size_t)(c->lanes == 2 ? 160 : 320) << 20;
     size_t k = budget / per_bootstrap_bytes(c);
     if (k >= 256) k = (k / 256) * 256;
     else k = (k / 8) * 8;
@@ -384,6 +412,13 @@ void timing_flush(sgfhe_ctx *c) {
         (void)hipEventDestroy(t.e2);
     }
     c->ev.clear();
+    for (auto &t : c->ev_call) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, t.e0, t.e1) == hipSuccess) { c->t_call += ms; c->n_call++; c->boots_call += t.batch; }
+        (void)hipEventDestroy(t.e0);
+        (void)hipEventDestroy(t.e1);
+    }
+    c->ev_call.clear();
 }
 
 // ---- the k-loop (fhe.jl:579-582) over one chunk, or over two chunks in a pipeline --------------------
@@ -456,6 +491,12 @@ int32_t bootstrap_device(sgfhe_ctx *c, const uint64_t *a1, const uint64_t *b1, c
         if (rc) return rc;
         c->last_chunk = round_up8(first);
     }
+    hipEvent_t ecall0 = nullptr, ecall1 = nullptr;
+    if (c->timing && c->ev_call.size() < 256) {
+        HIPCHK(c, hipEventCreate(&ecall0));
+        HIPCHK(c, hipEventCreate(&ecall1));
+        HIPCHK(c, hipEventRecord(ecall0, st));
+    }
     if (two_lanes) {  // fork: the second lane starts after everything already queued on st
         HIPCHK(c, hipEventRecord(c->ev_fork, st));
         HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
@@ -513,6 +554,10 @@ int32_t bootstrap_device(sgfhe_ctx *c, const uint64_t *a1, const uint64_t *b1, c
     if (two_lanes) {  // join
         HIPCHK(c, hipEventRecord(c->ev_join, c->stream2));
         HIPCHK(c, hipStreamWaitEvent(st, c->ev_join, 0));
+    }
+    if (ecall0) {
+        HIPCHK(c, hipEventRecord(ecall1, st));
+        c->ev_call.push_back({ecall0, ecall1, (uint64_t)batch});
     }
     return SGFHE_OK;
 }
@@ -625,6 +670,55 @@ int32_t build_constants(sgfhe_ctx *c) {
     limbs(Q, cc.Q32, 3);
     cc.Bd = u128_dbl(B);
 
+    {   // k_crt_lean (kernels.h; tests/rns_model.py::CrtLean derives the same values)
+        CrtLean &K = c->h_lean;
+        memset(&K, 0, sizeof K);
+        int nq = 0, nb = 0;
+        while (nq < 128 && (Q >> nq)) nq++;
+        while (nb < 64 && (B >> nb)) nb++;
+        int NL = (nq + 28) / 29;
+        if (NL < 2) NL = 2;
+        const int t = nq - 29, a = 29 * (NL - 1) - t;
+        if (nb >= 13 && NL <= 4 && nq >= 30 && a >= 0 && a <= 28) {
+            auto lim = [&](u128 v, uint32_t *w) {
+                for (int k = 0; k < 4; k++) w[k] = (uint32_t)((v >> (29 * k)) & 0x1FFFFFFFu);
+            };
+            for (int i = 0; i < NPR; i++) {
+                lim(cc.c[i], K.c[i]);
+                K.w[i] = (uint32_t)((1ull << 58) / c->primes[i]);
+            }
+            lim((Q - cM % Q) % Q, K.cMn);
+            K.hoff = (plast - 1) / 2;
+            limbs(Q, K.Qw, 3);
+            K.B0 = (uint32_t)(B & 0x1FFFFFFFu);
+            K.B1 = (uint32_t)(B >> 29);
+            K.Bw0 = (uint32_t)B;
+            K.Bw1 = (uint32_t)(B >> 32);
+            // floor(2^(t + 72) / Q) < 2^44: long division, 2^(t + 72) has up to 138 bits
+            {
+                u128 rem = 0, quo = 0;
+                for (int bit = t + 72; bit >= 0; bit--) {
+                    rem = (rem << 1) | (bit == t + 72 ? 1 : 0);
+                    quo <<= 1;
+                    if (rem >= Q) { rem -= Q; quo |= 1; }
+                }
+                K.mq0 = (uint32_t)quo;
+                K.mq1 = (uint32_t)(quo >> 32);
+            }
+            {   // floor(2^(nb + 51) / B) <= 2^52
+                const u128 quo = ((u128)1 << (nb + 51)) / B;
+                K.mb0 = (uint32_t)quo;
+                K.mb1 = (uint32_t)(quo >> 32);
+            }
+            K.a = (uint32_t)a;
+            K.t2 = (uint32_t)(nq > 63 ? nq - 63 : 0);
+            K.sB = (uint32_t)(nb + 51 - (int)K.t2 - 64);
+            K.nl = (uint32_t)NL;
+        }
+        const char *env = getenv("SGFHE_CRT_LEAN");
+        c->use_lean = !(env && env[0] == '0');
+    }
+
     // twiddle tables and per-prime constants (all residues centred: |.| <= (p - 1) / 2)
     std::vector<int32_t> tw((size_t)NPR * 2 * M);
     std::vector<PrimeK> pk(NPR);
@@ -688,6 +782,8 @@ int32_t build_constants(sgfhe_ctx *c) {
     HIPCHK(c, hipMemset(c->d_bad, 0, sizeof(uint32_t)));
     HIPCHK(c, hipMalloc(&c->d_crt, sizeof(CrtConst)));
     HIPCHK(c, hipMemcpy(c->d_crt, &cc, sizeof(CrtConst), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMalloc(&c->d_lean, sizeof(CrtLean)));
+    HIPCHK(c, hipMemcpy(c->d_lean, &c->h_lean, sizeof(CrtLean), hipMemcpyHostToDevice));
     return SGFHE_OK;
 }
 
@@ -851,6 +947,7 @@ int32_t sgfhe_ctx_destroy(sgfhe_ctx *c) {
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->d_primes) (void)hipFree(c->d_primes);
     if (c->d_crt) (void)hipFree(c->d_crt);
+    if (c->d_lean) (void)hipFree(c->d_lean);
     if (c->d_bad) (void)hipFree(c->d_bad);
     if (c->d_tw) (void)hipFree(c->d_tw);
     if (c->d_key) (void)hipFree(c->d_key);
@@ -1438,7 +1535,13 @@ int32_t sgfhe_timing_read(sgfhe_ctx *c, double *stats, int reset) {
     stats[2] = c->n_crt ? c->t_crt / (double)c->n_crt : 0.0;
     stats[3] = (double)c->n_crt;
     stats[4] = (double)c->last_chunk;
-    if (reset) { c->t_ext = c->t_crt = 0; c->n_ext = c->n_crt = 0; }
+    stats[5] = c->n_call ? c->t_call / (double)c->n_call : 0.0;
+    stats[6] = (double)c->n_call;
+    stats[7] = c->n_call ? (double)c->boots_call / (double)c->n_call : 0.0;
+    if (reset) {
+        c->t_ext = c->t_crt = c->t_call = 0;
+        c->n_ext = c->n_crt = c->n_call = c->boots_call = 0;
+    }
     return SGFHE_OK;
 }
 

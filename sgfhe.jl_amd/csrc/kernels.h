@@ -261,6 +261,9 @@ k_extprod(const uint64_t *__restrict__ dig, const int32_t *__restrict__ keyk,
     using G = NttGeom<LOGM, LE>;
     constexpr int M = G::M, T = G::T, E = G::E;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+#ifdef SGFHE_EXT_PRIO  // experiment: issue priority over a co-running k_crt_lean (second lane)
+    __builtin_amdgcn_s_setprio(SGFHE_EXT_PRIO);
+#endif
     int32_t *const z1 = reinterpret_cast<int32_t *>(lds) + M + threadIdx.x;  // z1[e * T]: private to the thread, conflict-free
 
     const int tid = threadIdx.x;
@@ -657,6 +660,163 @@ k_crt_acc2(const uint32_t *__restrict__ yres, uint64_t *__restrict__ dig,
     st_off<uint2>(dig, ol + 4u * M, make_uint2(olo[1][0], olo[1][1]));
     st_off<uint32_t>(dig, oh, (ohi[0][0] & 0xFFFFu) | (ohi[0][1] << 16));
     st_off<uint32_t>(dig, oh + 2u * M, (ohi[1][0] & 0xFFFFu) | (ohi[1][1] << 16));
+}
+
+// ---- k_crt_lean: the k-loop's CRT + accumulate + flatten in integer arithmetic ---------------------
+// Same function as k_crt_acc2 (deterministic flatten, previous accumulator present) at less than
+// half the vector instructions: the kernel is HBM-bound on its own, but on the second lane it runs
+// beside the other chunk's k_extprod, which is bound by vector-ALU issue -- there every instruction
+// of this kernel is paid in full (profiles/r03_exp_crt_ceiling.txt).  No floating point, no table:
+//   alpha = (sum_i y_i w_i) >> 58,  w_i = floor(2^58 / p_i)           (5 multiply-adds)
+//   S = sum_i y'_i c_i + alpha (-M mod Q) + hi_old B + lo_old  <  2^34.5 Q,  y'_i = y_i except
+//     y'_last = y_last - (p_last - 1) / 2: that takes H' = (M / p_last) (p_last - 1) / 2 out again
+//     as NL sums L_k over 29-bit limbs of the constants: every product is below 2^61, so a limb sum
+//     is one chain of v_mad_u64_u32 with no carry handling (S = sum_k L_k 2^(29 k))
+//   q = ((S >> t) mq) >> 72 with mq = floor(2^(t + 72) / Q) < 2^44, t = bits(Q) - 29, S >> t taken
+//     from the top three limb sums: q is floor(S / Q) or one less
+//   x = S - q Q modulo 2^96, in [0, 2 Q): one conditional subtraction
+//   hq = ((x >> t2) mb) >> (bits(B) + 51 - t2), mb = floor(2^(bits(B) + 51) / B) <= 2^52:
+//     floor(x / B) or one less;  lo = x - hq B modulo 2^64, in [0, 2 B): one conditional subtraction.
+// tests/rns_model.py::CrtLean restates this with every intermediate checked against its register
+// width and both estimates checked against the exact quotients.
+// Four adjacent coefficients per thread: 16-byte residue and digit-word accesses, 8-byte accesses
+// of the 16-bit high words.
+struct CrtLean {
+    uint32_t c[NPR_MAX][4];   // (M / p_i) mod Q in 29-bit limbs
+    uint32_t w[NPR_MAX];      // floor(2^58 / p_i)
+    uint32_t cMn[4];          // (-M) mod Q in 29-bit limbs
+    uint32_t hoff;            // (p_last - 1) / 2, the offset k_extprod adds to the last prime's residue
+    uint32_t Qw[3];           // Q in 32-bit words
+    uint32_t B0, B1;          // B = B0 + B1 2^29
+    uint32_t Bw0, Bw1;        // B in 32-bit words
+    uint32_t mq0, mq1;        // floor(2^(t + 72) / Q)
+    uint32_t mb0, mb1;        // floor(2^(bits(B) + 51) / B)
+    uint32_t a;               // top limb sum << a, the next >> 29 - a, the next >> 58 - a
+    uint32_t t2, sB;          // x >> t2;  final shift of the digit estimate
+    uint32_t nl;              // limbs in use (2, 3 or 4); 0 = parameter set outside this kernel's bounds
+};
+
+// (x m) >> 64 for x < 2^63.5 and m = m1 2^32 + m0 with m1 <= 2^20
+__device__ __forceinline__ uint64_t mulhi64_lean(uint64_t x, uint32_t m0, uint32_t m1) {
+    const uint32_t x0 = (uint32_t)x, x1 = (uint32_t)(x >> 32);
+    const uint64_t t1 = (uint64_t)x0 * m1 + __umulhi(x0, m0);
+    const uint64_t t2 = (uint64_t)x1 * m0 + t1;
+    return (uint64_t)x1 * m1 + (t2 >> 32);
+}
+
+template <int NP, int NL>
+__device__ __forceinline__ void crt_lean_one(const uint32_t (&y)[NP], uint64_t lo_o, uint64_t hi_o,
+                                             const CrtLean *__restrict__ K, uint64_t &lo_n,
+                                             uint64_t &hi_n) {
+    // alpha
+    uint64_t acc = 0;
+#pragma unroll
+    for (int q = 0; q < NP; q++) acc += (uint64_t)y[q] * K->w[q];
+    const uint32_t alpha = (uint32_t)(acc >> 58);
+    // limb sums
+    const uint32_t ylast = y[NP - 1] - K->hoff;   // >= 0: the residue proper is non-negative
+    uint64_t L[NL];
+#pragma unroll
+    for (int k = 0; k < NL; k++) {
+        uint64_t l = k == 0 ? lo_o : 0;
+#pragma unroll
+        for (int q = 0; q < NP; q++) l += (uint64_t)(q == NP - 1 ? ylast : y[q]) * K->c[q][k];
+        L[k] = l + (uint64_t)alpha * K->cMn[k];
+    }
+    {   // + hi_old B
+        const uint32_t h0 = (uint32_t)hi_o, h1 = (uint32_t)(hi_o >> 32);
+        L[0] += (uint64_t)h0 * K->B0;
+        L[1] += (uint64_t)h0 * K->B1;
+        L[1] += ((uint64_t)h1 * K->B0) << 3;
+        if constexpr (NL >= 3) L[2] += ((uint64_t)h1 * K->B1) << 3;
+    }
+    // quotient by Q
+    const uint32_t a = K->a;
+    uint64_t X = (L[NL - 1] << a) + (L[NL - 2] >> (29 - a));
+    if constexpr (NL >= 3) X += L[NL - 3] >> (58 - a);
+    const uint64_t q1 = mulhi64_lean(X, K->mq0, K->mq1) >> 8;
+    // S modulo 2^96
+    uint64_t slo = L[0];
+    uint32_t shi = 0;
+    {
+        const uint64_t v = L[1] << 29;
+        slo += v;
+        shi += (uint32_t)(L[1] >> 35) + (slo < v);
+    }
+    if constexpr (NL >= 3) {
+        const uint64_t v = L[2] << 58;
+        slo += v;
+        shi += (uint32_t)(L[2] >> 6) + (slo < v);
+    }
+    if constexpr (NL >= 4) shi += (uint32_t)L[3] << 23;
+    // x = S - q1 Q modulo 2^96
+    uint64_t xlo;
+    uint32_t xhi;
+    {
+        const uint32_t qa = (uint32_t)q1, qb = (uint32_t)(q1 >> 32);
+        const uint64_t m0 = (uint64_t)qa * K->Qw[0];
+        const uint64_t m1 = (uint64_t)qa * K->Qw[1] + (m0 >> 32) + (uint64_t)qb * K->Qw[0];  // modulo 2^64
+        const uint32_t m2 = qa * K->Qw[2] + qb * K->Qw[1] + (uint32_t)(m1 >> 32);
+        const uint64_t mlo = (m1 << 32) | (uint32_t)m0;
+        xlo = slo - mlo;
+        xhi = shi - m2 - (slo < mlo);
+    }
+    {   // in [0, 2 Q): subtract Q when that does not borrow
+        const uint64_t Qlo = ((uint64_t)K->Qw[1] << 32) | K->Qw[0];
+        const uint64_t dlo = xlo - Qlo;
+        const uint32_t bor = xlo < Qlo;
+        const uint32_t dhi = xhi - K->Qw[2] - bor;
+        const bool below = xhi < K->Qw[2] || (xhi == K->Qw[2] && bor);   // x < Q
+        xlo = below ? xlo : dlo;
+        xhi = below ? xhi : dhi;
+    }
+    // digits
+    const uint32_t t2 = K->t2;
+    const uint64_t X2 = t2 ? ((xlo >> t2) | ((uint64_t)xhi << (64 - t2))) : xlo;
+    uint64_t hq = mulhi64_lean(X2, K->mb0, K->mb1) >> K->sB;
+    const uint64_t Bv = ((uint64_t)K->Bw1 << 32) | K->Bw0;
+    uint64_t lo = xlo - hq * Bv;   // modulo 2^64: in [0, 2 B)
+    if (lo >= Bv) { lo -= Bv; hq += 1; }
+    lo_n = lo;
+    hi_n = hq;
+}
+
+template <int NP, int NL>
+__global__ void __launch_bounds__(256)
+k_crt_lean(const uint32_t *__restrict__ yres, uint64_t *__restrict__ dig,
+           const CrtLean *__restrict__ K, uint32_t quads, uint32_t logm) {
+    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= quads) return;
+    const uint32_t M = 1u << logm;
+    const uint32_t i = (4u * t) & (M - 1);  // multiple of 4
+    const uint32_t bc = (4u * t) >> logm;
+    const uint32_t yo = 4u * ((bc * NP << logm) + i);
+    uint4 yv[NP];
+#pragma unroll
+    for (int q = 0; q < NP; q++) yv[q] = ld_off<uint4>(yres, yo + ((uint32_t)(4 * q) << logm));
+    const uint32_t rec = bc * 16u * M;
+    const uint32_t ol = rec + 4u * i, oh = rec + 8u * M + 2u * i;
+    const uint4 l0 = ld_off<uint4>(dig, ol), l1 = ld_off<uint4>(dig, ol + 4u * M);
+    const uint2 h0 = ld_off<uint2>(dig, oh), h1 = ld_off<uint2>(dig, oh + 2u * M);
+    const uint32_t l0w[4] = {l0.x, l0.y, l0.z, l0.w}, l1w[4] = {l1.x, l1.y, l1.z, l1.w};
+    const uint32_t h0w[4] = {h0.x & 0xFFFFu, h0.x >> 16, h0.y & 0xFFFFu, h0.y >> 16};
+    const uint32_t h1w[4] = {h1.x & 0xFFFFu, h1.x >> 16, h1.y & 0xFFFFu, h1.y >> 16};
+    uint64_t nlo[4], nhi[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        uint32_t y[NP];
+#pragma unroll
+        for (int q = 0; q < NP; q++) y[q] = j == 0 ? yv[q].x : j == 1 ? yv[q].y : j == 2 ? yv[q].z : yv[q].w;
+        crt_lean_one<NP, NL>(y, l0w[j] | ((uint64_t)h0w[j] << 32), l1w[j] | ((uint64_t)h1w[j] << 32), K,
+                             nlo[j], nhi[j]);
+    }
+    st_off<uint4>(dig, ol, make_uint4((uint32_t)nlo[0], (uint32_t)nlo[1], (uint32_t)nlo[2], (uint32_t)nlo[3]));
+    st_off<uint4>(dig, ol + 4u * M,
+                  make_uint4((uint32_t)nhi[0], (uint32_t)nhi[1], (uint32_t)nhi[2], (uint32_t)nhi[3]));
+    st_off<uint2>(dig, oh, make_uint2((uint32_t)(nlo[0] >> 32) | ((uint32_t)(nlo[1] >> 32) << 16),
+                                      (uint32_t)(nlo[2] >> 32) | ((uint32_t)(nlo[3] >> 32) << 16)));
+    st_off<uint2>(dig, oh + 2u * M, make_uint2((uint32_t)(nhi[0] >> 32) | ((uint32_t)(nhi[1] >> 32) << 16),
+                                               (uint32_t)(nhi[2] >> 32) | ((uint32_t)(nhi[3] >> 32) << 16)));
 }
 
 // ---- small-batch ("latency") form of the external product --------------------------------------

@@ -267,7 +267,8 @@ class Engine:
         return self._L.sgfhe_build_id().decode()
 
     def timing_read(self, reset=True):
-        st = (ctypes.c_double * 5)()
+        st = (ctypes.c_double * 8)()
         self._chk(self._L.sgfhe_timing_read(self._h, st, int(reset)))
         return dict(extprod_ms=st[0], extprod_samples=int(st[1]), crt_ms=st[2],
-                    crt_samples=int(st[3]), chunk=int(st[4]))
+                    crt_samples=int(st[3]), chunk=int(st[4]), call_ms=st[5], calls=int(st[6]),
+                    call_batch=st[7])

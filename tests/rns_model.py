@@ -410,6 +410,109 @@ class RangeModel:
         return max(bv)
 
 
+# ---- k_crt_lean (kernels.h): the k-loop's CRT + accumulate + flatten in integer arithmetic -------
+# Model of the device algorithm with every intermediate checked against the width of the register
+# it lives in.  Constants as build_constants derives them.
+
+M64 = (1 << 64) - 1
+
+
+def u64(x):
+    assert 0 <= x <= M64, "64-bit overflow on the device"
+    return x
+
+
+class CrtLean:
+    """S = sum_i y'_i c_i + alpha (-M mod Q) + hi_o B + lo_o as 29-bit-limb sums L_k
+    (64-bit multiply-accumulate chains), quotient by Q and by B through 44 / 52-bit reciprocals
+    (estimate = true or true - 1), remainders modulo 2^96 / 2^64, one conditional correction each."""
+
+    def __init__(self, C):
+        self.C = C
+        Q, B, npr = C.Q, C.B, C.npr
+        self.nq, self.nb = Q.bit_length(), B.bit_length()
+        self.NL = NL = max(2, -(-self.nq // 29))
+        self.ok = self.nb >= 13 and NL <= 4 and 29 * (NL - 1) - (self.nq - 29) <= 28
+        if not self.ok:
+            return
+        lim = lambda v: [(v >> (29 * k)) & ((1 << 29) - 1) for k in range(NL)]
+        self.c = [lim(ci) for ci in C.c]
+        cM = C.Mrns % Q
+        plast = C.primes[-1]
+        self.hoff = (plast - 1) // 2
+        self.cMn = lim((Q - cM) % Q)
+        self.w = [(1 << 58) // p for p in C.primes]
+        self.B0, self.B1 = B & ((1 << 29) - 1), B >> 29
+        # quotient by Q: X = S >> t, t = nq - 29; q_est = (X mq) >> 72, mq = floor(2^(t + 72) / Q) < 2^44
+        self.t = self.nq - 29
+        self.a = 29 * (NL - 1) - self.t            # top limb << a, next >> 29 - a, next >> 58 - a
+        assert 0 <= self.a <= 28
+        self.mq = (1 << (self.t + 72)) // Q
+        assert self.mq < (1 << 44)
+        # quotient by B: X2 = x >> t2, t2 = max(0, nq - 63); hq_est = (X2 mb) >> (nb + 51 - t2)
+        self.t2 = max(0, self.nq - 63)
+        self.mb = (1 << (self.nb + 51)) // B
+        assert self.mb <= (1 << 52)
+        self.sB = self.nb + 51 - self.t2 - 64
+        assert self.sB >= 0 and self.t2 <= 31
+
+    @staticmethod
+    def mulhi64(x, m):
+        """(x m) >> 64 for x < 2^64 and m = m1 2^32 + m0 as the device forms it."""
+        x0, x1, m0, m1 = x & 0xFFFFFFFF, x >> 32, m & 0xFFFFFFFF, m >> 32
+        t0 = (x0 * m0) >> 32
+        t1 = u64(x0 * m1 + t0)
+        t2 = u64(x1 * m0 + t1)
+        return u64(x1 * m1 + (t2 >> 32))
+
+    def digits(self, y, lo_o, hi_o):
+        C, NL = self.C, self.NL
+        acc = 0
+        for i in range(C.npr):
+            acc = u64(acc + y[i] * self.w[i])
+        alpha = acc >> 58
+        L = [0] * NL
+        L[0] = lo_o
+        yl = list(y)
+        yl[-1] -= self.hoff                  # takes H' out again
+        assert yl[-1] >= 0
+        for k in range(NL):
+            for i in range(C.npr):
+                L[k] = u64(L[k] + yl[i] * self.c[i][k])
+            L[k] = u64(L[k] + alpha * self.cMn[k])
+        h0, h1 = hi_o & 0xFFFFFFFF, hi_o >> 32
+        L[0] = u64(L[0] + h0 * self.B0)
+        L[1] = u64(L[1] + h0 * self.B1)
+        L[1] = u64(L[1] + (u64(h1 * self.B0) << 3))
+        if NL >= 3:
+            L[2] = u64(L[2] + (u64(h1 * self.B1) << 3))
+        else:
+            assert h1 * self.B1 == 0
+        S = sum(L[k] << (29 * k) for k in range(NL))
+        # quotient estimate from the top limbs
+        X = u64(L[NL - 1] << self.a) + (L[NL - 2] >> (29 - self.a))
+        if NL >= 3:
+            X += L[NL - 3] >> (58 - self.a)
+        X = u64(X)
+        q = self.mulhi64(X, self.mq) >> 8
+        assert S // C.Q - 1 <= q <= S // C.Q, "quotient estimate"
+        # x = S - q Q modulo 2^96, in [0, 2 Q)
+        x = (S - q * C.Q) & ((1 << 96) - 1)
+        assert x == S - q * C.Q and x < 2 * C.Q
+        if x >= C.Q:
+            x -= C.Q
+        X2 = x >> self.t2
+        assert X2 < (1 << 63)
+        hq = self.mulhi64(X2, self.mb) >> self.sB
+        assert x // C.B - 1 <= hq <= x // C.B, "digit estimate"
+        lo = (x - hq * C.B) & M64
+        assert lo == x - hq * C.B and lo < 2 * C.B
+        if lo >= C.B:
+            lo -= C.B
+            hq += 1
+        return lo, hq, alpha
+
+
 def ntt_reference(poly, psi, p):
     """Evaluations of poly at psi^(2 bitrev(k) + 1), k = 0..m-1: the slot order of the merged
     Cooley-Tukey transform."""
@@ -518,6 +621,7 @@ class EngineModel:
         for pi in range(C.npr):
             f = np.float32(f + np.float32(y[pi]) * np.float32(np.float32(1.0) / np.float32(C.primes[pi])))
         alpha = int(f)
+        self.last_alpha = alpha
         return (C.T[alpha] + sum(y[pi] * C.c[pi] for pi in range(C.npr)) + x_old) % C.Q
 
     def random_digits(self, xn, key, ctr):

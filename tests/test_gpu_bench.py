@@ -26,7 +26,7 @@ def _run(*extra):
 
 
 def test_bench_line_contract():
-    d = _run()
+    d = _run("--chunk", "64")                       # four chunks: two lanes, as at the default workload
     assert d["metric"] == "bootstraps/sec" and d["unit"] == "bootstraps/sec"
     assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1
     assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
@@ -39,11 +39,15 @@ def test_bench_line_contract():
     # `frac` is the whole iteration (both launches of the k-loop), the dominant kernel alone is
     # under kernels.k_extprod; whole_job_frac is the driver-timed figure
     k = r["kernels"]
-    assert k["k_extprod"]["launch_samples"] > 0 and k["k_extprod"]["launch_ms"] > 0
-    assert k["k_crt_acc2"]["launch_samples"] > 0 and k["k_crt_acc2"]["launch_ms"] > 0
-    assert abs(r["launch_ms"] - k["k_extprod"]["launch_ms"] - k["k_crt_acc2"]["launch_ms"]) < 1e-9
+    for name in ("k_extprod", "k_crt_lean"):
+        assert k[name]["launch_samples"] > 0 and k[name]["launch_ms"] > 0
+        assert k[name]["launch_ms_alone"] > 0 and k[name]["kernel_frac"] > 0
+    # the iteration time is the device wall time of a step / chunk-iterations in it, not a sum of
+    # kernel durations (with two lanes the kernels of two chunks overlap)
+    assert d["config"]["lanes"] == 2 and "overlap" in r["kernel"]
+    assert k["k_extprod"]["launch_ms_is"].startswith("overlapped")
+    assert r["launch_ms"] > 0
     assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["launch_ms"] * 1e-3) / 1e9) < 1e-6 * r["achieved"]
-    assert k["k_extprod"]["kernel_frac"] > r["frac"] > 0
     assert r["whole_job_frac"] > 0
     assert "HIP events" in r["launch_ms_source"]
     # the committed counters are those of Params(1024): not quoted for another configuration
@@ -62,6 +66,10 @@ def test_bench_line_contract():
 
 
 def test_bench_flags():
-    d = _run("--no-cpu-baseline", "--no-host-io", "--flatten", "random")
+    d = _run("--no-cpu-baseline", "--no-host-io", "--flatten", "random", "--lanes", "1", "--chunk", "64")
     assert "cpu_baseline" not in d and "host_io" not in d
     assert "random flatten" in d["config"]["workload"] and d["value"] > 0
+    assert d["config"]["lanes"] == 1 and d["config"]["chunk"] == 64
+    k = d["roofline"]["kernels"]
+    assert k["k_extprod"]["launch_ms_is"] == "alone on the device"
+    assert k["k_extprod"]["launch_ms_alone"] == k["k_extprod"]["launch_ms"]

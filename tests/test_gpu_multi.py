@@ -128,7 +128,14 @@ def _rank_of_eight(rank, world, port, tmpdir, batch, wave):
     import torch
     import torch.distributed as dist
     import sgfhe_jl_amd as S
+    # A rank must not open the GPU (8 ranks + their GPU children would exceed the guard):
+    # dist.barrier() initialises the HIP runtime even on a gloo group, so the barriers here are
+    # all-reduces of a CPU tensor, and torch.cuda reports no device inside a rank.
+    torch.cuda.is_available = lambda: False
     dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    def cpu_barrier():
+        dist.all_reduce(torch.zeros(1))
 
     def child(mode, blob_path, out_path):
         subprocess.run([sys.executable, "-c", _GPU_CHILD, root, mode, blob_path, str(rank), str(world),
@@ -150,10 +157,10 @@ def _rank_of_eight(rank, world, port, tmpdir, batch, wave):
     for w in range((world + wave - 1) // wave):
         if rank // wave == w:
             child("shard", mine, out_path)
-        dist.barrier()
+        cpu_barrier()
     full = S.distributed.gather_outputs(np.load(out_path), batch, world)
     np.save(os.path.join(tmpdir, "full_%d.npy" % rank), full)
-    dist.barrier()
+    cpu_barrier()
     dist.destroy_process_group()
 
 

@@ -221,3 +221,54 @@ def test_exactness_bound_reference_params():
         p = BO.Params.make(n)
         assert RM.Consts(p.n, p.m, p.Q, p.B, p.DQ_tilde).npr == det
         assert RM.select_npr(p.m.bit_length() - 1, p.B, p.Q, random_flatten=True) == rnd
+
+
+def _lean_cases():
+    import bench
+    import sgfhe_jl_amd as S
+    for name in ("params1024", "params512", "params64", "synth64", "rns2", "params2048"):
+        p = bench.make_params(S, name)
+        yield name, (p.n, p.m, p.Q, p.B, p.DQ_tilde)
+    Q = BO.find_modulus(2 * 64, 1 << 50)
+    yield "synthetic m = 64", (8, 64, Q, 1 << 26, Q // 8)
+    yield "external-product ring", (8, 64, (1 << 60) - 1, 1 << 30, ((1 << 60) - 1) // 8)
+
+
+@pytest.mark.parametrize("name,args", list(_lean_cases()), ids=[c[0] for c in _lean_cases()])
+def test_crt_lean_model(name, args):
+    """k_crt_lean's integer algorithm (29-bit limb sums, reciprocal quotient estimates, one
+    conditional correction each) on every parameter set of BASELINE.json and of the tests: equal to
+    the exact (x_old + D) mod Q and its base-B digits, with every intermediate inside its register
+    width and both estimates within one of the exact quotients (asserted inside RM.CrtLean).  The
+    residues are built as k_extprod hands them over: non-negative representatives below 5.7 p,
+    plus (p - 1) / 2 on the last prime; D runs to the edge of the exactness bound, x_old and
+    x_new to the edges of [0, Q) and of the digit boundaries."""
+    import random
+    rnd = random.Random(hash(name) & 0xFFFF)
+    C = RM.Consts(*args)
+    L = RM.CrtLean(C)
+    assert L.ok
+    E = RM.EngineModel.__new__(RM.EngineModel)
+    E.C = C
+    bound = min(int(0.4 * C.Mrns), 2 * C.M * C.B * C.Q)
+    inv = [pow(C.Mrns // p, -1, p) for p in C.primes]
+    for it in range(4000):
+        D = rnd.randint(-bound, bound)
+        if it % 11 == 0:
+            D = rnd.choice([bound, -bound, 0, 1, -1])
+        y = []
+        for i, p in enumerate(C.primes):
+            r = D * inv[i] % p
+            r += rnd.randint(0, 5 if r < 0.7 * p else 4) * p
+            y.append(r + C.pk[i]["hoff"])
+            assert r < 5.7 * p
+        xo = rnd.randrange(C.Q)
+        if it % 7 == 0:
+            xo = rnd.choice([0, C.Q - 1, C.B - 1, C.B % C.Q, (C.Q - C.B) % C.Q])
+        if it % 13 == 0:        # x_new at 0, Q - 1 and at digit boundaries
+            xo = (-D + rnd.choice([0, 1, -1, C.B, C.B - 1])) % C.Q
+        lo, hq, alpha = L.digits(y, xo % C.B, xo // C.B)
+        xn = E.crt_value(y, xo)                       # the float-alpha / table form of k_crt_acc
+        assert alpha == E.last_alpha
+        assert xn == (xo + D) % C.Q
+        assert (lo, hq) == (xn % C.B, xn // C.B)

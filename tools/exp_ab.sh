@@ -4,9 +4,8 @@
 #   gpurun -- 'bash tools/exp_ab.sh > gpurun_out/exp_ab.txt 2>&1'
 # (boxes differ by 2-3 %: only numbers from one call are comparable; tools/abl/ is git-ignored)
 B="python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-host-io"
-P='import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d["roofline"]; print("RESULT", sys.argv[1], round(d["value"],1), "ext_us", round(r["launch_ms"]*1e3,1), "crt_us", round(r["pair_launch_ms"]*1e3,1))'
 for i in 1 2; do
-SGFHE_HIP_LIB=$PWD/tools/abl/lib_base.so $B | python -c "$P" base_$i
-$B | python -c "$P" new_$i
+SGFHE_HIP_LIB=$PWD/tools/abl/lib_base.so $B | python tools/result_line.py base_$i
+$B | python tools/result_line.py new_$i
 done
 python -m pytest tests -q -m gpu -x 2>&1 | tail -3

@@ -3,10 +3,9 @@
 B="python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-host-io"
 # variant library (build here, it travels with gpurun; tools/abl/ is git-ignored):
 #   mkdir -p tools/abl && (cd sgfhe.jl_amd/csrc && hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DSGFHE_ACC0_32 -shared -o ../../tools/abl/lib_acc32.so engine.hip)
-P='import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d["roofline"]; print("RESULT", sys.argv[1], round(d["value"],1), "ext_us", round(r["launch_ms"]*1e3,1), "crt_us", round(r["pair_launch_ms"]*1e3,1))'
 for i in 1 2; do
-$B --lanes 1 | python -c "$P" acc64_lanes1_$i
-$B --lanes 2 | python -c "$P" acc64_lanes2_$i
-SGFHE_HIP_LIB=$PWD/tools/abl/lib_acc32.so $B --lanes 1 | python -c "$P" acc32_lanes1_$i
-SGFHE_HIP_LIB=$PWD/tools/abl/lib_acc32.so $B --lanes 2 | python -c "$P" acc32_lanes2_$i
+$B --lanes 1 | python tools/result_line.py acc64_lanes1_$i
+$B --lanes 2 | python tools/result_line.py acc64_lanes2_$i
+SGFHE_HIP_LIB=$PWD/tools/abl/lib_acc32.so $B --lanes 1 | python tools/result_line.py acc32_lanes1_$i
+SGFHE_HIP_LIB=$PWD/tools/abl/lib_acc32.so $B --lanes 2 | python tools/result_line.py acc32_lanes2_$i
 done

@@ -2,10 +2,9 @@
 # Same-box A/B: base (lanes 1, chunk 512), base (lanes 2, chunk 256), and the timing-only
 # -DSGFHE_ABL_CRT_MEMONLY build in both schedules (wrong results, timing only).
 B="python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-host-io"
-P='import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d["roofline"]["kernels"]; print("RESULT", sys.argv[1], round(d["value"],1), "ext_us", round(r["k_extprod"]["launch_ms"]*1e3,1), "crt_us", round(r["k_crt_acc2"]["launch_ms"]*1e3,1))'
 for i in 1 2; do
-$B | python -c "$P" base_l1_c512_$i
-$B --lanes 2 --chunk 256 | python -c "$P" base_l2_c256_$i
-SGFHE_HIP_LIB=$PWD/tools/abl/lib_crt_memonly.so $B | python -c "$P" memonly_l1_c512_$i
-SGFHE_HIP_LIB=$PWD/tools/abl/lib_crt_memonly.so $B --lanes 2 --chunk 256 | python -c "$P" memonly_l2_c256_$i
+$B | python tools/result_line.py base_l1_c512_$i
+$B --lanes 2 --chunk 256 | python tools/result_line.py base_l2_c256_$i
+SGFHE_HIP_LIB=$PWD/tools/abl/lib_crt_memonly.so $B | python tools/result_line.py memonly_l1_c512_$i
+SGFHE_HIP_LIB=$PWD/tools/abl/lib_crt_memonly.so $B --lanes 2 --chunk 256 | python tools/result_line.py memonly_l2_c256_$i
 done

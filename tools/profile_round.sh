@@ -5,13 +5,17 @@
 #   usage: tools/profile_round.sh TAG [CHUNK]
 set -e
 TAG=${1:-rXX}
-CHUNK=${2:-512}   # one chunk of the engine default size at Params(1024)
+CHUNK=${2:-256}   # one chunk of the engine default size at Params(1024) (two lanes of 256)
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-ONE="--batch $CHUNK --steps 1 --warmup 0 --no-cpu-baseline --no-host-io"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o run -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-host-io > $OUT/bench_stats.log 2>&1
+# the default schedule: two lanes, the kernels of the two chunks overlap
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o run -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-host-io --no-isolated > $OUT/bench_stats.log 2>&1
 echo "stats done"
+# the same chunks one after the other: every kernel alone on the device
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_alone -o run -- python3 bench.py --lanes 1 --chunk $CHUNK --steps 1 --warmup 0 --no-cpu-baseline --no-host-io > $OUT/bench_stats_alone.log 2>&1
+echo "stats (one lane) done"
+ONE="--lanes 1 --chunk $CHUNK --batch $CHUNK --steps 1 --warmup 0 --no-cpu-baseline --no-host-io"
 for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_$C -o run -- python3 bench.py $ONE > $OUT/pmc_$C.log 2>&1
   echo "$C done"

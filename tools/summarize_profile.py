@@ -20,7 +20,7 @@ def counter_avgs(d):
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
             name = r["Kernel_Name"]
-            for k in ("k_extprod", "k_crt_acc", "k_init", "k_final"):
+            for k in ("k_extprod", "k_crt_lean", "k_crt_acc", "k_init", "k_final"):
                 if k in name:
                     res[k][r["Grid_Size"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
     out = {}
@@ -47,7 +47,7 @@ def main():
             open(os.path.join(prof, "%s_bench_under_rocprof.json" % tag), "w").write(lines[-1])
             bench_line = json.loads(lines[-1])
     out = {"note": "rocprofv3 --pmc passes (one counter group per run, --kernel-trace only), "
-                   "bench.py --batch %d --steps 1 --warmup 0 = one chunk of %d bootstraps, " % (chunk, chunk) +
+                   "bench.py --lanes 1 --chunk %d --batch %d --steps 1 --warmup 0 = one chunk of %d bootstraps, " % (chunk, chunk, chunk) +
                    "Params(1024); per-launch averages. FETCH_SIZE / WRITE_SIZE are reported in KB; "
                    "on gfx950 FETCH_SIZE counts half the bytes of wide coalesced reads "
                    "(MI355X_MICROARCH.md, HBM section): traffic = (2 FETCH_SIZE + WRITE_SIZE) * 1024 B.",
@@ -57,14 +57,36 @@ def main():
     # bench.py quotes these numbers only beside a library with this sgfhe_build_id(): the id the
     # profiled run itself reported, else the hash of the sources here
     out["build_id"] = (bench_line or {}).get("config", {}).get("build_id") or sgfhe_jl_amd.source_hash()
-    if stats:   # rocprofv3 --kernel-trace --stats averages of the two k-loop kernels (the authority
-                # for launch durations; the HIP-event samples of bench.py over-read by a few per cent)
+    def kernel_avgs(path):
         avg = {}
-        for r in csv.DictReader(open(stats[0])):
-            for k in ("k_extprod", "k_crt_acc2"):
+        for r in csv.DictReader(open(path)):
+            for k in ("k_extprod", "k_crt_lean"):
                 if "::" + k + "<" in r["Name"]:
                     avg[k] = float(r["AverageNs"]) / 1e3
-        out["rocprof_avg_us"] = avg
+        return avg
+    if stats:   # rocprofv3 --kernel-trace --stats averages of the two k-loop kernels in the default
+                # schedule (two lanes: durations under co-execution)
+        out["rocprof_avg_us"] = kernel_avgs(stats[0])
+        # device wall time of one k-loop iteration of one chunk, from the dispatch time stamps of
+        # the same trace: span of the k-loop's dispatches / chunk-iterations in it
+        trace = glob.glob(os.path.join(src, "stats", "**", "*kernel_trace.csv"), recursive=True)
+        if trace and bench_line:
+            t0, t1, n_ext = None, None, 0
+            for r in csv.DictReader(open(trace[0])):
+                name = r.get("Kernel_Name", "")
+                if "k_extprod" in name or "k_crt_lean" in name:
+                    a, b = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+                    t0 = a if t0 is None else min(t0, a)
+                    t1 = b if t1 is None else max(t1, b)
+                    n_ext += "k_extprod" in name
+            if n_ext:
+                out["rocprof_iter_us"] = (t1 - t0) / 1e3 / n_ext
+                out["rocprof_iter_note"] = ("(last end - first start) of the %d k-loop dispatches of the "
+                                            "profiled run / k_extprod launches" % (2 * n_ext))
+    alone = glob.glob(os.path.join(src, "stats_alone", "**", "*kernel_stats.csv"), recursive=True)
+    if alone:   # the same chunks on one lane: each kernel alone on the device
+        out["rocprof_alone_avg_us"] = kernel_avgs(alone[0])
+        shutil.copy(alone[0], os.path.join(prof, "%s_kernel_stats_one_lane.csv" % tag))
     try:
         out["valu_mix"] = json.loads(subprocess.check_output(
             [sys.executable, os.path.join(root, "tools", "valu_mix.py")]).decode())
