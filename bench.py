@@ -158,17 +158,19 @@ def cpu_baseline(p, sk, key_seed, cap, seconds_target=8.0):
     what the Julia reference executes), one independent bootstrap per thread (OpenMP over the
     batch, the sharding the GPUs use), over a k-loop truncated to about `seconds_target` seconds
     and scaled to the full loop; `opt` = the same arithmetic in the GPU path's algebra (key in the
-    NTT domain, 4 + 2 NTTs per iteration; bit-identical).  Timed twice: on every core this process
-    may use (the box's CPU rate: the headline `value`) and on one GPU's share of them (an eighth:
-    `share`).  Test infrastructure used as a reported baseline only.  The key is the oracle's own
+    NTT domain, 4 + 2 NTTs per iteration; bit-identical).  Timed on every core this process may
+    use -- the affinity mask, or the cgroup CPU quota where that is smaller (the GPU boxes of the
+    pool show 256 cores and a quota of 16: 32 threads measured no faster than 16) -- as the
+    headline `value`, and on one GPU's share of the affinity mask (an eighth: `share`) when that
+    is a different number.  Test infrastructure used as a reported baseline only.  The key is the oracle's own
     generation from the same seed (the same key as on the device)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle_c
     avail, quota = _cpu_budget()
     full = max(1, min(cap, avail) if cap else avail)
-    if quota:
+    if quota:   # a cgroup CPU quota below the affinity mask: more threads than that add nothing
         full = max(1, min(full, int(quota + 0.5)))
-    share = max(1, avail // 8)
+    share = min(full, max(1, avail // 8))
     o = oracle_c.Oracle.from_params(p)
     key = o.bootstrap_key(sk, key_seed)
     khat = o.key_transform(key, threads=full) if o.uses_ntt else None

@@ -119,6 +119,12 @@ int32_t sgfhe_set_lanes(sgfhe_ctx *ctx, uint32_t lanes);
  * bit.  They decrypt like the reference's but are not bit-comparable with it (Julia's
  * MersenneTwister stream cannot be reproduced).  Applies to later bootstrap / pack calls; needs a
  * ctx whose RNS primes cover it (SGFHE_CTX_RANDOM_FLATTEN), else SGFHE_ERR_UNSUPPORTED.
+ * Every Params(n) the reference can build is covered, n = 64 ... 2048 (B up to 2^47: above 2^46
+ * the stored digits take a third plane of the digit record).
+ * The stream is a statistical one: all perturbations of a call are a function of the 64-bit seed
+ * through Philox4x32-10, which is not a cryptographic generator (the reference draws every v_i
+ * from the caller's rng, src/utils.jl:229).  Key material does not come from this stream:
+ * sgfhe_bkey_generate uses ChaCha20 with a 32-byte seed.
  */
 int32_t sgfhe_set_random_flatten(sgfhe_ctx *ctx, int enable, uint64_t seed);
 

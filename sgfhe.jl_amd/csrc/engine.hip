@@ -114,6 +114,11 @@ struct sgfhe_ctx {
     bool use_lean = true;     // SGFHE_CRT_LEAN=0 in the environment: keep k_crt_acc2 (A/B measurements)
     uint32_t small_max = 24;  // chunks of at most this many bootstraps take the small-batch form
                               // (measured crossover at Params(1024): 24 -> 32.3 vs 40.9 ms, 32 -> 44.0 vs 42.3 ms)
+    // staging buffers of the host-pointer entry point (sgfhe_bootstrap_batch: the drop-in signature of
+    // fhe.jl:608-610, usually called with one gate): grown on demand and kept, so that a call does
+    // not pay a hipMalloc / hipFree pair (hipFree synchronises the device)
+    uint64_t *io_in = nullptr, *io_out = nullptr;
+    size_t io_in_words = 0, io_out_words = 0;
     // timing
     bool timing = false;
     struct EvTriple { hipEvent_t e0, e1, e2; };  // ext = e0 -> e1, crt = e1 -> e2
@@ -173,11 +178,18 @@ int32_t launch_extprod_t(sgfhe_ctx *c, const sgfhe_ctx::Lane &L, const int32_t *
     if (!(c->attr_done & ATTR_EXTPROD)) {
         HIPCHK(c, hipFuncSetAttribute((const void *)k_extprod<LOGM, ext_loge<LOGM>()>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIPCHK(c, hipFuncSetAttribute((const void *)k_extprod<LOGM, ext_loge<LOGM>(), true>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         c->attr_done |= ATTR_EXTPROD;
     }
-    hipLaunchKernelGGL((k_extprod<LOGM, ext_loge<LOGM>()>), dim3(cpad * c->npr),
-                       dim3(NttGeom<LOGM, ext_loge<LOGM>()>::T), lds, st, L.dig,
-                       keyk, L.yres, L.ua, c->d_primes, k, c->n, mode);
+    if (mode & MODE_WIDE)   // digit planes with a third plane (randomised flatten, B >= 2^46)
+        hipLaunchKernelGGL((k_extprod<LOGM, ext_loge<LOGM>(), true>), dim3(cpad * c->npr),
+                           dim3(NttGeom<LOGM, ext_loge<LOGM>()>::T), lds, st, L.dig,
+                           keyk, L.yres, L.ua, c->d_primes, k, c->n, mode);
+    else
+        hipLaunchKernelGGL((k_extprod<LOGM, ext_loge<LOGM>()>), dim3(cpad * c->npr),
+                           dim3(NttGeom<LOGM, ext_loge<LOGM>()>::T), lds, st, L.dig,
+                           keyk, L.yres, L.ua, c->d_primes, k, c->n, mode);
     HIPCHK(c, hipGetLastError());
     return SGFHE_OK;
 }
@@ -201,12 +213,18 @@ int32_t launch_small_t(sgfhe_ctx *c, const sgfhe_ctx::Lane &L, const int32_t *ke
     if (!(c->attr_done & ATTR_SMALL)) {
         HIPCHK(c, hipFuncSetAttribute((const void *)k_fwd_phase<LOGM, LE>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIPCHK(c, hipFuncSetAttribute((const void *)k_fwd_phase<LOGM, LE, true>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIPCHK(c, hipFuncSetAttribute((const void *)k_inv_column<LOGM, LE>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         c->attr_done |= ATTR_SMALL;
     }
-    hipLaunchKernelGGL((k_fwd_phase<LOGM, LE>), dim3(cpad * c->npr * 4), dim3(TH), lds, st, L.dig,
-                       keyk, L.zpart, c->d_primes, mode);
+    if (mode & MODE_WIDE)
+        hipLaunchKernelGGL((k_fwd_phase<LOGM, LE, true>), dim3(cpad * c->npr * 4), dim3(TH), lds, st, L.dig,
+                           keyk, L.zpart, c->d_primes, mode);
+    else
+        hipLaunchKernelGGL((k_fwd_phase<LOGM, LE>), dim3(cpad * c->npr * 4), dim3(TH), lds, st, L.dig,
+                           keyk, L.zpart, c->d_primes, mode);
     hipLaunchKernelGGL((k_inv_column<LOGM, LE>), dim3(cpad * c->npr * 2), dim3(TH), lds, st, L.zpart,
                        L.yres, L.ua, c->d_primes, k, c->n);
     HIPCHK(c, hipGetLastError());
@@ -482,7 +500,7 @@ int32_t bootstrap_device(sgfhe_ctx *c, const uint64_t *a1, const uint64_t *b1, c
             return fail(c, SGFHE_ERR_INVALID_ARG, "SGFHE_FLAG_RAW_RNS2: no RNS2 moduli (upload the key with sgfhe_bkey_upload_rns2)");
     }
     const bool two_lanes = c->lanes == 2 && batch > chunk;
-    const uint32_t mode = c->rnd ? MODE_RANDOM : 0u;
+    const uint32_t mode = c->rnd ? (MODE_RANDOM | ((c->B >> 46) ? MODE_WIDE : 0u)) : 0u;
     const uint32_t call = c->rnd ? c->rnd_call++ : 0u;
     c->last_call = call;
     {   // work buffers for the largest chunk of this call, before anything of it is queued
@@ -535,7 +553,7 @@ int32_t bootstrap_device(sgfhe_ctx *c, const uint64_t *a1, const uint64_t *b1, c
             if (dig_out) {
                 const uint32_t t2 = J.cb * 2 * M;
                 hipLaunchKernelGGL(k_dump_digits, dim3((t2 + 255) / 256), dim3(256), 0, J.st, J.L->dig,
-                                   dig_out + J.c0 * 4 * M, t2, (uint32_t)c->logm);
+                                   dig_out + J.c0 * 4 * M, t2, (uint32_t)c->logm, mode);
                 HIPCHK(c, hipGetLastError());
             }
             if (out) {
@@ -638,7 +656,9 @@ int32_t build_constants(sgfhe_ctx *c) {
         // |u| <= 2 B in that mode: the exactness bound needs 4 x more head-room.  Its reductions
         // (random_digits, acc_from_digits, crt_reduce) divide values up to about 4 B^2 by Q with a
         // double-precision quotient estimate, exact while the quotient stays below 2^50.
-        c->rnd_ok = (log_need + 2.0 <= log_have) && (B >> 46) == 0 &&
+        // (stored digits reach 4 B: above 2^48 they take the third plane of the digit record,
+        // MODE_WIDE; B < 2^47 is checked at ctx creation)
+        c->rnd_ok = (log_need + 2.0 <= log_have) &&
                     (2.0 * u128_log2(B) + 2.0 - u128_log2(Q) < 50.0);
     }
     cc.DQ = ld128(c->par.DQ_tilde) % Q;
@@ -948,6 +968,8 @@ int32_t sgfhe_ctx_destroy(sgfhe_ctx *c) {
     if (c->d_primes) (void)hipFree(c->d_primes);
     if (c->d_crt) (void)hipFree(c->d_crt);
     if (c->d_lean) (void)hipFree(c->d_lean);
+    if (c->io_in) (void)hipFree(c->io_in);
+    if (c->io_out) (void)hipFree(c->io_out);
     if (c->d_bad) (void)hipFree(c->d_bad);
     if (c->d_tw) (void)hipFree(c->d_tw);
     if (c->d_key) (void)hipFree(c->d_key);
@@ -974,7 +996,7 @@ int32_t sgfhe_set_random_flatten(sgfhe_ctx *c, int enable, uint64_t seed) {
     SGFHE_LOCK(c);
     if (enable && !c->rnd_ok)
         return fail(c, SGFHE_ERR_UNSUPPORTED,
-                    "randomised flatten: 20 m B Q exceeds the product of this ctx's RNS primes (or B >= 2^46); "
+                    "randomised flatten: 20 m B Q exceeds the product of this ctx's RNS primes (or B^2 > 2^48 Q); "
                     "create the ctx with sgfhe_ctx_create_ex(..., SGFHE_CTX_RANDOM_FLATTEN, ...)");
     c->rnd = enable != 0;
     c->rnd_seed = seed;
@@ -1245,13 +1267,27 @@ static int32_t bootstrap_host(sgfhe_ctx *c, const uint64_t *a1, const uint64_t *
     ulonglong2 *d_acc = nullptr;
     const size_t dig_words = batch * 4 * (size_t)c->M;
     const size_t in_words = 2 * batch * (n + 1);
-    HIPCHK(c, hipMalloc(&d_in, in_words * 8));
+    if (in_words > c->io_in_words) {
+        if (c->io_in) (void)hipFree(c->io_in);
+        c->io_in = nullptr;
+        c->io_in_words = 0;
+        HIPCHK(c, hipMalloc(&c->io_in, in_words * 8));
+        c->io_in_words = in_words;
+    }
+    if (out && out_words > c->io_out_words) {
+        if (c->io_out) (void)hipFree(c->io_out);
+        c->io_out = nullptr;
+        c->io_out_words = 0;
+        HIPCHK(c, hipMalloc(&c->io_out, out_words * 8));
+        c->io_out_words = out_words;
+    }
+    d_in = c->io_in;
+    if (out) d_out = c->io_out;
     int32_t rc = SGFHE_OK;
     hipError_t e = hipSuccess;
     uint64_t *d_a1 = d_in, *d_a2 = d_in + batch * n, *d_b1 = d_in + 2 * batch * n,
              *d_b2 = d_b1 + batch;
     do {
-        if (out && (e = hipMalloc(&d_out, out_words * 8)) != hipSuccess) break;
         if (acc && (e = hipMalloc(&d_acc, acc_words * 8)) != hipSuccess) break;
         if (digs && (e = hipMalloc(&d_dig, dig_words * 8)) != hipSuccess) break;
         if ((e = hipMemcpyAsync(d_a1, a1, batch * n * 8, hipMemcpyHostToDevice, c->stream))) break;
@@ -1270,9 +1306,7 @@ static int32_t bootstrap_host(sgfhe_ctx *c, const uint64_t *a1, const uint64_t *
         e = hipStreamSynchronize(c->stream);
     } while (0);
     if (e != hipSuccess && rc == SGFHE_OK) rc = fail(c, SGFHE_ERR_HIP, hipGetErrorString(e));
-    (void)hipFree(d_in);
-    if (d_out) (void)hipFree(d_out);
-    if (d_acc) (void)hipFree(d_acc);
+    if (d_acc) (void)hipFree(d_acc);   // debug hooks only
     if (d_dig) (void)hipFree(d_dig);
     return rc;
 }
@@ -1326,7 +1360,7 @@ int32_t sgfhe_debug_flatten(sgfhe_ctx *c, const uint64_t *values, uint64_t *digi
         hipLaunchKernelGGL(k_flatten_canon, dim3((2 * M + 255) / 256), dim3(256), 0, c->stream, d_in,
                            L.dig, c->d_crt, 2 * M, (uint32_t)c->logm);
         hipLaunchKernelGGL(k_dump_digits, dim3((2 * M + 255) / 256), dim3(256), 0, c->stream, L.dig,
-                           d_out, 2 * M, (uint32_t)c->logm);
+                           d_out, 2 * M, (uint32_t)c->logm, 0u);
         if ((e = hipGetLastError())) break;
         if ((e = hipMemcpyAsync(digits, d_out, (size_t)4 * M * 8, hipMemcpyDeviceToHost, c->stream))) break;
         e = hipStreamSynchronize(c->stream);

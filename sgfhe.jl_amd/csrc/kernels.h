@@ -79,8 +79,10 @@ enum : uint32_t {
     MODE_PLAIN = 1u,  // k_extprod: no (x^j - 1) factor (external_product debug hook)
     MODE_NOACC = 2u,  // k_crt_acc: do not add the previous accumulator
     MODE_CANON = 4u,  // k_crt_acc: write canonical residues instead of digits
-    MODE_RANDOM = 16u // randomised flatten (rng != nothing, utils.jl:198-241): digits e_i hold
+    MODE_RANDOM = 16u,// randomised flatten (rng != nothing, utils.jl:198-241): digits e_i hold
                       // u_i + s + xmax, u_i in (-2B, 2B]
+    MODE_WIDE = 32u   // with MODE_RANDOM and B >= 2^46: stored digits reach 4 B >= 2^48, bits 48..55
+                      // live in the record's third plane (Params(2048): B = 35 * 2^41)
 };
 
 // ---- small 128-bit helpers -----------------------------------------------------------------
@@ -108,6 +110,7 @@ __device__ __forceinline__ u128 mod_wide(u128 x, u128 d, double inv, uint64_t *q
 // Per (bootstrap, c) a record of 16 m bytes (the size of the canonical residues it replaces):
 //   [lo words: digit 0 | digit 1] 2 m x uint32      bits 0..31 of the digits
 //   [hi words: digit 0 | digit 1] 2 m x uint16      bits 32..47          (12 m bytes in use)
+//   [top bytes: digit 0 | digit 1] 2 m x uint8      bits 48..55, MODE_WIDE only (14 m bytes in use)
 // digit 0 = lo, digit 1 = hi of x' for acc_a (c = 0) and acc_b (c = 1); every stored digit is
 // below 2^48 (B < 2^46 is checked at ctx creation; the randomised mode stores up to 4 B).  Plane
 // p = 2 c + digit is the p-th row of u = [a_lo, a_hi, b_lo, b_hi] (fhe.jl:524-526) and multiplies
@@ -139,6 +142,9 @@ __device__ __forceinline__ uint32_t buf_ld_u32(BufRsrc r, uint32_t voff, uint32_
 __device__ __forceinline__ uint32_t buf_ld_u16(BufRsrc r, uint32_t voff, uint32_t soff) {
     return (uint16_t)__builtin_amdgcn_raw_buffer_load_b16(r, (int)voff, (int)soff, 0);
 }
+__device__ __forceinline__ uint32_t buf_ld_u8(BufRsrc r, uint32_t voff, uint32_t soff) {
+    return (uint8_t)__builtin_amdgcn_raw_buffer_load_b8(r, (int)voff, (int)soff, 0);
+}
 __device__ __forceinline__ int4 buf_ld_i4(BufRsrc r, uint32_t voff, uint32_t soff) {
     typedef unsigned int v4u __attribute__((ext_vector_type(4)));
     const v4u v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0);
@@ -164,21 +170,32 @@ __device__ __forceinline__ const uint16_t *digit_hi_plane(const uint64_t *dig, s
     return reinterpret_cast<const uint16_t *>(dig + bc * 2 * M + M);
 }
 __device__ __forceinline__ ulonglong2 load_digits(const uint64_t *__restrict__ dig, size_t bc,
-                                                  uint32_t i, uint32_t M) {
+                                                  uint32_t i, uint32_t M, bool wide = false) {
     const uint32_t rec = (uint32_t)bc * 16u * M;           // byte offset of the record
     const uint32_t lo = rec + 4u * i, hi = rec + 8u * M + 2u * i;
-    return make_ulonglong2(
+    ulonglong2 d = make_ulonglong2(
         ld_off<uint32_t>(dig, lo) | ((uint64_t)ld_off<uint16_t>(dig, hi) << 32),
         ld_off<uint32_t>(dig, lo + 4u * M) | ((uint64_t)ld_off<uint16_t>(dig, hi + 2u * M) << 32));
+    if (wide) {
+        const uint32_t top = rec + 12u * M + i;
+        d.x |= (uint64_t)ld_off<uint8_t>(dig, top) << 48;
+        d.y |= (uint64_t)ld_off<uint8_t>(dig, top + M) << 48;
+    }
+    return d;
 }
 __device__ __forceinline__ void store_digits(uint64_t *__restrict__ dig, size_t bc, uint32_t i,
-                                             uint32_t M, uint64_t lo, uint64_t hi) {
+                                             uint32_t M, uint64_t lo, uint64_t hi, bool wide = false) {
     const uint32_t rec = (uint32_t)bc * 16u * M;
     const uint32_t ol = rec + 4u * i, oh = rec + 8u * M + 2u * i;
     st_off<uint32_t>(dig, ol, (uint32_t)lo);
     st_off<uint32_t>(dig, ol + 4u * M, (uint32_t)hi);
     st_off<uint16_t>(dig, oh, (uint16_t)(lo >> 32));
     st_off<uint16_t>(dig, oh + 2u * M, (uint16_t)(hi >> 32));
+    if (wide) {
+        const uint32_t top = rec + 12u * M + i;
+        st_off<uint8_t>(dig, top, (uint8_t)(lo >> 48));
+        st_off<uint8_t>(dig, top + M, (uint8_t)(hi >> 48));
+    }
 }
 
 // ---- randomised flatten (utils.jl:198-241) ----------------------------------------------------------
@@ -253,7 +270,9 @@ __device__ __forceinline__ int32_t digit_reduce(uint64_t e, const Mod &md, int32
 #define SGFHE_EXT_WAVES 4
 #endif
 // LE: points per thread (2^LE); 16 wherever that leaves a full wavefront, 8 for m <= 512
-template <int LOGM, int LE>
+// WIDE: the digit planes carry a third plane (bits 48..55; MODE_WIDE): a separate instantiation, so
+// that the deterministic kernel is textually what it was.
+template <int LOGM, int LE, bool WIDE = false>
 __global__ void __launch_bounds__((NttGeom<LOGM, LE>::T), (NttGeom<LOGM, LE>::T >= 256 ? SGFHE_EXT_WAVES : 1))
 k_extprod(const uint64_t *__restrict__ dig, const int32_t *__restrict__ keyk,
           uint32_t *__restrict__ yres, const uint32_t *__restrict__ ua, PrimeSet PS, uint32_t k,
@@ -321,7 +340,10 @@ k_extprod(const uint64_t *__restrict__ dig, const int32_t *__restrict__ keyk,
             // (the part of the stride below 4096 goes into the instruction's immediate offset)
             const uint32_t OL = (uint32_t)(4 * T * e), OH = (uint32_t)(2 * T * e);  // constants after unrolling
             const uint32_t lo = buf_ld_u32(rdig, vlo + (OL & 4095u), slo + (OL & ~4095u));
-            const uint32_t hi = buf_ld_u16(rdig, vhi + (OH & 4095u), shi + (OH & ~4095u));
+            uint32_t hi = buf_ld_u16(rdig, vhi + (OH & 4095u), shi + (OH & ~4095u));
+            if constexpr (WIDE)
+                hi |= buf_ld_u8(rdig, (uint32_t)tid + ((uint32_t)(T * e) & 4095u),
+                                srec + 12u * (uint32_t)M + (uint32_t)(ph & 1) * (uint32_t)M + ((uint32_t)(T * e) & ~4095u)) << 16;
             x[0][e] = digit_reduce(lo | ((uint64_t)hi << 32), md, sRd);
 #endif
         }
@@ -572,7 +594,8 @@ k_crt_acc(const uint32_t *__restrict__ yres, uint64_t *__restrict__ dig,
     for (int q = 0; q < NP; q++) y[q] = ld_off<uint32_t>(yres, yo + ((uint32_t)(4 * q) << logm));
 #endif
     const bool have_old = !(mode & MODE_NOACC);
-    const ulonglong2 d = have_old ? load_digits(dig, bc, i, M) : make_ulonglong2(0, 0);
+    const bool wide = (mode & MODE_WIDE) != 0;
+    const ulonglong2 d = have_old ? load_digits(dig, bc, i, M, wide) : make_ulonglong2(0, 0);
 #ifdef SGFHE_ABL_CRT_MEMONLY  // timing-only build: every load and store, no arithmetic (wrong results)
     {
         uint32_t acc = 0;
@@ -591,7 +614,7 @@ k_crt_acc(const uint32_t *__restrict__ yres, uint64_t *__restrict__ dig,
     if (mode & MODE_RANDOM) {
         const uint4 ctr = make_uint4(((bc & 1u) << logm) + i, iter, ra.chunk + (bc >> 1), ra.call);
         const ulonglong2 e = random_digits(((u128)a.w2 << 64) | xlo, CC, ra, ctr);
-        store_digits(dig, bc, i, M, e.x, e.y);
+        store_digits(dig, bc, i, M, e.x, e.y, wide);
         return;
     }
     // digits: hi = x' / B (double estimate +- 1), lo = x' - hi B (exact modulo 2^64)
@@ -831,7 +854,7 @@ k_crt_lean(const uint32_t *__restrict__ yres, uint64_t *__restrict__ dig,
 //   zpart [chunk][npr][4][2][m]   slot order (the order of the key slices)
 // Both run with 8 points per thread where that fits a workgroup (LE = 3: twice the threads on
 // each transform); the slot order of a transform does not depend on the points per thread.
-template <int LOGM, int LE>
+template <int LOGM, int LE, bool WIDE = false>
 __global__ void __launch_bounds__((NttGeom<LOGM, LE>::T), (NttGeom<LOGM, LE>::T >= 256 ? 4 : 1))
 k_fwd_phase(const uint64_t *__restrict__ dig, const int32_t *__restrict__ keyk,
             int32_t *__restrict__ zpart, PrimeSet PS, uint32_t mode) {
@@ -850,9 +873,13 @@ k_fwd_phase(const uint64_t *__restrict__ dig, const int32_t *__restrict__ keyk,
     int32_t x[1][E];
     const uint32_t *dl = digit_lo_plane(dig, (size_t)b * 2 + (ph >> 1), M) + (ph & 1) * M;
     const uint16_t *dh = digit_hi_plane(dig, (size_t)b * 2 + (ph >> 1), M) + (ph & 1) * M;
+    const uint8_t *dt = reinterpret_cast<const uint8_t *>(dig + ((size_t)b * 2 + (ph >> 1)) * 2 * M) + 12 * M + (ph & 1) * M;
 #pragma unroll
-    for (int e = 0; e < E; e++)
-        x[0][e] = digit_reduce(dl[tid + T * e] | ((uint64_t)dh[tid + T * e] << 32), md, sRd);
+    for (int e = 0; e < E; e++) {
+        uint64_t d = dl[tid + T * e] | ((uint64_t)dh[tid + T * e] << 32);
+        if constexpr (WIDE) d |= (uint64_t)dt[tid + T * e] << 48;
+        x[0][e] = digit_reduce(d, md, sRd);
+    }
     ntt_forward<LOGM, 1, LE>(x, lds, P.twf, tid, md);
 
     const int32_t *kp = keyk + ((size_t)pi * 8 + ph * 2) * M + E * tid;
@@ -961,8 +988,8 @@ k_init(const uint64_t *__restrict__ a1, const uint64_t *__restrict__ b1,
         if (xb >= Q) xb -= Q;
         const ulonglong2 ea = random_digits(offr, CC, ra, make_uint4(i, 0u, ra.chunk + b, ra.call));
         const ulonglong2 eb = random_digits(xb, CC, ra, make_uint4(M + i, 0u, ra.chunk + b, ra.call));
-        store_digits(dig, (size_t)b * 2 + 0, i, M, ea.x, ea.y);
-        store_digits(dig, (size_t)b * 2 + 1, i, M, eb.x, eb.y);
+        store_digits(dig, (size_t)b * 2 + 0, i, M, ea.x, ea.y, (mode & MODE_WIDE) != 0);
+        store_digits(dig, (size_t)b * 2 + 1, i, M, eb.x, eb.y, (mode & MODE_WIDE) != 0);
         return;
     }
     store_digits(dig, (size_t)b * 2 + 0, i, M, CC->dig0.x, CC->dig0.y);
@@ -1002,15 +1029,16 @@ k_final(const uint64_t *__restrict__ dig, uint64_t *__restrict__ out,
     const uint32_t b = t / (n + 1), e = t % (n + 1);
     const size_t ba = (size_t)b * 2 + 0, bb = (size_t)b * 2 + 1;
     const u128 Q = CC->Q;
+    const bool wide = (mode & MODE_WIDE) != 0;
     u128 va, vo;
     if (e < n) {
-        va = acc_from_digits(load_digits(dig, ba, 3 * M / 4 - e, M), CC, mode);
-        const u128 w = acc_from_digits(load_digits(dig, ba, M / 4 - e, M), CC, mode);
+        va = acc_from_digits(load_digits(dig, ba, 3 * M / 4 - e, M, wide), CC, mode);
+        const u128 w = acc_from_digits(load_digits(dig, ba, M / 4 - e, M, wide), CC, mode);
         vo = w ? Q - w : 0;
     } else {
-        va = CC->DQ + acc_from_digits(load_digits(dig, bb, 3 * M / 4, M), CC, mode);
+        va = CC->DQ + acc_from_digits(load_digits(dig, bb, 3 * M / 4, M, wide), CC, mode);
         if (va >= Q) va -= Q;
-        const u128 w = acc_from_digits(load_digits(dig, bb, M / 4, M), CC, mode);
+        const u128 w = acc_from_digits(load_digits(dig, bb, M / 4, M, wide), CC, mode);
         vo = CC->DQ >= w ? CC->DQ - w : CC->DQ + Q - w;
     }
     const u128 vx = vo >= va ? vo - va : vo + Q - va;
@@ -1035,7 +1063,7 @@ k_dump_acc(const uint64_t *__restrict__ dig, ulonglong2 *__restrict__ out,
     const uint32_t t = blockIdx.x * 256 + threadIdx.x;
     if (t >= total) return;
     const uint32_t M = 1u << logm;
-    const u128 x = acc_from_digits(load_digits(dig, t >> logm, t & (M - 1), M), CC, mode);
+    const u128 x = acc_from_digits(load_digits(dig, t >> logm, t & (M - 1), M, (mode & MODE_WIDE) != 0), CC, mode);
     out[t] = make_ulonglong2((uint64_t)x, (uint64_t)(x >> 64));
 }
 
@@ -1043,11 +1071,11 @@ k_dump_acc(const uint64_t *__restrict__ dig, ulonglong2 *__restrict__ out,
 // u_i + s + xmax in the randomised mode, u the reference's flatten result as a signed integer
 __global__ void __launch_bounds__(256)
 k_dump_digits(const uint64_t *__restrict__ dig, uint64_t *__restrict__ out, uint32_t total,
-              uint32_t logm) {
+              uint32_t logm, uint32_t mode) {
     const uint32_t t = blockIdx.x * 256 + threadIdx.x;
     if (t >= total) return;
     const uint32_t M = 1u << logm, bc = t >> logm, i = t & (M - 1);
-    const ulonglong2 d = load_digits(dig, bc, i, M);
+    const ulonglong2 d = load_digits(dig, bc, i, M, (mode & MODE_WIDE) != 0);
     out[((size_t)bc * 2 + 0) * M + i] = d.x;
     out[((size_t)bc * 2 + 1) * M + i] = d.y;
 }

@@ -235,7 +235,8 @@ def test_params2048_largest_reference_ring(S, oc, form):
     """Params(2048): the largest parameter set the reference can build (Q 92.25 bits < 2^128,
     src/fhe.jl:74-77): m = 16384, six RNS primes, B just above 2^46.  The first two k-loop
     iterations against the oracle (only key slices 0 and 1 are filled), then complete gate
-    bootstraps with a device-generated key, checked by decryption."""
+    bootstraps with a device-generated key, checked by decryption, in both flatten modes
+    (src/utils.jl:155-189 and :198-241)."""
     import bench
     params = S.Params(2048)
     o = oc.Oracle.from_params(params)
@@ -262,8 +263,17 @@ def test_params2048_largest_reference_ring(S, oc, form):
     for g, fn in enumerate((np.bitwise_and, np.bitwise_or, np.bitwise_xor)):
         dec = o.lwe_decrypt_bits(sk, out[:, g, :params.n], out[:, g, params.n])
         assert np.array_equal(dec, fn(y1, y2))
-    with pytest.raises(S.SgfheError):                      # digits of the randomised mode need B < 2^46
-        eng.set_random_flatten(True, 1)
+    # the randomised flatten on the same ring (B = 35 * 2^41 > 2^46: its stored digits reach
+    # 4 B > 2^48 and use the third plane of the digit record): decrypt-level truth table, and the
+    # deterministic result comes back unchanged afterwards
+    eng.set_random_flatten(True, 1)
+    rnd = eng.bootstrap_batch(a[0::2], b[0::2], a[1::2], b[1::2])
+    assert not np.array_equal(rnd, out)
+    for g, fn in enumerate((np.bitwise_and, np.bitwise_or, np.bitwise_xor)):
+        dec = o.lwe_decrypt_bits(sk, rnd[:, g, :params.n], rnd[:, g, params.n])
+        assert np.array_equal(dec, fn(y1, y2))
+    eng.set_random_flatten(False)
+    assert np.array_equal(eng.bootstrap_batch(a[0::2], b[0::2], a[1::2], b[1::2]), out)
     eng.close()
 
 

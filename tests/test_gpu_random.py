@@ -48,15 +48,23 @@ def _ints(arr):
     return [int(lo) | (int(hi) << 64) for lo, hi in flat]
 
 
-@pytest.mark.parametrize("ring", ["params64", "synthetic"])
+@pytest.mark.parametrize("ring", ["params64", "synthetic", "wide base"])
 def test_random_mode_equals_oracle_bit_for_bit(S, oc, ring):
     if ring == "params64":
         params, noise = S.Params(64), None
-    else:                                       # m = 128: another pass structure, odd-free base
+    elif ring == "synthetic":                   # m = 128: another pass structure, odd-free base
         n = 16
         params, noise = S.Params.custom(n, BO.find_modulus(16 * n, 1 << 52), 1 << 27), 2
+    else:
+        # B = 3 * 2^45 + 1 >= 2^46 (odd): the stored digits u + s + xmax reach 4 B = 1.5 * 2^48 and
+        # take the third plane of the digit record (MODE_WIDE), as at Params(2048) (B = 35 * 2^41);
+        # Q just under B^2, 92 bits: six RNS primes, four 29-bit limbs in k_crt_lean
+        n = 8
+        params, noise = S.Params.custom(n, BO.find_modulus(16 * n, 1 << 92), 3 * (1 << 45) + 1), 2
     o, sk, bkey, eng, bp, bk = _setup(S, oc, params, 300, noise)
     n, m, B, Q = params.n, params.m, params.B, params.Q
+    if ring == "wide base":
+        assert len(eng.primes()) == 6 and B >= 1 << 46
     bits = np.array([1, 1, 0, 1, 1, 0], dtype=np.uint8)
     a, b = o.lwe_encrypt_bits(sk, bits, 301)
     a1, b1, a2, b2 = a[0::2], b[0::2], a[1::2], b[1::2]
@@ -81,6 +89,8 @@ def test_random_mode_equals_oracle_bit_for_bit(S, oc, ring):
             for i in range(2):
                 u = [int(v) - s_shift for v in dig[t, c, i]]
                 assert all(-2 * B < x <= 2 * B for x in u)        # internals.test.jl:48-52
+                if ring == "wide base":                           # the third plane is really in use
+                    assert max(int(v) for v in dig[t, c, i]) >= 1 << 48
                 assert [x % Q for x in u] == want[i]
             restored = [(int(dig[t, c, 0, j]) - s_shift + (int(dig[t, c, 1, j]) - s_shift) * B) % Q
                         for j in range(m)]
@@ -174,3 +184,57 @@ def test_random_mode_needs_headroom_at_params1024(S):
     both.set_random_flatten(True, 1)
     both.set_random_flatten(False)
     both.close()
+
+
+def test_random_mode_refused_when_its_reductions_would_overflow(S):
+    """A parameter set with B^2 far above Q (4 B^2 / Q >= 2^50): the randomised flatten divides
+    values up to 4 B^2 by Q with a double-precision quotient estimate, so the mode is refused
+    (SGFHE_ERR_UNSUPPORTED) instead of returning silently wrong digits; the deterministic flatten of
+    the same ring works."""
+    params = S.Params.custom(8, (1 << 17) + 1, 1 << 45)
+    eng = S.Engine(params, random_flatten=True)
+    with pytest.raises(S.SgfheError) as ei:
+        eng.set_random_flatten(True, 1)
+    assert ei.value.code == -2
+    key = np.zeros((params.n, 4, 2, params.m, 2), dtype=np.uint64)
+    key[..., 0] = np.random.default_rng(1).integers(0, params.Q, size=key.shape[:-1], dtype=np.uint64)
+    eng.upload_key(key)
+    rng = np.random.default_rng(2)
+    a1 = rng.integers(0, params.r, size=(2, params.n), dtype=np.uint64)
+    b1 = rng.integers(0, params.r, size=2, dtype=np.uint64)
+    acc = eng.debug_accumulators(a1, b1, a1, b1, 2)
+    import bigint_oracle as BO
+    bp = BO.Params.custom(params.n, params.Q, params.B, DQ_tilde=params.DQ_tilde)
+    vals = [int(lo) | (int(hi) << 64) for lo, hi in key.reshape(-1, 2)]
+    m = params.m
+    bk = [[[vals[((k * 4 + r) * 2 + c) * m:((k * 4 + r) * 2 + c + 1) * m] for c in range(2)]
+           for r in range(4)] for k in range(params.n)]
+    got = {}
+    BO.bootstrap_internal(bp, bk, ([int(x) for x in a1[0]], int(b1[0])), ([int(x) for x in a1[0]], int(b1[0])),
+                          trace=lambda k, a, b: got.__setitem__(k + 1, (list(a), list(b))))
+    assert _ints(acc[0, 0]) == got[2][0] and _ints(acc[0, 1]) == got[2][1]
+    eng.close()
+
+
+def test_key_generation_rejects_noise_out_of_range(S):
+    """sgfhe_bkey_generate forms the noise in int32 and lifts it as Q - |e|: noise >= 2^30 or
+    >= Q / 2 is SGFHE_ERR_INVALID_ARG, not a silently invalid key (the oracle's generators raise
+    on the same bound)."""
+    import oracle_c
+    params = S.Params(64)
+    eng = S.Engine(params)
+    sk = np.zeros(params.n, dtype=np.uint64)
+    for noise in (1 << 30, (1 << 32) - 1):
+        with pytest.raises(S.SgfheError) as ei:
+            eng.generate_key(sk, 5, noise=noise)
+        assert ei.value.code == -1
+    eng.generate_key(sk, 5, noise=(1 << 30) - 1)
+    eng.close()
+    small = S.Params.custom(8, (1 << 17) + 1, 1 << 9)
+    eng = S.Engine(small)
+    with pytest.raises(S.SgfheError) as ei:
+        eng.generate_key(np.zeros(8, dtype=np.uint64), 5, noise=(1 << 16) + 1)   # 2 noise >= Q
+    assert ei.value.code == -1
+    eng.close()
+    with pytest.raises(ValueError):
+        oracle_c.Oracle.from_params(params).bootstrap_key(sk, 5, noise=1 << 30)
