@@ -40,7 +40,7 @@ def main():
                                os.path.join(ROOT, "sgfhe.jl_amd", "csrc", "engine.hip")],
                               stderr=subprocess.DEVNULL)
         asm = open(out).read()
-    print(json.dumps(mix_of(kernel_body(asm, "k_extprodILi13E"))))
+    print(json.dumps(mix_of(kernel_body(asm, "k_extprodILi13ELi4ELb0E"))))
 
 
 if __name__ == "__main__":
