@@ -110,7 +110,8 @@ def _counters(config, chunk, build_id):
             stale = stale or os.path.basename(path)
             continue
         return dict(d["kernels"], source=os.path.basename(path), valu_mix=d.get("valu_mix"),
-                    rocprof_avg_us=d.get("rocprof_avg_us")), None
+                    rocprof_avg_us=d.get("rocprof_avg_us"), rocprof_iter_us=d.get("rocprof_iter_us"),
+                    rocprof_alone_avg_us=d.get("rocprof_alone_avg_us")), None
     if stale:
         return None, "the loaded library (build id %s) is not the one %s was collected on" % (build_id, stale)
     return None, "no committed counters for chunk %d" % chunk
