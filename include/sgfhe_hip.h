@@ -250,6 +250,39 @@ int32_t sgfhe_debug_ntt(sgfhe_ctx *ctx, uint32_t prime_index, int inverse, const
 int32_t sgfhe_debug_primes(const sgfhe_ctx *ctx, uint32_t *count, uint32_t *primes);
 
 /*
+ * The ciphertext plumbing either side of the path, on the host: no
+ * device, no ctx; `p` supplies n, r = 2 m (t = log2 r - 1, Dr = r / 4).  Polynomials over Z_r
+ * are arrays of uint64 in [0, r) (the memory of Polynomial{ModUInt{UInt64, r}}), bit arrays are
+ * one uint8 per bit, bit matrices [rows][n] row-major.  Every function is pure: the random draws
+ * of the reference (src/fhe.jl:315,319) are arguments, so the caller keeps its own generator.
+ */
+/* deterministic_expand(params, u) (src/fhe.jl:304-307): u[n] seed bits -> a[n] over Z_r.
+ * prng_expand (src/utils.jl:63-68) is built on SHAKE-256 here, the primitive the reference names
+ * as intended (utils.jl:64); the reference itself seeds a MersenneTwister with hash(seq). */
+int32_t sgfhe_host_deterministic_expand(const sgfhe_params *p, const uint8_t *u, uint64_t *a);
+/* _encrypt_private(key, rng, message) (src/fhe.jl:310-328) given its draws u[n] (bits) and
+ * w[n] in [-Dr/8, Dr/8]: sk[n] key bits (bit 0 of each word), message[n] bits -> RLWE (a, b). */
+int32_t sgfhe_host_encrypt_private(const sgfhe_params *p, const uint64_t *sk, const uint8_t *u,
+                                   const int64_t *w, const uint8_t *message, uint64_t *a, uint64_t *b);
+/* The v of encrypt_optimal(key::PrivateKey, ...) (src/fhe.jl:339-345): b[n] -> v[5][n] bits. */
+int32_t sgfhe_host_pack_private(const sgfhe_params *p, const uint64_t *b, uint8_t *v);
+/* normalize_ciphertext(::PrivateEncryptedCiphertext) (src/fhe.jl:354-359): (u[n], v[5][n]) -> (a, b). */
+int32_t sgfhe_host_normalize_private(const sgfhe_params *p, const uint8_t *u, const uint8_t *v,
+                                     uint64_t *a, uint64_t *b);
+/* split_ciphertext(ct) (src/fhe.jl:287-290, extract :237-244) of an RLWE with polynomials of
+ * length N = n (PackedCiphertext) or N = m (Ciphertext): lwe_a[n][n], lwe_b[n] -- the inputs of
+ * sgfhe_bootstrap_batch. */
+int32_t sgfhe_host_split_ciphertext(const sgfhe_params *p, const uint64_t *a, const uint64_t *b,
+                                    size_t N, uint64_t *lwe_a, uint64_t *lwe_b);
+/* decrypt(key, ::EncryptedBit) (src/fhe.jl:504-507) for `count` LWEs: lwe_a[count][n], lwe_b[count]
+ * (e.g. one gate of sgfhe_bootstrap_batch's output) -> bits[count]. */
+int32_t sgfhe_host_decrypt_lwe(const sgfhe_params *p, const uint64_t *sk, const uint64_t *lwe_a,
+                               const uint64_t *lwe_b, size_t count, uint8_t *bits);
+/* decrypt(key, ::Union{Ciphertext, PackedCiphertext}) (src/fhe.jl:471-494), N = n or m -> bits[n]. */
+int32_t sgfhe_host_decrypt_rlwe(const sgfhe_params *p, const uint64_t *sk, const uint64_t *a,
+                                const uint64_t *b, size_t N, uint8_t *bits);
+
+/*
  * Measurement hook for bench.py: HIP-event timings taken on the ctx stream around sampled
  * launches of the two per-iteration kernels since the last reset (stats must hold 8 doubles).
  *   stats[0] = average external-product kernel time (ms)   stats[1] = its sampled launches

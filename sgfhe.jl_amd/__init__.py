@@ -10,12 +10,13 @@ from ._lib import build, lib, LIB_PATH, EXPORTED_SYMBOLS, ABI_VERSION, source_ha
 from .engine import Engine, SgfheError, FLAG_RAW_MODQ, CTX_RANDOM_FLATTEN
 from .params import Params, find_modulus, isprime
 from . import distributed
+from . import host
 from .scheme import (PrivateKey, PublicKey, PublicEncryptedCiphertext, BootstrapKey, LWE, RLWE, EncryptedBit, PackedCiphertext,
                      Ciphertext, encrypt, extract, split_ciphertext, decrypt, bootstrap,
                      bootstrap_batch, pack_encrypted_bits, encrypt_optimal, normalize_ciphertext,
                      PrivateEncryptedCiphertext, packbits, unpackbits, prng_expand)
 
-__all__ = ["distributed", "build", "lib", "LIB_PATH", "EXPORTED_SYMBOLS", "ABI_VERSION", "source_hash", "embedded_build_id", "Engine", "SgfheError",
+__all__ = ["distributed", "host", "build", "lib", "LIB_PATH", "EXPORTED_SYMBOLS", "ABI_VERSION", "source_hash", "embedded_build_id", "Engine", "SgfheError",
            "FLAG_RAW_MODQ", "CTX_RANDOM_FLATTEN", "Params", "find_modulus", "isprime", "PrivateKey", "BootstrapKey",
            "PublicKey", "PublicEncryptedCiphertext",
            "LWE", "RLWE", "EncryptedBit", "PackedCiphertext", "encrypt", "extract",

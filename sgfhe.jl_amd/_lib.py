@@ -117,6 +117,13 @@ def lib():
         "sgfhe_debug_flatten": (i32, [vp, vp, vp]),
         "sgfhe_debug_ntt": (i32, [vp, u32, ctypes.c_int, vp, vp]),
         "sgfhe_debug_primes": (i32, [vp, _u32p, _u32p]),
+        "sgfhe_host_deterministic_expand": (i32, [ctypes.POINTER(SgfheParams), vp, vp]),
+        "sgfhe_host_encrypt_private": (i32, [ctypes.POINTER(SgfheParams), vp, vp, vp, vp, vp, vp]),
+        "sgfhe_host_pack_private": (i32, [ctypes.POINTER(SgfheParams), vp, vp]),
+        "sgfhe_host_normalize_private": (i32, [ctypes.POINTER(SgfheParams), vp, vp, vp, vp]),
+        "sgfhe_host_split_ciphertext": (i32, [ctypes.POINTER(SgfheParams), vp, vp, sz, vp, vp]),
+        "sgfhe_host_decrypt_lwe": (i32, [ctypes.POINTER(SgfheParams), vp, vp, vp, sz, vp]),
+        "sgfhe_host_decrypt_rlwe": (i32, [ctypes.POINTER(SgfheParams), vp, vp, vp, sz, vp]),
         "sgfhe_timing_enable": (i32, [vp, ctypes.c_int]),
         "sgfhe_timing_read": (i32, [vp, ctypes.POINTER(ctypes.c_double), ctypes.c_int]),
     }
@@ -137,4 +144,6 @@ EXPORTED_SYMBOLS = (
     "sgfhe_bkey_device_form_bytes", "sgfhe_bkey_export_device_form",
     "sgfhe_bkey_import_device_form", "sgfhe_bootstrap_batch", "sgfhe_bootstrap_batch_device",
     "sgfhe_sync", "sgfhe_external_product", "sgfhe_pack_encrypted_bits", "sgfhe_debug_cmux", "sgfhe_debug_accumulators", "sgfhe_debug_digits", "sgfhe_debug_flatten", "sgfhe_debug_ntt",
-    "sgfhe_debug_primes", "sgfhe_timing_enable", "sgfhe_timing_read")
+    "sgfhe_debug_primes", "sgfhe_host_deterministic_expand", "sgfhe_host_encrypt_private",
+    "sgfhe_host_pack_private", "sgfhe_host_normalize_private", "sgfhe_host_split_ciphertext",
+    "sgfhe_host_decrypt_lwe", "sgfhe_host_decrypt_rlwe", "sgfhe_timing_enable", "sgfhe_timing_read")

@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "kernels.h"
+#include "host_plumbing.h"
 
 using namespace sgfhe;
 
@@ -1548,6 +1549,108 @@ int32_t sgfhe_debug_primes(const sgfhe_ctx *c, uint32_t *count, uint32_t *primes
     SGFHE_LOCK(c);
     *count = c->npr;
     for (uint32_t i = 0; i < c->npr; i++) primes[i] = c->primes[i];
+    return SGFHE_OK;
+}
+
+// ---- N3: the ciphertext plumbing either side of the path, on the host (no device, no ctx) ----------
+
+namespace {
+// r = 2 m a power of two, n <= m, t = log2(r) - 1, Dr = r / 4
+bool host_params_ok(const sgfhe_params *p) {
+    return p && p->n >= 1 && p->m >= p->n && p->r == 2 * p->m && (p->r & (p->r - 1)) == 0 && p->r >= 32 &&
+           p->r <= (1ull << 32);
+}
+unsigned host_t(const sgfhe_params *p) {
+    unsigned lg = 0;
+    while ((1ull << lg) < p->r) lg++;
+    return lg - 1;
+}
+}  // namespace
+
+int32_t sgfhe_host_deterministic_expand(const sgfhe_params *p, const uint8_t *u, uint64_t *a) {
+    if (!host_params_ok(p) || !u || !a) return SGFHE_ERR_INVALID_ARG;
+    sgfhe_host::prng_expand(u, p->n, host_t(p) + 1, a);
+    for (uint64_t i = 0; i < p->n; i++) a[i] &= p->r - 1;
+    return SGFHE_OK;
+}
+
+int32_t sgfhe_host_encrypt_private(const sgfhe_params *p, const uint64_t *sk, const uint8_t *u,
+                                   const int64_t *w, const uint8_t *message, uint64_t *a, uint64_t *b) {
+    if (!host_params_ok(p) || !sk || !u || !w || !message || !a || !b) return SGFHE_ERR_INVALID_ARG;
+    const uint64_t n = p->n, rmask = p->r - 1, Dr = p->r / 4;
+    const int64_t wr = (int64_t)(Dr / 8);
+    for (uint64_t i = 0; i < n; i++)
+        if (w[i] < -wr || w[i] > wr) return SGFHE_ERR_INVALID_ARG;      // w in -Dr/8 .. Dr/8 (fhe.jl:318-319)
+    int32_t rc = sgfhe_host_deterministic_expand(p, u, a);             // fhe.jl:316
+    if (rc) return rc;
+    std::vector<uint64_t> key(n), as(n);
+    for (uint64_t i = 0; i < n; i++) key[i] = sk[i] & 1;
+    sgfhe_host::negacyclic_mul(a, key.data(), n, rmask, as.data());
+    const unsigned sh = host_t(p) - 4;
+    for (uint64_t i = 0; i < n; i++) {
+        const uint64_t v = (as[i] + (uint64_t)w[i] + (uint64_t)(message[i] & 1) * Dr) & rmask;   // fhe.jl:322
+        b[i] = (v >> sh) << sh;                                          // the highmost 5 bits (fhe.jl:325)
+    }
+    return SGFHE_OK;
+}
+
+int32_t sgfhe_host_pack_private(const sgfhe_params *p, const uint64_t *b, uint8_t *v) {
+    if (!host_params_ok(p) || !b || !v) return SGFHE_ERR_INVALID_ARG;
+    std::vector<uint64_t> packed(p->n);
+    const unsigned sh = host_t(p) - 4;
+    for (uint64_t i = 0; i < p->n; i++) packed[i] = b[i] >> sh;        // fhe.jl:342
+    sgfhe_host::unpackbits(packed.data(), p->n, 5, v);
+    return SGFHE_OK;
+}
+
+int32_t sgfhe_host_normalize_private(const sgfhe_params *p, const uint8_t *u, const uint8_t *v,
+                                     uint64_t *a, uint64_t *b) {
+    if (!host_params_ok(p) || !u || !v || !a || !b) return SGFHE_ERR_INVALID_ARG;
+    int32_t rc = sgfhe_host_deterministic_expand(p, u, a);             // fhe.jl:356
+    if (rc) return rc;
+    sgfhe_host::packbits(v, 5, p->n, b);                               // fhe.jl:357
+    const unsigned sh = host_t(p) - 4;
+    for (uint64_t i = 0; i < p->n; i++) b[i] = (b[i] << sh) & (p->r - 1);
+    return SGFHE_OK;
+}
+
+int32_t sgfhe_host_split_ciphertext(const sgfhe_params *p, const uint64_t *a, const uint64_t *b,
+                                    size_t N, uint64_t *lwe_a, uint64_t *lwe_b) {
+    if (!host_params_ok(p) || !a || !b || !lwe_a || !lwe_b || (N != p->n && N != p->m))
+        return SGFHE_ERR_INVALID_ARG;
+    const uint64_t n = p->n, rmask = p->r - 1;
+    for (uint64_t i = 1; i <= n; i++) {                                 // fhe.jl:288-289
+        sgfhe_host::extract(a, N, i, n, rmask, lwe_a + (i - 1) * n);
+        lwe_b[i - 1] = b[i - 1] & rmask;
+    }
+    return SGFHE_OK;
+}
+
+int32_t sgfhe_host_decrypt_lwe(const sgfhe_params *p, const uint64_t *sk, const uint64_t *lwe_a,
+                               const uint64_t *lwe_b, size_t count, uint8_t *bits) {
+    if (!host_params_ok(p) || !sk || !lwe_a || !lwe_b || !bits) return SGFHE_ERR_INVALID_ARG;
+    const uint64_t n = p->n, rmask = p->r - 1, Dr = p->r / 4;
+    for (size_t t = 0; t < count; t++) {
+        uint64_t dot = 0;
+        for (uint64_t i = 0; i < n; i++) dot += lwe_a[t * n + i] * (sk[i] & 1);
+        const uint64_t b1 = (lwe_b[t] - dot) & rmask;                    // fhe.jl:505
+        bits[t] = (uint8_t)((((b1 + Dr / 2) & rmask) / Dr) & 1);         // fhe.jl:506
+    }
+    return SGFHE_OK;
+}
+
+int32_t sgfhe_host_decrypt_rlwe(const sgfhe_params *p, const uint64_t *sk, const uint64_t *a,
+                                const uint64_t *b, size_t N, uint8_t *bits) {
+    if (!host_params_ok(p) || !sk || !a || !b || !bits || (N != p->n && N != p->m))
+        return SGFHE_ERR_INVALID_ARG;
+    const uint64_t n = p->n, rmask = p->r - 1, Dr = p->r / 4;
+    std::vector<uint64_t> key(N, 0), as(N);                              // resize(key, m) for a Ciphertext (fhe.jl:474-478)
+    for (uint64_t i = 0; i < n; i++) key[i] = sk[i] & 1;
+    sgfhe_host::negacyclic_mul(a, key.data(), N, rmask, as.data());
+    for (uint64_t i = 0; i < n; i++) {                                   // the first n coefficients (fhe.jl:481-482)
+        const uint64_t b1 = (b[i] - as[i]) & rmask;
+        bits[i] = (uint8_t)((((b1 + Dr / 2) & rmask) / Dr) & 1);         // fhe.jl:491-493
+    }
     return SGFHE_OK;
 }
 

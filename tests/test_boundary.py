@@ -84,3 +84,17 @@ def test_header_documents_what_the_engine_accepts():
     eng = open(os.path.join(ROOT, "sgfhe.jl_amd", "csrc", "engine.hip")).read()
     assert "B < 2^47" in hdr and "(c->B >> 47)" in eng
     assert "Always the deterministic flatten" not in hdr
+
+
+def test_c_example_compiles_against_the_header(S, tmp_path):
+    """examples/gate_demo.c is plain C99 over the C ABI alone; it builds and links here (running it
+    needs a GPU: tests/test_gpu_c_example.py) and fails loudly without a device."""
+    lib_dir = os.path.dirname(S.build())
+    exe = str(tmp_path / "gate_demo")
+    subprocess.check_call(["gcc", "-std=c99", "-O2", "-Wall", "-Wextra", "-Werror", "-I", os.path.dirname(HDR),
+                           os.path.join(ROOT, "examples", "gate_demo.c"), "-L", lib_dir, "-lsgfhe_hip",
+                           "-Wl,-rpath," + lib_dir, "-o", exe])
+    import torch
+    if not torch.cuda.is_available():
+        r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+        assert r.returncode == 1 and "-> -3" in r.stderr          # SGFHE_ERR_NO_DEVICE, no fallback
