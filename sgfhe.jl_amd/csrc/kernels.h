@@ -814,9 +814,23 @@ k_crt_lean(const uint32_t *__restrict__ yres, uint64_t *__restrict__ dig,
     const uint32_t i = (4u * t) & (M - 1);  // multiple of 4
     const uint32_t bc = (4u * t) >> logm;
     const uint32_t yo = 4u * ((bc * NP << logm) + i);
+    // The residues are read exactly once: non-temporal loads keep them from displacing what the other
+    // lane's k_extprod re-reads from the caches (key slice, digit planes).  Same call, two lanes of
+    // 256 (profiles/r03_exp_cache_policy.txt): 2076 against 2016 bootstraps/s, +3.0 %, and +2.9 % on
+    // a second box; the old digits loaded the same way as well: +2.2 % (they are in the caches, the
+    // external product of this chunk has just read them), so those stay plain loads.
+    typedef unsigned int v4u __attribute__((ext_vector_type(4)));
     uint4 yv[NP];
 #pragma unroll
-    for (int q = 0; q < NP; q++) yv[q] = ld_off<uint4>(yres, yo + ((uint32_t)(4 * q) << logm));
+    for (int q = 0; q < NP; q++) {
+#ifdef SGFHE_CRT_PLAIN_LOADS  // (A/B builds)
+        yv[q] = ld_off<uint4>(yres, yo + ((uint32_t)(4 * q) << logm));
+#else
+        const v4u t = __builtin_nontemporal_load(reinterpret_cast<const v4u *>(
+            reinterpret_cast<const char *>(yres) + yo + ((uint32_t)(4 * q) << logm)));
+        yv[q] = make_uint4(t.x, t.y, t.z, t.w);
+#endif
+    }
     const uint32_t rec = bc * 16u * M;
     const uint32_t ol = rec + 4u * i, oh = rec + 8u * M + 2u * i;
     const uint4 l0 = ld_off<uint4>(dig, ol), l1 = ld_off<uint4>(dig, ol + 4u * M);
