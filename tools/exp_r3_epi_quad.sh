@@ -1,0 +1,11 @@
+# k_extprod epilogue with four adjacent coefficients per thread and 16-byte residue stores
+# (-DSGFHE_EPI_QUAD) against the 4-byte stores; two lanes, and one lane.
+B="python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-host-io --no-isolated"
+for i in 1 2 3; do
+for v in base epiquad; do
+SGFHE_HIP_LIB=$PWD/tools/abl/lib_$v.so $B | python tools/result_line.py ${v}_l2_$i
+done
+done
+for v in base epiquad; do
+SGFHE_HIP_LIB=$PWD/tools/abl/lib_$v.so $B --lanes 1 | python tools/result_line.py ${v}_l1
+done
