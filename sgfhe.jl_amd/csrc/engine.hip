@@ -492,7 +492,18 @@ int32_t bootstrap_device(sgfhe_ctx *c, const uint64_t *a1, const uint64_t *b1, c
                          uint64_t n_iters, ulonglong2 *acc_out, hipStream_t st,
                          uint64_t *dig_out = nullptr) {
     if (!c->have_key) return fail(c, SGFHE_ERR_NO_KEY, "no bootstrap key uploaded");
-    const uint32_t chunk = c->chunk ? c->chunk : default_chunk(c);
+    uint32_t chunk = c->chunk ? c->chunk : default_chunk(c);
+    if (!c->chunk && c->lanes == 2 && batch > 2 * (size_t)c->small_max) {
+        // Automatic chunk size with two lanes: cut the batch into an even number of equal chunks no
+        // larger than the default, so that both lanes are busy from the first bootstrap to the last
+        // (a batch of 256 runs as 128 + 128 instead of one chunk on one lane, 384 as 192 + 192
+        // instead of 256 + 128).  Measured at Params(1024) (profiles/r03_exp_mid_batches.txt):
+        // 64 / 128 / 256 / 384 / 640 bootstraps 1158 -> 1401, 1555 -> 1858, 1875 -> 1981, 1847 -> 2071,
+        // 1850 -> 2030 per second.  Halves that would fall to the small-batch form (batch <= 48) are not
+        // split: 48 bootstraps run at 1277 per second as one chunk and at 1024 as 24 + 24.
+        const size_t pairs = (batch + 2 * (size_t)chunk - 1) / (2 * (size_t)chunk);
+        chunk = round_up8((uint32_t)((batch + 2 * pairs - 1) / (2 * pairs)));
+    }
     const uint32_t n = c->n, M = c->M;
     const bool raw = flags & SGFHE_FLAG_RAW_MODQ;
     if (flags & SGFHE_FLAG_RAW_RNS2) {
