@@ -303,11 +303,20 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    # Rehearsal on a box with fewer GPUs than ranks (tests/test_gpu_multi.py): the ranks share the
+    # devices that exist and talk over gloo (RCCL refuses two ranks on one device).  Never a
+    # measurement: the line says so in config.rehearsal.
+    rehearsal = os.environ.get("SGFHE_BENCH_SHARE_GPU") == "1"
+    if rehearsal:
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1 or "RANK" in os.environ:      # launched by torch.distributed.run: RCCL over xGMI
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     p = make_params(S, args.config)
     W = W_BYTES[args.config]
@@ -456,7 +465,9 @@ def main():
                        "rns_primes": len(eng.primes()),
                        "key": "generated on the device from a seed (valid key)",
                        "keygen_s": round(keygen_s, 3), "key_bytes": eng.key_device_form_bytes(),
-                       "key_broadcast_s": round(bcast_s, 4), "build_id": build_id},
+                       "key_broadcast_s": round(bcast_s, 4), "build_id": build_id,
+                       **({"rehearsal": "ranks share %d GPU(s) over gloo: not a measurement"
+                                        % torch.cuda.device_count()} if rehearsal else {})},
             "roofline": {"bound": "hbm",
                          "kernel": "k_extprod + k_crt_lean (one k-loop iteration of a %d-bootstrap chunk%s)"
                                    % (chunk, "; the two kernels of the two lanes' chunks overlap" if lanes == 2 else ""),

@@ -219,3 +219,28 @@ def test_bench_two_gpus_self_launch():
     assert r.returncode == 0, r.stderr[-2000:]
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert d["n_gpus"] == 2 and d["config"]["key_broadcast_s"] > 0 and d["value"] > 0
+
+
+@pytest.mark.parametrize("ranks", [2, 4])
+def test_bench_ranks_rehearsal_on_one_gpu(ranks):
+    """The N > 1 control flow of bench.py on the hardware a one-GPU box has: `--gpus N` starts N
+    ranks (torch.distributed.run on 127.0.0.1), rank 0 generates the key, the device-form blob is
+    broadcast and imported by the peers, every rank times its shard between barriers, the MAX over
+    ranks is taken and rank 0 prints one line with the whole-job value.  The ranks share device 0
+    and talk over gloo (SGFHE_BENCH_SHARE_GPU=1: RCCL refuses two ranks on one device), and the
+    line carries config.rehearsal; the RCCL form is test_bench_two_gpus_self_launch."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env["SGFHE_BENCH_SHARE_GPU"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(ranks), "--config",
+                        "params64", "--batch", "512", "--steps", "2", "--warmup", "1"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == ranks and d["config"]["key_broadcast_s"] > 0 and "rehearsal" in d["config"]
+    assert d["value"] > 0 and abs(d["value"] - ranks * 512 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    assert d["host_io"]["equals_device_resident_output"] is True and "cpu_baseline" not in d
