@@ -94,7 +94,9 @@ int32_t sgfhe_ctx_destroy(sgfhe_ctx *ctx);
 const char *sgfhe_last_error_string(const sgfhe_ctx *ctx);
 
 /* Batch-scheduling knobs.  chunk: bootstraps that move through the k-loop in lock-step
- * (0 = default; rounded up to a multiple of 8; a chunk's buffers must stay below 4 GiB).
+ * (rounded up to a multiple of 8; a chunk's buffers must stay below 4 GiB).  0 = automatic: a size
+ * near the Infinity Cache budget (256 per lane at Params(1024)), and with two lanes a batch above
+ * 48 gates is cut into an even number of equal chunks, so that both lanes carry the same load.
  * lanes: 2 (default) runs pairs of chunks on two HIP streams, so that the memory-bound CRT kernel
  * of one chunk runs beside the arithmetic-bound external product of the other (+2 ... 5 % at
  * Params(1024), profiles/r03_exp_lanes_sweep.txt); 1 runs the chunks of a batch one after the
