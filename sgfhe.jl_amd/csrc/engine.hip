@@ -752,7 +752,9 @@ int32_t build_constants(sgfhe_ctx *c) {
     }
 
     // twiddle tables and per-prime constants (all residues centred: |.| <= (p - 1) / 2)
-    std::vector<int32_t> tw((size_t)NPR * 2 * M);
+    // per prime four tables of m entries: forward twiddles, inverse twiddles, and at + 2 m from each the
+    // product twiddles of the radix-4 steps (ntt.h fwd_step4): twp[j] = +-tw[j >> 1] tw[j], minus for odd j
+    std::vector<int32_t> tw((size_t)NPR * 4 * M);
     std::vector<PrimeK> pk(NPR);
     cc.npr = npr;
     HIPCHK(c, hipMalloc(&c->d_tw, tw.size() * sizeof(int32_t)));
@@ -765,15 +767,25 @@ int32_t build_constants(sgfhe_ctx *c) {
         }
         if (!psi) return fail(c, SGFHE_ERR_UNSUPPORTED, "no primitive 2m-th root of unity");
         const uint32_t ipsi = powmod32(psi, p - 2, p);
-        int32_t *f = tw.data() + (size_t)(2 * i) * M, *v = f + M;
+        int32_t *f = tw.data() + (size_t)(4 * i) * M, *v = f + M, *fp = f + 2 * M, *vp = f + 3 * M;
         const uint32_t R1m = (uint32_t)((1ull << 32) % p);
+        std::vector<uint32_t> pf(M), pv(M);   // plain values in table order
         uint32_t pw = 1, ipw = 1;
         for (uint32_t t = 0; t < M; t++) {
             const uint32_t br = bitrev(t, logm);
+            pf[br] = pw;
+            pv[br] = ipw;
             f[br] = centre32(mulmod32(pw, R1m, p), p);   // Montgomery form
             v[br] = centre32(mulmod32(ipw, R1m, p), p);
             pw = mulmod32(pw, psi, p);
             ipw = mulmod32(ipw, ipsi, p);
+        }
+        fp[0] = fp[1] = vp[0] = vp[1] = 0;
+        for (uint32_t j = 2; j < M; j++) {
+            const uint32_t a = mulmod32(mulmod32(pf[j >> 1], pf[j], p), R1m, p);
+            const uint32_t b = mulmod32(mulmod32(pv[j >> 1], pv[j], p), R1m, p);
+            fp[j] = centre32((j & 1) ? (p - a) % p : a, p);
+            vp[j] = centre32((j & 1) ? (p - b) % p : b, p);
         }
         PrimeK &P = pk[i];
         memset(&P, 0, sizeof P);
@@ -803,8 +815,8 @@ int32_t build_constants(sgfhe_ctx *c) {
         P.kappaR = centre32(mulmod32(kappa, R1, p), p);
         P.minvR = centre32(mulmod32(minv, R1, p), p);
         P.invp = 1.0f / (float)p;
-        P.twf = c->d_tw + (size_t)(2 * i) * M;
-        P.twi = c->d_tw + (size_t)(2 * i + 1) * M;
+        P.twf = c->d_tw + (size_t)(4 * i) * M;
+        P.twi = c->d_tw + (size_t)(4 * i + 1) * M;
         P.npr = npr;
     }
     HIPCHK(c, hipMemcpy(c->d_tw, tw.data(), tw.size() * sizeof(int32_t), hipMemcpyHostToDevice));

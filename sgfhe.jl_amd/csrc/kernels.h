@@ -308,7 +308,7 @@ k_extprod(const uint64_t *__restrict__ dig, const int32_t *__restrict__ keyk,
 #ifdef SGFHE_ACC0_32
     int32_t acc0[E];  // column 0 summed like column 1, Montgomery-reduced per phase (< 2.9 * 2^29)
 #else
-    int64_t acc0[E];  // 64-bit NTT-domain sum of column 0 over the four phases (|.| < 1.85 * 2^60)
+    int64_t acc0[E];  // 64-bit NTT-domain sum of column 0 over the four phases (|.| < 1.98 * 2^60)
 #endif
 #pragma unroll
     for (int e = 0; e < E; e++) { acc0[e] = 0; z1[e * T] = 0; }
@@ -381,13 +381,13 @@ k_extprod(const uint64_t *__restrict__ dig, const int32_t *__restrict__ keyk,
             load_key();
         }
 
-        // 3. pointwise: z_c += U * K[ph][c]   (fhe.jl:527-528 in the NTT domain), |U| < 3.7 * 2^29,
+        // 3. pointwise: z_c += U * K[ph][c]   (fhe.jl:527-528 in the NTT domain), |U| < 3.95 * 2^29,
         //    |K| <= p / 2
         //    column 0: 64-bit multiply-accumulate (one v_mad_i64_i32 per product), reduced once after
         //              the loop.  (SGFHE_ACC0_32: Montgomery-reduced per phase into 16 registers
         //              instead of 32 -- 104 VGPRs and no spills, but 2 more multiplies per product:
         //              measured 230.8 against 225.1 us per launch, profiles/r02_acc32_* vs r02_v1_*.)
-        //    column 1: Montgomery-reduced (|.| < 0.74 * 2^29) and added to the LDS accumulator
+        //    column 1: Montgomery-reduced (|.| < 0.75 * 2^29) and added to the LDS accumulator
         const Mod &mdp = md;
 #pragma unroll
         for (int h = 0; h < E / 4; h++) {
@@ -413,7 +413,7 @@ k_extprod(const uint64_t *__restrict__ dig, const int32_t *__restrict__ keyk,
     //    P_c = (M/p)^-1 * sum_row u_row (*) C_row[c]  mod p
     int32_t z[2][E];
     // With 16 points per thread the first inverse pass takes column 0 as the Montgomery step
-    // leaves it (|.| < 1.43 * 2^29) and reduces six more of its sums instead (ntt.h inv_red_mask).
+    // leaves it (|.| < 1.49 * 2^29) and reduces six more of its sums instead (ntt.h inv_red_mask).
 #ifdef SGFHE_ACC0_32
     constexpr bool WIDE0 = false;
 #else
@@ -425,10 +425,10 @@ k_extprod(const uint64_t *__restrict__ dig, const int32_t *__restrict__ keyk,
 #ifdef SGFHE_ACC0_32
         z[0][e] = sred(acc0[e], md);
 #else
-        const int32_t r0 = sredc(acc0[e], md);   // |REDC| < 1.43 * 2^29
+        const int32_t r0 = sredc(acc0[e], md);   // |REDC| < 1.49 * 2^29
         z[0][e] = WIDE0 ? r0 : sred(r0, md);
 #endif
-        z[1][e] = sred(z1[e * T], md);           // four phases: < 2.95 * 2^29
+        z[1][e] = sred(z1[e * T], md);           // four phases: < 2.99 * 2^29
     }
     SGFHE_SYNC();  // every thread has taken its z_1 out of the buffer the exchanges now reuse
     ntt_inverse<LOGM, 2, LE, WIDE0>(z, lds, P.twi, tid, md);  // |z| < 1.4 * 2^29
@@ -939,7 +939,7 @@ k_inv_column(const int32_t *__restrict__ zpart, uint32_t *__restrict__ yres,
 #pragma unroll
         for (int ph = 0; ph < 4; ph++) {
             const int4 v = reinterpret_cast<const int4 *>(zp + (size_t)ph * 2 * M)[h];
-            acc[0] += v.x; acc[1] += v.y; acc[2] += v.z; acc[3] += v.w;  // < 2.95 * 2^29
+            acc[0] += v.x; acc[1] += v.y; acc[2] += v.z; acc[3] += v.w;  // < 2.99 * 2^29
         }
 #pragma unroll
         for (int t = 0; t < 4; t++) z[0][4 * h + t] = sred(acc[t], md);
@@ -1412,7 +1412,7 @@ k_polymul_s(const ulonglong2 *__restrict__ acan, const int32_t *__restrict__ sha
     }
     ntt_forward<LOGM, 1, LOGE>(x, lds, P.twf, tid, md);
 #pragma unroll
-    for (int e = 0; e < E; e++)  // |x| < 3.7 * 2^29, |shat| <= p / 2: |product R^-1| < 0.74 * 2^29
+    for (int e = 0; e < E; e++)  // |x| < 3.95 * 2^29, |shat| <= p / 2: |product R^-1| < 0.75 * 2^29
         x[0][e] = smont(x[0][e], shat[(size_t)pi * M + E * tid + e], md);
     __syncthreads();
     ntt_inverse<LOGM, 1, LOGE>(x, lds, P.twi, tid, md);

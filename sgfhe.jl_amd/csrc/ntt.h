@@ -36,6 +36,10 @@
 #define SGFHE_SYNC() __syncthreads()
 #endif
 
+#ifndef SGFHE_FWD_RADIX4
+#define SGFHE_FWD_RADIX4 1
+#endif
+
 namespace sgfhe {
 
 template <int LOGE>
@@ -130,6 +134,53 @@ __device__ __forceinline__ void fwd_stage(int32_t (&x)[NP][1 << LOGE],
                 bfly_fwd(x[q][e0], x[q][e0 | (1 << B)], t[NG - 1 + g], md);
             }
 }
+// Two forward stages (local bits BH and BH - 1) as one radix-4 step with the second stage's
+// products deferred: with X0..X3 = x[e0], x[e0 | lo], x[e0 | hi], x[e0 | hi | lo] and the twiddles
+// wA (stage BH), wB0 / wB1 (stage BH - 1, the two children of wA in the table's binary tree),
+//   u = wA X2,  a = X0 + u,  b = X0 - u,
+//   s = wB0 X1 + (wA wB0) X3,   r = wB1 X1 - (wA wB1) X3      (one Montgomery reduction each: the two
+//                                                               64-bit products are summed first)
+//   outputs a + s, a - s, b + r, b - r
+// -- 17 instructions where four radix-2 butterflies take 20.  tp holds the product twiddles
+// wA wB0 and -(wA wB1) (table tw + 2 m, same indexing as tw).  Any int32 X1..X3; the sums stay
+// below 2^60.  |u| <= |X2| / 16 + p / 2,  |s|, |r| <= (|X1| + |X3|) / 16 + p / 2.
+template <int NP, int LOGE, int BH>
+__device__ __forceinline__ void fwd_step4(int32_t (&x)[NP][1 << LOGE], const int32_t (&t)[(1 << LOGE) - 1],
+                                          const int32_t (&tp)[(1 << LOGE) - 1], const Mod &md) {
+    static_assert(BH >= 1, "a radix-4 step covers local bits BH and BH - 1");
+    constexpr int NGA = 1 << (LOGE - 1 - BH);
+    constexpr int LO = 1 << (BH - 1), HI = 1 << BH;
+#pragma unroll
+    for (int q = 0; q < NP; q++)
+#pragma unroll
+        for (int g = 0; g < NGA; g++)
+#pragma unroll
+            for (int l = 0; l < LO; l++) {
+                const int e0 = (g << (BH + 1)) | l;
+                const int32_t wA = t[NGA - 1 + g];
+                const int32_t wB0 = t[2 * NGA - 1 + 2 * g], wB1 = t[2 * NGA - 1 + 2 * g + 1];
+                const int32_t P0 = tp[2 * NGA - 1 + 2 * g], P1 = tp[2 * NGA - 1 + 2 * g + 1];
+                const int32_t X0 = x[q][e0], X1 = x[q][e0 | LO], X2 = x[q][e0 | HI], X3 = x[q][e0 | HI | LO];
+                const int32_t u = smont(X2, wA, md);
+                const int32_t a = X0 + u, b = X0 - u;
+                const int32_t s_ = sredc((int64_t)X1 * wB0 + (int64_t)X3 * P0, md);
+                const int32_t r_ = sredc((int64_t)X1 * wB1 + (int64_t)X3 * P1, md);
+                x[q][e0] = a + s_;
+                x[q][e0 | LO] = a - s_;
+                x[q][e0 | HI] = b + r_;
+                x[q][e0 | HI | LO] = b - r_;
+            }
+}
+// registers whose index has the local bits BH and BH - 1 clear: the X0 inputs of fwd_step4<BH>
+template <int NP, int LOGE, int BH>
+__device__ __forceinline__ void fwd_reduce_x0(int32_t (&x)[NP][1 << LOGE], const Mod &md) {
+#pragma unroll
+    for (int q = 0; q < NP; q++)
+#pragma unroll
+        for (int e = 0; e < (1 << LOGE); e++)
+            if ((e & (3 << (BH - 1))) == 0) x[q][e] = sred_floor(x[q][e], md);
+}
+
 // REDMASK: bit e0 set = the sum X' of the butterfly whose X sits in register e0 is range-reduced
 // (REDMASK0: the same for polynomial 0, which may arrive with a different bound)
 template <int NP, int LOGE, int B, uint32_t REDMASK, uint32_t REDMASK0>
@@ -157,7 +208,8 @@ __device__ __forceinline__ void fwd_stages(int32_t (&x)[NP][1 << LOGE],
 }
 // The X inputs of the first stage of a full pass (register index bit LOGE-1 clear) are pulled back
 // to [0, 2^29] (`sred_floor`: any int32 in, three instructions); the stages of the pass then add at
-// most 0.73 * 2^29 each, so a transform hands out |x| < 3.7 * 2^29 (tests/rns_model.py RangeModel).
+// most 0.73 * 2^29 each, so a radix-2 pass hands out |x| < 3.7 * 2^29; with the radix-4 steps of
+// FwdPasses a transform hands out |x| < 3.95 * 2^29 (tests/rns_model.py RangeModel).
 template <int NP, int LOGE>
 __device__ __forceinline__ void fwd_reduce_x(int32_t (&x)[NP][1 << LOGE], const Mod &md) {
 #pragma unroll
@@ -177,7 +229,7 @@ __device__ __forceinline__ void fwd_reduce_x(int32_t (&x)[NP][1 << LOGE], const 
 //    and returns to the input bound; tests/rns_model.py RangeModel re-derives the bounds.)
 //  * the same pass as the LAST step of a transform (LASTRED = 2: its outputs only have to stay
 //    below 1.4 * 2^29 for the epilogues) reduces 9: in stage 3 only registers 0, 2 and 3.
-//  * the same pass as the FIRST step with inputs up to 1.45 * 2^29 (LASTRED = 3: k_extprod's
+//  * the same pass as the FIRST step with inputs up to 1.5 * 2^29 (LASTRED = 3: k_extprod's
 //    column 0 straight out of its Montgomery reduction, without the input `sred`) reduces 20:
 //    stage 0 all, stage 1 none, stage 2 the registers with bit 1 clear, stage 3 all.
 //  * any other run of stages reduces every sum of every second stage (counted from its first
@@ -284,8 +336,18 @@ struct FwdPasses {
     static __device__ __forceinline__ void run(int32_t (&x)[NP][1 << LOGE], uint32_t *lds,
                                                const int32_t *tw, int tid, const Mod &md,
                                                const F &before_last) {
-        int32_t t[(1 << LOGE) - 1];
+        int32_t t[(1 << LOGE) - 1], tp[(1 << LOGE) - 1];
         load_twiddles<LOGM, LOGE, SCUR, LOGE - 1, 0>(t, tw, (uint32_t)tid >> SCUR);
+        // Product twiddles of the radix-4 steps (table tw + 2 m).  A pass whose twiddles are
+        // wave-uniform keeps them in scalar registers and runs both of its step pairs as radix-4
+        // (LOGE = 4: ten products); a pass with per-lane twiddles only its first pair (two more
+        // vector registers).
+        constexpr bool UNIFORM = (1 << SCUR) >= 64;
+        constexpr bool TWO_STEPS = SGFHE_FWD_RADIX4 && LOGE == 4 && UNIFORM;
+        if constexpr (SGFHE_FWD_RADIX4) {
+            load_twiddles<LOGM, LOGE, SCUR, LOGE - 2, LOGE - 2>(tp, tw + (2 << LOGM), (uint32_t)tid >> SCUR);
+            if constexpr (TWO_STEPS) load_twiddles<LOGM, LOGE, SCUR, 0, 0>(tp, tw + (2 << LOGM), (uint32_t)tid >> SCUR);
+        }
         if constexpr (SCUR < LOGE) before_last();
         lds_store<LOGM, NP, LOGE, SPREV>(x, lds, tid);
         exchange_sync<LOGE, SCUR>();
@@ -295,8 +357,21 @@ struct FwdPasses {
         // no longer sees the 32 x 32 -> 64 multiply-add of `sredc` and emulates a 64 x 64 one.
         Mod mdl = md;
         mdl.negp += (int32_t)opaque_zero_s();
-        fwd_reduce_x<NP, LOGE>(x, mdl);
-        fwd_stages<NP, LOGE, LOGE - 1, 0>(x, t, mdl);
+        if constexpr (TWO_STEPS) {
+            // X0 inputs of each step pulled back to [0, 2^29]: every value of the pass stays below
+            // 2.5 * 2^29 (tests/rns_model.py RangeModel)
+            fwd_reduce_x0<NP, LOGE, 3>(x, mdl);
+            fwd_step4<NP, LOGE, 3>(x, t, tp, mdl);
+            fwd_reduce_x0<NP, LOGE, 1>(x, mdl);
+            fwd_step4<NP, LOGE, 1>(x, t, tp, mdl);
+        } else if constexpr (SGFHE_FWD_RADIX4) {
+            fwd_reduce_x<NP, LOGE>(x, mdl);
+            fwd_step4<NP, LOGE, LOGE - 1>(x, t, tp, mdl);
+            fwd_stages<NP, LOGE, LOGE - 3, 0>(x, t, mdl);
+        } else {
+            fwd_reduce_x<NP, LOGE>(x, mdl);
+            fwd_stages<NP, LOGE, LOGE - 1, 0>(x, t, mdl);
+        }
         if constexpr (SCUR >= LOGE)
             FwdPasses<LOGM, NP, LOGE, SCUR, SCUR - LOGE>::run(x, lds, tw, tid, md, before_last);
     }
@@ -304,7 +379,7 @@ struct FwdPasses {
 // inverse passes S = SCUR, SCUR + LOGE, ..., SLAST; data arrives in registers in layout SCUR and
 // the twiddles of pass SCUR in t
 // FINAL: the pass S = SLAST is the last step of the transform (no partial pass follows);
-// WIDE0: polynomial 0 enters the first pass with |x| <= 1.45 * 2^29 instead of 0.75 (LOGE = 4 only)
+// WIDE0: polynomial 0 enters the first pass with |x| <= 1.5 * 2^29 instead of 0.75 (LOGE = 4 only)
 template <int LOGM, int NP, int LOGE, int SCUR, int SLAST, bool FINAL = false, bool WIDE0 = false>
 struct InvPasses {
     static __device__ __forceinline__ void run(int32_t (&x)[NP][1 << LOGE], uint32_t *lds,
@@ -326,7 +401,7 @@ struct InvPasses {
 };
 
 // Forward transform.  In: x[q][e] = coefficient tid + T e of polynomial q, |x| <= 1.01 * 2^29.
-// Out: x[q][e] = slot E tid + e, |x| < 3.7 * 2^29.  `lds` must hold NP * m words.
+// Out: x[q][e] = slot E tid + e, |x| < 3.95 * 2^29.  `lds` must hold NP * m words.
 template <int LOGM, int NP, int LOGE, class F = NoHook>
 __device__ __forceinline__ void ntt_forward(int32_t (&x)[NP][1 << LOGE], uint32_t *lds,
                                             const int32_t *tw, int tid, const Mod &md,
@@ -343,7 +418,7 @@ __device__ __forceinline__ void ntt_forward(int32_t (&x)[NP][1 << LOGE], uint32_
 }
 
 // Inverse transform (unscaled).  In: slots E tid + e, |x| <= 0.75 * 2^29 (WIDE0: polynomial 0 up
-// to 1.45 * 2^29; needs LOGE = 4 and at least one full pass).  Out: coefficient
+// to 1.5 * 2^29; needs LOGE = 4 and at least one full pass).  Out: coefficient
 // tid + T e, |x| < 1.4 * 2^29, in registers; the last LDS accesses of every thread were loads in
 // layout STOP.
 template <int LOGM, int NP, int LOGE, bool WIDE0 = false>

@@ -109,13 +109,21 @@ class Consts:
             R1 = (1 << 32) % p
             twf = np.zeros(m, dtype=np.int64)
             twi = np.zeros(m, dtype=np.int64)
+            pf = [0] * m
             pw = ipw = 1
             for t in range(m):
                 br = bitrev(t, self.logm)
                 twf[br] = centre(pw * R1, p)          # Montgomery form, centred
                 twi[br] = centre(ipw * R1, p)
+                pf[br] = pw
                 pw = pw * psi % p
                 ipw = ipw * ipsi % p
+            # product twiddles of the forward radix-4 steps (table tw + 2 m on the device):
+            # twfp[j] = +-tw[j >> 1] tw[j], minus for odd j
+            twfp = np.zeros(m, dtype=np.int64)
+            for j in range(2, m):
+                v = pf[j >> 1] * pf[j] % p * R1 % p
+                twfp[j] = centre((p - v) % p if j & 1 else v, p)
             Rinv = pow(R1, p - 2, p)
             Mi = prod // p % p
             ei = pow(Mi, p - 2, p)
@@ -126,7 +134,7 @@ class Consts:
                 sRr=centre(-((self.s + self.xmax) % p) * Rinv, p),
                 hoff=(p - 1) // 2 if i == NPR - 1 else 0, r1=centre(R1, p), r2=centre(R1 * R1, p),
                 r3=centre(R1 * R1 * R1, p), qmodp=centre(Q, p), kappaR=centre(kappa * R1, p),
-                minvR=centre(minv * R1, p), twf=twf, twi=twi, psi=psi, kappa=kappa, ei=ei))
+                minvR=centre(minv * R1, p), twf=twf, twi=twi, twfp=twfp, psi=psi, kappa=kappa, ei=ei))
 
     def digits_of(self, acc):
         x = (acc + self.off) % self.Q
@@ -231,7 +239,7 @@ def inv_red_mask(loge, B, bfirst, bhi, lastred):
         for e0 in range(E):
             if e0 & (1 << B):
                 continue
-            if lastred == 3:        # first pass, inputs up to 1.45 * 2^29
+            if lastred == 3:        # first pass, inputs up to 1.5 * 2^29
                 red = B == 0 or B == 3 or (B == 2 and (e0 & 2) == 0)
             else:
                 red = ((e0 & 1) == 0) if B == 1 else ((e0 & 3) == 1) if B == 2 else \
@@ -286,20 +294,51 @@ class NttModel:
                 else:
                     x[:, e0], x[:, e1] = bfly_inv(x[:, e0], x[:, e1], w, P, e0 in red)
 
+    def step4(self, x, tw, twp, P, BH, S):
+        """ntt.h fwd_step4: the forward stages on local bits BH and BH - 1 as one radix-4 step, the
+        products of the second stage summed in 64 bits before one Montgomery reduction."""
+        hi = self.tid >> S
+        nga = 1 << (self.LOGE - 1 - BH)
+        base_a = (1 << (self.LOGM - 1 - S - BH)) + (hi << (self.LOGE - 1 - BH))
+        base_b = (1 << (self.LOGM - S - BH)) + (hi << (self.LOGE - BH))
+        lo, hb = 1 << (BH - 1), 1 << BH
+        for g in range(nga):
+            wA = tw[base_a + g]
+            wB0, wB1 = tw[base_b + 2 * g], tw[base_b + 2 * g + 1]
+            P0, P1 = twp[base_b + 2 * g], twp[base_b + 2 * g + 1]
+            for l in range(lo):
+                e0 = (g << (BH + 1)) | l
+                X0, X1, X2, X3 = (i32(x[:, e]) for e in (e0, e0 | lo, e0 | hb, e0 | hb | lo))
+                u = smont(X2, wA, P)
+                a, b = i32(X0 + u), i32(X0 - u)
+                s_ = sredc(X1 * np.asarray(wB0, dtype=np.int64) + X3 * np.asarray(P0, dtype=np.int64), P)
+                r_ = sredc(X1 * np.asarray(wB1, dtype=np.int64) + X3 * np.asarray(P1, dtype=np.int64), P)
+                x[:, e0], x[:, e0 | lo] = i32(a + s_), i32(a - s_)
+                x[:, e0 | hb], x[:, e0 | hb | lo] = i32(b + r_), i32(b - r_)
+
     def forward(self, x, tw, P):
         """x[tid, e] = coefficient tid + T e -> slot E tid + e."""
         x = np.asarray(x, dtype=np.int64).copy()
+        twp = P["twfp"]
         lds = np.zeros(self.M, dtype=np.int64)
         blo = 0 if self.RHO == 0 else self.LOGE - self.RHO
         for B in range(self.LOGE - 1, blo - 1, -1):
             self.stage(x, tw, P, B, self.STOP, True)
         sprev, S = self.STOP, self.SFIRST
+        E = self.E
         while S >= 0:
             self.store(x, lds, sprev)
             x = self.load(lds, S)
-            x[:, :self.E // 2] = sred_floor(x[:, :self.E // 2], P)   # fwd_reduce_x
-            for B in range(self.LOGE - 1, -1, -1):
-                self.stage(x, tw, P, B, S, True)
+            if self.LOGE == 4 and (1 << S) >= 64:          # wave-uniform twiddles: two radix-4 steps
+                for BH in (3, 1):
+                    x0 = [e for e in range(E) if (e & (3 << (BH - 1))) == 0]   # fwd_reduce_x0
+                    x[:, x0] = sred_floor(x[:, x0], P)
+                    self.step4(x, tw, twp, P, BH, S)
+            else:                                          # per-lane twiddles: one radix-4 step, then radix 2
+                x[:, :E // 2] = sred_floor(x[:, :E // 2], P)                   # fwd_reduce_x
+                self.step4(x, tw, twp, P, self.LOGE - 1, S)
+                for B in range(self.LOGE - 3, -1, -1):
+                    self.stage(x, tw, P, B, S, True)
             sprev, S = S, S - self.LOGE
         return x
 
@@ -308,7 +347,7 @@ class NttModel:
             self.stage(x, tw, P, B, S, False, inv_red_mask(self.LOGE, B, blo, bhi, lastred))
 
     def wide_ok(self):
-        """k_extprod's WIDE0: column 0 may enter the inverse transform un-reduced (|.| < 1.45 * 2^29)."""
+        """k_extprod's WIDE0: column 0 may enter the inverse transform un-reduced (|.| < 1.5 * 2^29)."""
         return self.LOGE == 4 and self.SLAST_INV >= 0 and not (self.RHO == 0 and self.STOP == 0)
 
     def inverse(self, x, tw, P, wide=False):
@@ -368,16 +407,23 @@ class RangeModel:
         first = N.RHO if N.RHO else N.LOGE
         for _ in range(first):                               # register pass: no reduction
             b = self._chk(b + b / 16 + 0.5)
-        passes = (N.SFIRST // N.LOGE + 1) if N.SFIRST >= 0 else 0
-        for _ in range(passes):
+        red = 1.0 + 3 * self.delta                           # sred_floor output: [-4 delta, 1 + 3 delta)
+        S = N.SFIRST
+        while S >= 0:
             self._chk(b)                                     # sred_floor takes any int32
-            x = 1.0 + 3 * self.delta                         # X inputs of the first stage: [-4 delta, 1 + 3 delta)
-            y = b                                            # Y inputs: any int32
-            for _s in range(N.LOGE):
-                t = y / 16 + 0.5
-                x = self._chk(x + t)
-                y = x
-            b = x
+            if N.LOGE == 4 and (1 << S) >= 64:
+                # two radix-4 steps; before each, its X0 inputs are reduced; X1..X3 are whatever
+                # the previous step (or pass) left: u <= X2 / 16 + 0.5, s <= (X1 + X3) / 16 + 0.5
+                for _step in range(2):
+                    assert 2 * b / 16 * 2 ** 29 * 2 ** 28 < 2 ** 62     # the 64-bit sum of two products
+                    b = self._chk(red + (b / 16 + 0.5) + (2 * b / 16 + 0.5))
+            else:
+                # X0, X1 reduced; radix-4 step on the top two stages, radix-2 stages below
+                x = self._chk(red + (b / 16 + 0.5) + ((red + b) / 16 + 0.5))
+                for _s in range(N.LOGE - 2):
+                    x = self._chk(x + x / 16 + 0.5)
+                b = x
+            S -= N.LOGE
         return b
 
     def inverse(self, b_in, wide=False):
@@ -590,7 +636,7 @@ class EngineModel:
                     # column 0: 64-bit accumulation over the four phases, one reduction
                     acc = sum(U[row] * keyslice[pi][row * 2] for row in range(4))
                     z = sredc(acc, P)
-                    assert int(np.max(np.abs(z))) < 1.45 * 2 ** 29
+                    assert int(np.max(np.abs(z))) < 1.5 * 2 ** 29
                     if not self.ntt.wide_ok():
                         z = sred(z, P)
                 else:

@@ -34,7 +34,7 @@ def test_ntt_model(logm, loge):
     p = P["p"]
     poly = np.random.default_rng(logm).integers(0, p, size=m, dtype=np.uint64)
     x = N.forward(N.to_regs(poly), P["twf"], P)               # i32() inside checks the int32 range
-    assert int(np.abs(x).max()) < 3.7 * 2 ** 29
+    assert int(np.abs(x).max()) < 3.95 * 2 ** 29
     got = [int(v) % p for v in x.reshape(-1)]
     Rinv = pow(1 << 32, p - 2, p)
     plain = np.array([int(w) * Rinv % p for w in P["twf"]], dtype=np.uint64)
@@ -57,10 +57,11 @@ def test_worst_case_ranges(logm, loge):
     <= 0.75 * 2^29)."""
     for p in RM.rns_primes():
         R = RM.RangeModel(logm, loge, p)
-        assert R.forward(1.01) < 3.7         # pointwise products assume |U| < 3.7 * 2^29
+        assert R.forward(1.01) < 3.95        # pointwise products assume |U| < 3.95 * 2^29: four products
+                                             # of column 0 stay below 2^61, column 1 sums to 2.99 * 2^29
         assert R.inverse(0.75) < 1.4         # the rotate-and-subtract epilogue assumes < 1.4 * 2^29
         if R.N.wide_ok():                    # k_extprod's column 0: no input reduction, 16 points per thread
-            assert R.inverse(1.45, wide=True) < 1.4
+            assert R.inverse(1.5, wide=True) < 1.4
         assert R.peak < 3.99
 
 
