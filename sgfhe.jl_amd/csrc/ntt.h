@@ -39,6 +39,9 @@
 #ifndef SGFHE_FWD_RADIX4
 #define SGFHE_FWD_RADIX4 1
 #endif
+#ifndef SGFHE_INV_RADIX4
+#define SGFHE_INV_RADIX4 1
+#endif
 
 namespace sgfhe {
 
@@ -179,6 +182,49 @@ __device__ __forceinline__ void fwd_reduce_x0(int32_t (&x)[NP][1 << LOGE], const
 #pragma unroll
         for (int e = 0; e < (1 << LOGE); e++)
             if ((e & (3 << (BH - 1))) == 0) x[q][e] = sred_floor(x[q][e], md);
+}
+
+// Two inverse (Gentleman-Sande) stages, local bits B then B + 1, as one radix-4 step.  With
+// x0..x3 = x[e0], x[e0 | lo], x[e0 | hi], x[e0 | hi | lo], the stage-B twiddles wB0 / wB1 and the
+// stage-(B+1) twiddle wA (their parent in the table's tree):
+//   s0 = x0 + x1, s1 = x2 + x3, d0 = x0 - x1, d1 = x2 - x3
+//   y0 = s0 + s1                       -> x[e0]            (a sum of four: reduced by the caller)
+//   y2 = wA (s0 - s1)                  -> x[e0 | hi]
+//   y1 = wB0 d0 + wB1 d1               -> x[e0 | lo]       (two 64-bit products summed, one reduction)
+//   y3 = (wA wB0) d0 - (wA wB1) d1     -> x[e0 | hi | lo]  (product twiddles from the table tw + 2 m)
+// 17 instructions where four radix-2 butterflies take 20, and no intermediate sum needs a range
+// reduction.  Inputs below 0.875 * 2^29 keep y0 inside `sred`'s precondition (3.5 * 2^29).
+template <int NP, int LOGE, int B>
+__device__ __forceinline__ void inv_step4(int32_t (&x)[NP][1 << LOGE], const int32_t (&t)[(1 << LOGE) - 1],
+                                          const int32_t (&tp)[(1 << LOGE) - 1], const Mod &md) {
+    constexpr int NGA = 1 << (LOGE - 2 - B);          // groups of stage B + 1
+    constexpr int LO = 1 << B, HI = 1 << (B + 1);
+#pragma unroll
+    for (int q = 0; q < NP; q++)
+#pragma unroll
+        for (int g = 0; g < NGA; g++)
+#pragma unroll
+            for (int l = 0; l < LO; l++) {
+                const int e0 = (g << (B + 2)) | l;
+                const int32_t wA = t[NGA - 1 + g];
+                const int32_t wB0 = t[2 * NGA - 1 + 2 * g], wB1 = t[2 * NGA - 1 + 2 * g + 1];
+                const int32_t P0 = tp[2 * NGA - 1 + 2 * g], P1 = tp[2 * NGA - 1 + 2 * g + 1];
+                const int32_t x0 = x[q][e0], x1 = x[q][e0 | LO], x2 = x[q][e0 | HI], x3 = x[q][e0 | HI | LO];
+                const int32_t s0 = x0 + x1, s1 = x2 + x3, d0 = x0 - x1, d1 = x2 - x3;
+                x[q][e0] = s0 + s1;
+                x[q][e0 | HI] = smont(s0 - s1, wA, md);
+                x[q][e0 | LO] = sredc((int64_t)d0 * wB0 + (int64_t)d1 * wB1, md);
+                x[q][e0 | HI | LO] = sredc((int64_t)d0 * P0 + (int64_t)d1 * P1, md);
+            }
+}
+// `sred` of the registers whose index has the local bits B and B + 1 clear: the y0 outputs of inv_step4<B>
+template <int NP, int LOGE, int B>
+__device__ __forceinline__ void inv_reduce_y0(int32_t (&x)[NP][1 << LOGE], const Mod &md) {
+#pragma unroll
+    for (int q = 0; q < NP; q++)
+#pragma unroll
+        for (int e = 0; e < (1 << LOGE); e++)
+            if ((e & (3 << B)) == 0) x[q][e] = sred(x[q][e], md);
 }
 
 // REDMASK: bit e0 set = the sum X' of the butterfly whose X sits in register e0 is range-reduced
@@ -380,22 +426,59 @@ struct FwdPasses {
 // the twiddles of pass SCUR in t
 // FINAL: the pass S = SLAST is the last step of the transform (no partial pass follows);
 // WIDE0: polynomial 0 enters the first pass with |x| <= 1.5 * 2^29 instead of 0.75 (LOGE = 4 only)
+// product twiddles of inverse pass S (table tw + 2 m): for the step on local bits 0 / 1, and on 2 / 3
+// as well where the pass runs both steps (LOGE = 4, wave-uniform twiddles)
+template <int LOGM, int LOGE, int S>
+__device__ __forceinline__ void load_inv_products(int32_t (&tp)[(1 << LOGE) - 1], const int32_t *tw, int tid) {
+#if SGFHE_INV_RADIX4
+    load_twiddles<LOGM, LOGE, S, 0, 0>(tp, tw + (2 << LOGM), (uint32_t)tid >> S);
+    if constexpr (LOGE == 4 && (1 << S) >= 64)
+        load_twiddles<LOGM, LOGE, S, 2, 2>(tp, tw + (2 << LOGM), (uint32_t)tid >> S);
+#endif
+}
 template <int LOGM, int NP, int LOGE, int SCUR, int SLAST, bool FINAL = false, bool WIDE0 = false>
 struct InvPasses {
     static __device__ __forceinline__ void run(int32_t (&x)[NP][1 << LOGE], uint32_t *lds,
                                                const int32_t *tw, int tid, const Mod &md,
-                                               const int32_t (&t)[(1 << LOGE) - 1]) {
+                                               const int32_t (&t)[(1 << LOGE) - 1],
+                                               const int32_t (&tp)[(1 << LOGE) - 1]) {
         constexpr int MODE = (FINAL && SCUR == SLAST) ? 2 : 1;
+#if SGFHE_INV_RADIX4
+        // Radix-4 steps with deferred reductions (inv_step4).  Every pass opens with one on local
+        // bits 0 and 1; a pass whose twiddles are wave-uniform (scalar registers) runs bits 2 and 3
+        // the same way, the others as radix-2 stages.  Reductions: the four-fold sums y0 after each
+        // step; in the radix-2 tail the sums of the last stage (in the final pass only those that
+        // can exceed 1.4 * 2^29).  tests/rns_model.py NttModel.inv_pass / RangeModel.inverse.
+        static_assert(!WIDE0, "the radix-4 inverse takes every polynomial below 0.75 * 2^29");
+        {
+            constexpr bool UNIFORM = (1 << SCUR) >= 64;
+            inv_step4<NP, LOGE, 0>(x, t, tp, md);
+            inv_reduce_y0<NP, LOGE, 0>(x, md);
+            if constexpr (LOGE == 4 && UNIFORM) {
+                inv_step4<NP, LOGE, 2>(x, t, tp, md);
+                inv_reduce_y0<NP, LOGE, 2>(x, md);
+            } else if constexpr (LOGE == 4) {
+                inv_stage<NP, LOGE, 2, 0u, 0u>(x, t, md);
+                // last stage: all eight sums, or in the final pass the sums of sums (registers 0..3)
+                inv_stage<NP, LOGE, 3, MODE == 2 ? 0x000Fu : 0x00FFu, MODE == 2 ? 0x000Fu : 0x00FFu>(x, t, md);
+            } else {
+                static_assert(LOGE == 3, "8 or 16 points per thread");
+                inv_stage<NP, LOGE, 2, MODE == 2 ? 0u : 0x0Fu, MODE == 2 ? 0u : 0x0Fu>(x, t, md);
+            }
+        }
+#else
         static_assert(!WIDE0 || (LOGE == 4 && !(FINAL && SLAST == 0)), "wide first pass: radix 16, not the final pass");
         inv_stages<NP, LOGE, 0, LOGE - 1, 0, MODE, (WIDE0 && SCUR == 0) ? 3 : MODE>(x, t, md);
+#endif
         if constexpr (SCUR < SLAST) {
-            int32_t tn[(1 << LOGE) - 1];
+            int32_t tn[(1 << LOGE) - 1], tpn[(1 << LOGE) - 1];
             load_twiddles<LOGM, LOGE, SCUR + LOGE, LOGE - 1, 0>(tn, tw,
                                                                 (uint32_t)tid >> (SCUR + LOGE));
+            load_inv_products<LOGM, LOGE, SCUR + LOGE>(tpn, tw, tid);
             lds_store<LOGM, NP, LOGE, SCUR>(x, lds, tid);
             exchange_sync<LOGE, SCUR>();
             lds_load<LOGM, NP, LOGE, SCUR + LOGE>(x, lds, tid);
-            InvPasses<LOGM, NP, LOGE, SCUR + LOGE, SLAST, FINAL, WIDE0>::run(x, lds, tw, tid, md, tn);
+            InvPasses<LOGM, NP, LOGE, SCUR + LOGE, SLAST, FINAL, WIDE0>::run(x, lds, tw, tid, md, tn, tpn);
         }
     }
 };
@@ -426,15 +509,17 @@ __device__ __forceinline__ void ntt_inverse(int32_t (&x)[NP][1 << LOGE], uint32_
                                             const int32_t *tw, int tid, const Mod &md) {
     using G = NttGeom<LOGM, LOGE>;
     if constexpr (G::RHO == 0) {
-        int32_t t[(1 << LOGE) - 1];
+        int32_t t[(1 << LOGE) - 1], tp[(1 << LOGE) - 1];
         load_twiddles<LOGM, LOGE, 0, LOGE - 1, 0>(t, tw, (uint32_t)tid);
-        InvPasses<LOGM, NP, LOGE, 0, G::STOP, true, WIDE0>::run(x, lds, tw, tid, md, t);
+        load_inv_products<LOGM, LOGE, 0>(tp, tw, tid);
+        InvPasses<LOGM, NP, LOGE, 0, G::STOP, true, WIDE0>::run(x, lds, tw, tid, md, t, tp);
     } else {
         int32_t tp[(1 << LOGE) - 1];
         if constexpr (G::SLAST_INV >= 0) {
-            int32_t t[(1 << LOGE) - 1];
+            int32_t t[(1 << LOGE) - 1], tq[(1 << LOGE) - 1];   // (tp is the partial pass's twiddle array)
             load_twiddles<LOGM, LOGE, 0, LOGE - 1, 0>(t, tw, (uint32_t)tid);
-            InvPasses<LOGM, NP, LOGE, 0, G::SLAST_INV, false, WIDE0>::run(x, lds, tw, tid, md, t);
+            load_inv_products<LOGM, LOGE, 0>(tq, tw, tid);
+            InvPasses<LOGM, NP, LOGE, 0, G::SLAST_INV, false, WIDE0>::run(x, lds, tw, tid, md, t, tq);
             load_twiddles<LOGM, LOGE, G::STOP, LOGE - 1, LOGE - G::RHO>(tp, tw, 0u);
             lds_store<LOGM, NP, LOGE, G::SLAST_INV>(x, lds, tid);
             SGFHE_SYNC();

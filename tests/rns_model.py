@@ -109,21 +109,24 @@ class Consts:
             R1 = (1 << 32) % p
             twf = np.zeros(m, dtype=np.int64)
             twi = np.zeros(m, dtype=np.int64)
-            pf = [0] * m
+            pf, pv = [0] * m, [0] * m
             pw = ipw = 1
             for t in range(m):
                 br = bitrev(t, self.logm)
                 twf[br] = centre(pw * R1, p)          # Montgomery form, centred
                 twi[br] = centre(ipw * R1, p)
-                pf[br] = pw
+                pf[br], pv[br] = pw, ipw
                 pw = pw * psi % p
                 ipw = ipw * ipsi % p
             # product twiddles of the forward radix-4 steps (table tw + 2 m on the device):
             # twfp[j] = +-tw[j >> 1] tw[j], minus for odd j
             twfp = np.zeros(m, dtype=np.int64)
+            twip = np.zeros(m, dtype=np.int64)
             for j in range(2, m):
                 v = pf[j >> 1] * pf[j] % p * R1 % p
                 twfp[j] = centre((p - v) % p if j & 1 else v, p)
+                v = pv[j >> 1] * pv[j] % p * R1 % p
+                twip[j] = centre((p - v) % p if j & 1 else v, p)
             Rinv = pow(R1, p - 2, p)
             Mi = prod // p % p
             ei = pow(Mi, p - 2, p)
@@ -134,7 +137,7 @@ class Consts:
                 sRr=centre(-((self.s + self.xmax) % p) * Rinv, p),
                 hoff=(p - 1) // 2 if i == NPR - 1 else 0, r1=centre(R1, p), r2=centre(R1 * R1, p),
                 r3=centre(R1 * R1 * R1, p), qmodp=centre(Q, p), kappaR=centre(kappa * R1, p),
-                minvR=centre(minv * R1, p), twf=twf, twi=twi, twfp=twfp, psi=psi, kappa=kappa, ei=ei))
+                minvR=centre(minv * R1, p), twf=twf, twi=twi, twfp=twfp, twip=twip, psi=psi, kappa=kappa, ei=ei))
 
     def digits_of(self, acc):
         x = (acc + self.off) % self.Q
@@ -346,22 +349,63 @@ class NttModel:
         for B in range(blo, bhi + 1):
             self.stage(x, tw, P, B, S, False, inv_red_mask(self.LOGE, B, blo, bhi, lastred))
 
+    def step4_inv(self, x, tw, twp, P, B, S):
+        """ntt.h inv_step4: the Gentleman-Sande stages on local bits B and B + 1 as one radix-4 step:
+        y0 = x0 + x1 + x2 + x3, y2 = wA ((x0 + x1) - (x2 + x3)), and the two outputs that go through
+        both twiddles from 64-bit sums of two products, one Montgomery reduction each."""
+        hi = self.tid >> S
+        nga = 1 << (self.LOGE - 2 - B)
+        base_a = (1 << (self.LOGM - 2 - S - B)) + (hi << (self.LOGE - 2 - B))
+        base_b = (1 << (self.LOGM - 1 - S - B)) + (hi << (self.LOGE - 1 - B))
+        lo, hb = 1 << B, 1 << (B + 1)
+        for g in range(nga):
+            wA = np.asarray(tw[base_a + g], dtype=np.int64)
+            wB0, wB1 = (np.asarray(tw[base_b + 2 * g + k], dtype=np.int64) for k in (0, 1))
+            P0, P1 = (np.asarray(twp[base_b + 2 * g + k], dtype=np.int64) for k in (0, 1))
+            for l in range(lo):
+                e0 = (g << (B + 2)) | l
+                x0, x1, x2, x3 = (i32(x[:, e]) for e in (e0, e0 | lo, e0 | hb, e0 | hb | lo))
+                s0, s1, d0, d1 = i32(x0 + x1), i32(x2 + x3), i32(x0 - x1), i32(x2 - x3)
+                x[:, e0] = i32(s0 + s1)
+                x[:, e0 | hb] = smont(i32(s0 - s1), wA, P)
+                x[:, e0 | lo] = sredc(d0 * wB0 + d1 * wB1, P)
+                x[:, e0 | hb | lo] = sredc(d0 * P0 + d1 * P1, P)
+
     def wide_ok(self):
-        """k_extprod's WIDE0: column 0 may enter the inverse transform un-reduced (|.| < 1.5 * 2^29)."""
-        return self.LOGE == 4 and self.SLAST_INV >= 0 and not (self.RHO == 0 and self.STOP == 0)
+        """(the radix-4 inverse has no un-reduced entry: every polynomial arrives below 0.75 * 2^29)"""
+        return False
+
+    def inv_pass(self, x, tw, P, S, final):
+        """One full inverse pass over [S, S + LOGE) as ntt.h InvPasses runs it."""
+        E = self.E
+        twp = P["twip"]
+        sums4 = lambda B: [e for e in range(E) if (e & (3 << B)) == 0]      # the y0 registers of a step on (B, B + 1)
+        self.step4_inv(x, tw, twp, P, 0, S)
+        x[:, sums4(0)] = sred(x[:, sums4(0)], P)
+        if self.LOGE == 4 and (1 << S) >= 64:          # wave-uniform twiddles: second radix-4 step
+            self.step4_inv(x, tw, twp, P, 2, S)
+            x[:, sums4(2)] = sred(x[:, sums4(2)], P)
+            return
+        for B in range(2, self.LOGE):                  # radix-2 stages above the step
+            last = B == self.LOGE - 1
+            if not last:
+                red = ()
+            elif final:                                # outputs only have to stay below 1.4 * 2^29:
+                red = [e for e in range(E) if (e & (3 << (B - 1))) == 0] if self.LOGE == 4 else ()
+            else:
+                red = [e for e in range(E) if not e & (1 << B)]
+            self.stage(x, tw, P, B, S, False, red)
 
     def inverse(self, x, tw, P, wide=False):
-        """slots E tid + e -> coefficient tid + T e (unscaled).  wide: ntt_inverse<..., WIDE0> for
-        this polynomial."""
-        assert not wide or self.wide_ok()
+        """slots E tid + e -> coefficient tid + T e (unscaled)."""
+        assert not wide
         x = np.asarray(x, dtype=np.int64).copy()
         lds = np.zeros(self.M, dtype=np.int64)
         if self.SLAST_INV >= 0:
             S = 0
             while True:
                 final = (not self.RHO) and S >= self.SLAST_INV     # InvPasses<..., FINAL>
-                mode = 3 if (wide and S == 0) else (2 if final else 1)
-                self.inv_stages(x, tw, P, S, 0, self.LOGE - 1, mode)
+                self.inv_pass(x, tw, P, S, final)
                 if S >= self.SLAST_INV:
                     break
                 self.store(x, lds, S)
@@ -427,32 +471,75 @@ class RangeModel:
         return b
 
     def inverse(self, b_in, wide=False):
+        """Bounds of the radix-4 inverse (NttModel.inv_pass) from inputs below b_in * 2^29, per
+        register: step sums y0 = x0 + x1 + x2 + x3, y2 = smont(s0 - s1), y1 / y3 = one reduction of
+        a sum of two products of differences."""
         N = self.N
-        E = N.E
-        assert not wide or N.wide_ok()
+        E, LOGE = N.E, N.LOGE
+        assert not wide
+        red_out = 0.5 + 4 * self.delta
 
-        def run(bv, blo, bhi, lastred):
-            for B in range(blo, bhi + 1):
-                mask = inv_red_mask(N.LOGE, B, blo, bhi, lastred)
-                nb = list(bv)
-                for e0 in range(E):
-                    if e0 & (1 << B):
-                        continue
-                    e1 = e0 | (1 << B)
-                    red = e0 in mask
-                    s = self._chk(bv[e0] + bv[e1], 3.5 if red else 4.0)
-                    nb[e0] = (0.5 + 4 * self.delta) if red else s
-                    nb[e1] = s / 16 + 0.5
-                bv = nb
+        def step4(bv, B):
+            nb = list(bv)
+            lo, hb = 1 << B, 1 << (B + 1)
+            for e0 in range(E):
+                if e0 & (lo | hb):
+                    continue
+                x0, x1, x2, x3 = bv[e0], bv[e0 | lo], bv[e0 | hb], bv[e0 | hb | lo]
+                s0, s1 = self._chk(x0 + x1), self._chk(x2 + x3)
+                d0, d1 = s0, s1                                   # |x0 - x1| <= |x0| + |x1|
+                nb[e0] = self._chk(s0 + s1)
+                nb[e0 | hb] = self._chk(s0 + s1) / 16 + 0.5       # smont of s0 - s1
+                assert (d0 + d1) * 2 ** 57 < 2 ** 62              # 64-bit sum of two products
+                nb[e0 | lo] = nb[e0 | hb | lo] = (d0 + d1) / 16 + 0.5
+            return nb
+
+        def reduce(bv, regs):
+            for e in regs:
+                bv[e] = self.sred(bv[e])                          # checks the 3.5 precondition
             return bv
 
+        def radix2(bv, B, red):
+            nb = list(bv)
+            for e0 in range(E):
+                if e0 & (1 << B):
+                    continue
+                e1 = e0 | (1 << B)
+                ssum = self._chk(bv[e0] + bv[e1], 3.5 if e0 in red else 4.0)
+                nb[e0] = red_out if e0 in red else ssum
+                nb[e1] = ssum / 16 + 0.5
+            return nb
+
         bv = [b_in] * E
-        full = (N.SLAST_INV // N.LOGE + 1) if N.SLAST_INV >= 0 else 0
-        for i in range(full):
-            final = (not N.RHO) and i == full - 1
-            bv = [max(run(bv, 0, N.LOGE - 1, 3 if (wide and i == 0) else (2 if final else 1)))] * E
+        if N.SLAST_INV >= 0:
+            S = 0
+            while True:
+                final = (not N.RHO) and S >= N.SLAST_INV
+                bv = step4(bv, 0)
+                bv = reduce(bv, [e for e in range(E) if (e & 3) == 0])
+                if LOGE == 4 and (1 << S) >= 64:
+                    bv = step4(bv, 2)
+                    bv = reduce(bv, [e for e in range(E) if (e & 12) == 0])
+                else:
+                    for B in range(2, LOGE):
+                        last = B == LOGE - 1
+                        if not last:
+                            red = ()
+                        elif final:
+                            red = [e for e in range(E) if (e & (3 << (B - 1))) == 0] if LOGE == 4 else ()
+                        else:
+                            red = [e for e in range(E) if not e & (1 << B)]
+                        bv = radix2(bv, B, red)
+                if S >= N.SLAST_INV:
+                    break
+                bv = [max(bv)] * E                                # the exchange mixes the registers
+                S += LOGE
         if N.RHO:
-            bv = run(bv, N.LOGE - N.RHO, N.LOGE - 1, False)
+            bv = [max(bv)] * E
+            blo, bhi = LOGE - N.RHO, LOGE - 1
+            for B in range(blo, bhi + 1):
+                mask = inv_red_mask(LOGE, B, blo, bhi, False)
+                bv = radix2(bv, B, [e for e in range(E) if e in mask])
         return max(bv)
 
 
