@@ -414,8 +414,12 @@ k_extprod(const uint64_t *__restrict__ dig, const int32_t *__restrict__ keyk,
     int32_t z[2][E];
     // With 16 points per thread the first inverse pass takes column 0 as the Montgomery step
     // leaves it (|.| < 1.49 * 2^29) and reduces six more of its sums instead (ntt.h inv_red_mask).
-#if defined(SGFHE_ACC0_32) || SGFHE_INV_RADIX4
-    constexpr bool WIDE0 = false;   // (the radix-4 inverse reduces column 0 on entry like column 1)
+#if defined(SGFHE_ACC0_32)
+    constexpr bool WIDE0 = false;
+#elif SGFHE_INV_RADIX4
+    // (the radix-4 inverse reduces column 0 on entry like column 1)
+    constexpr bool WIDE0 = !SGFHE_INV_R4(LOGM) && LE == 4 && NttGeom<LOGM, LE>::SLAST_INV >= 0 &&
+                           !(NttGeom<LOGM, LE>::RHO == 0 && NttGeom<LOGM, LE>::STOP == 0);
 #else
     constexpr bool WIDE0 = LE == 4 && NttGeom<LOGM, LE>::SLAST_INV >= 0 &&
                            !(NttGeom<LOGM, LE>::RHO == 0 && NttGeom<LOGM, LE>::STOP == 0);

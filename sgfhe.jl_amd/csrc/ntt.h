@@ -42,6 +42,16 @@
 #ifndef SGFHE_INV_RADIX4
 #define SGFHE_INV_RADIX4 1
 #endif
+// Forward passes with per-lane twiddles take the radix-4 form (two more vector registers) only where
+// k_extprod keeps its registers without spilling: hipcc spills 16-20 bytes at m = 4096 and 16384.
+#ifndef SGFHE_FWD_VEC4
+#define SGFHE_FWD_VEC4(LOGM) ((LOGM) != 12 && (LOGM) != 14)
+#endif
+// The inverse keeps its radix-2 form (with the searched reduction pattern and the un-reduced entry
+// of column 0) at m = 4096, where the radix-4 steps cost k_extprod 20-24 bytes of scratch.
+#ifndef SGFHE_INV_R4
+#define SGFHE_INV_R4(LOGM) ((LOGM) != 12)
+#endif
 
 namespace sgfhe {
 
@@ -390,7 +400,7 @@ struct FwdPasses {
         // vector registers).
         constexpr bool UNIFORM = (1 << SCUR) >= 64;
         constexpr bool TWO_STEPS = SGFHE_FWD_RADIX4 && LOGE == 4 && UNIFORM;
-        if constexpr (SGFHE_FWD_RADIX4) {
+        if constexpr (SGFHE_FWD_RADIX4 && (UNIFORM || SGFHE_FWD_VEC4(LOGM))) {
             load_twiddles<LOGM, LOGE, SCUR, LOGE - 2, LOGE - 2>(tp, tw + (2 << LOGM), (uint32_t)tid >> SCUR);
             if constexpr (TWO_STEPS) load_twiddles<LOGM, LOGE, SCUR, 0, 0>(tp, tw + (2 << LOGM), (uint32_t)tid >> SCUR);
         }
@@ -410,7 +420,7 @@ struct FwdPasses {
             fwd_step4<NP, LOGE, 3>(x, t, tp, mdl);
             fwd_reduce_x0<NP, LOGE, 1>(x, mdl);
             fwd_step4<NP, LOGE, 1>(x, t, tp, mdl);
-        } else if constexpr (SGFHE_FWD_RADIX4) {
+        } else if constexpr (SGFHE_FWD_RADIX4 && (UNIFORM || SGFHE_FWD_VEC4(LOGM))) {
             fwd_reduce_x<NP, LOGE>(x, mdl);
             fwd_step4<NP, LOGE, LOGE - 1>(x, t, tp, mdl);
             fwd_stages<NP, LOGE, LOGE - 3, 0>(x, t, mdl);
@@ -428,13 +438,15 @@ struct FwdPasses {
 // WIDE0: polynomial 0 enters the first pass with |x| <= 1.5 * 2^29 instead of 0.75 (LOGE = 4 only)
 // product twiddles of inverse pass S (table tw + 2 m): for the step on local bits 0 / 1, and on 2 / 3
 // as well where the pass runs both steps (LOGE = 4, wave-uniform twiddles)
+template <int LOGM, int S>
+constexpr bool inv_pass_radix4() { return SGFHE_INV_RADIX4 && SGFHE_INV_R4(LOGM); }
 template <int LOGM, int LOGE, int S>
 __device__ __forceinline__ void load_inv_products(int32_t (&tp)[(1 << LOGE) - 1], const int32_t *tw, int tid) {
-#if SGFHE_INV_RADIX4
-    load_twiddles<LOGM, LOGE, S, 0, 0>(tp, tw + (2 << LOGM), (uint32_t)tid >> S);
-    if constexpr (LOGE == 4 && (1 << S) >= 64)
-        load_twiddles<LOGM, LOGE, S, 2, 2>(tp, tw + (2 << LOGM), (uint32_t)tid >> S);
-#endif
+    if constexpr (inv_pass_radix4<LOGM, S>()) {
+        load_twiddles<LOGM, LOGE, S, 0, 0>(tp, tw + (2 << LOGM), (uint32_t)tid >> S);
+        if constexpr (LOGE == 4 && (1 << S) >= 64)
+            load_twiddles<LOGM, LOGE, S, 2, 2>(tp, tw + (2 << LOGM), (uint32_t)tid >> S);
+    }
 }
 template <int LOGM, int NP, int LOGE, int SCUR, int SLAST, bool FINAL = false, bool WIDE0 = false>
 struct InvPasses {
@@ -444,13 +456,18 @@ struct InvPasses {
                                                const int32_t (&tp)[(1 << LOGE) - 1]) {
         constexpr int MODE = (FINAL && SCUR == SLAST) ? 2 : 1;
 #if SGFHE_INV_RADIX4
+        if constexpr (!inv_pass_radix4<LOGM, SCUR>()) {
+            // radix-2 stages with the searched reduction pattern (inputs and outputs below 0.75 * 2^29)
+            static_assert(!WIDE0 || (LOGE == 4 && !(FINAL && SLAST == 0)), "wide first pass: radix 16, not the final pass");
+            inv_stages<NP, LOGE, 0, LOGE - 1, 0, MODE, (WIDE0 && SCUR == 0) ? 3 : MODE>(x, t, md);
+        } else
         // Radix-4 steps with deferred reductions (inv_step4).  Every pass opens with one on local
         // bits 0 and 1; a pass whose twiddles are wave-uniform (scalar registers) runs bits 2 and 3
         // the same way, the others as radix-2 stages.  Reductions: the four-fold sums y0 after each
         // step; in the radix-2 tail the sums of the last stage (in the final pass only those that
         // can exceed 1.4 * 2^29).  tests/rns_model.py NttModel.inv_pass / RangeModel.inverse.
-        static_assert(!WIDE0, "the radix-4 inverse takes every polynomial below 0.75 * 2^29");
         {
+            static_assert(!WIDE0, "the radix-4 inverse takes every polynomial below 0.75 * 2^29");
             constexpr bool UNIFORM = (1 << SCUR) >= 64;
             inv_step4<NP, LOGE, 0>(x, t, tp, md);
             inv_reduce_y0<NP, LOGE, 0>(x, md);

@@ -254,6 +254,17 @@ def inv_red_mask(loge, B, bfirst, bhi, lastred):
     return {e0 for e0 in range(E) if not e0 & (1 << B)} if allred else set()
 
 
+def fwd_vec4(logm):
+    """ntt.h SGFHE_FWD_VEC4: forward passes with per-lane twiddles take the radix-4 form except where
+    k_extprod would spill registers (m = 4096, 16384)."""
+    return logm not in (12, 14)
+
+
+def inv_r4(logm):
+    """ntt.h SGFHE_INV_R4: the inverse keeps its radix-2 form at m = 4096."""
+    return logm != 12
+
+
 class NttModel:
     """x has shape [T, E] (one polynomial); lds is a flat array of M words."""
 
@@ -337,10 +348,14 @@ class NttModel:
                     x0 = [e for e in range(E) if (e & (3 << (BH - 1))) == 0]   # fwd_reduce_x0
                     x[:, x0] = sred_floor(x[:, x0], P)
                     self.step4(x, tw, twp, P, BH, S)
-            else:                                          # per-lane twiddles: one radix-4 step, then radix 2
+            elif (1 << S) >= 64 or fwd_vec4(self.LOGM):    # one radix-4 step, then radix 2
                 x[:, :E // 2] = sred_floor(x[:, :E // 2], P)                   # fwd_reduce_x
                 self.step4(x, tw, twp, P, self.LOGE - 1, S)
                 for B in range(self.LOGE - 3, -1, -1):
+                    self.stage(x, tw, P, B, S, True)
+            else:                                          # per-lane twiddles at m = 4096 / 16384: radix 2
+                x[:, :E // 2] = sred_floor(x[:, :E // 2], P)
+                for B in range(self.LOGE - 1, -1, -1):
                     self.stage(x, tw, P, B, S, True)
             sprev, S = S, S - self.LOGE
         return x
@@ -372,8 +387,10 @@ class NttModel:
                 x[:, e0 | hb | lo] = sredc(d0 * P0 + d1 * P1, P)
 
     def wide_ok(self):
-        """(the radix-4 inverse has no un-reduced entry: every polynomial arrives below 0.75 * 2^29)"""
-        return False
+        """k_extprod's WIDE0 (column 0 enters the inverse un-reduced, |.| < 1.5 * 2^29): only where the
+        inverse is the radix-2 one; the radix-4 inverse takes every polynomial below 0.75 * 2^29."""
+        return (not inv_r4(self.LOGM)) and self.LOGE == 4 and self.SLAST_INV >= 0 and \
+            not (self.RHO == 0 and self.STOP == 0)
 
     def inv_pass(self, x, tw, P, S, final):
         """One full inverse pass over [S, S + LOGE) as ntt.h InvPasses runs it."""
@@ -397,15 +414,20 @@ class NttModel:
             self.stage(x, tw, P, B, S, False, red)
 
     def inverse(self, x, tw, P, wide=False):
-        """slots E tid + e -> coefficient tid + T e (unscaled)."""
-        assert not wide
+        """slots E tid + e -> coefficient tid + T e (unscaled).  wide: ntt_inverse<..., WIDE0> for
+        this polynomial (radix-2 inverse only)."""
+        assert not wide or self.wide_ok()
         x = np.asarray(x, dtype=np.int64).copy()
         lds = np.zeros(self.M, dtype=np.int64)
         if self.SLAST_INV >= 0:
             S = 0
             while True:
                 final = (not self.RHO) and S >= self.SLAST_INV     # InvPasses<..., FINAL>
-                self.inv_pass(x, tw, P, S, final)
+                if inv_r4(self.LOGM):
+                    self.inv_pass(x, tw, P, S, final)
+                else:
+                    mode = 3 if (wide and S == 0) else (2 if final else 1)
+                    self.inv_stages(x, tw, P, S, 0, self.LOGE - 1, mode)
                 if S >= self.SLAST_INV:
                     break
                 self.store(x, lds, S)
@@ -461,14 +483,50 @@ class RangeModel:
                 for _step in range(2):
                     assert 2 * b / 16 * 2 ** 29 * 2 ** 28 < 2 ** 62     # the 64-bit sum of two products
                     b = self._chk(red + (b / 16 + 0.5) + (2 * b / 16 + 0.5))
-            else:
+            elif (1 << S) >= 64 or fwd_vec4(N.LOGM):
                 # X0, X1 reduced; radix-4 step on the top two stages, radix-2 stages below
                 x = self._chk(red + (b / 16 + 0.5) + ((red + b) / 16 + 0.5))
                 for _s in range(N.LOGE - 2):
                     x = self._chk(x + x / 16 + 0.5)
                 b = x
+            else:                                            # radix-2 pass
+                x, y = red, b
+                for _s in range(N.LOGE):
+                    x = self._chk(x + y / 16 + 0.5)
+                    y = x
+                b = x
             S -= N.LOGE
         return b
+
+    def inverse_radix2(self, b_in, wide=False):
+        """Bounds of the radix-2 inverse with the searched reduction pattern (inv_red_mask)."""
+        N = self.N
+        E = N.E
+        assert not wide or N.wide_ok()
+
+        def run(bv, blo, bhi, lastred):
+            for B in range(blo, bhi + 1):
+                mask = inv_red_mask(N.LOGE, B, blo, bhi, lastred)
+                nb = list(bv)
+                for e0 in range(E):
+                    if e0 & (1 << B):
+                        continue
+                    e1 = e0 | (1 << B)
+                    red = e0 in mask
+                    s = self._chk(bv[e0] + bv[e1], 3.5 if red else 4.0)
+                    nb[e0] = (0.5 + 4 * self.delta) if red else s
+                    nb[e1] = s / 16 + 0.5
+                bv = nb
+            return bv
+
+        bv = [b_in] * E
+        full = (N.SLAST_INV // N.LOGE + 1) if N.SLAST_INV >= 0 else 0
+        for i in range(full):
+            final = (not N.RHO) and i == full - 1
+            bv = [max(run(bv, 0, N.LOGE - 1, 3 if (wide and i == 0) else (2 if final else 1)))] * E
+        if N.RHO:
+            bv = run(bv, N.LOGE - N.RHO, N.LOGE - 1, False)
+        return max(bv)
 
     def inverse(self, b_in, wide=False):
         """Bounds of the radix-4 inverse (NttModel.inv_pass) from inputs below b_in * 2^29, per
@@ -476,6 +534,8 @@ class RangeModel:
         a sum of two products of differences."""
         N = self.N
         E, LOGE = N.E, N.LOGE
+        if not inv_r4(N.LOGM):
+            return self.inverse_radix2(b_in, wide)
         assert not wide
         red_out = 0.5 + 4 * self.delta
 
