@@ -337,17 +337,33 @@ void launch_crt_lean_t(sgfhe_ctx *c, const uint32_t *yres, uint64_t *dig, uint32
     default: hipLaunchKernelGGL((k_crt_lean<NP, 4>), grid, block, 0, st, yres, dig, c->d_lean, total / 4, (uint32_t)c->logm); break;
     }
 }
+template <int NP, bool WIDE>
+void launch_crt_lean_rnd_t(sgfhe_ctx *c, const uint32_t *yres, uint64_t *dig, uint32_t total, hipStream_t st,
+                           RndArgs ra, uint32_t iter) {
+    const dim3 grid((total / 4 + 255) / 256), block(256);
+    switch (c->h_lean.nl) {
+    case 2: hipLaunchKernelGGL((k_crt_lean_rnd<NP, 2, WIDE>), grid, block, 0, st, yres, dig, c->d_lean, total / 4, (uint32_t)c->logm, ra, iter); break;
+    case 3: hipLaunchKernelGGL((k_crt_lean_rnd<NP, 3, WIDE>), grid, block, 0, st, yres, dig, c->d_lean, total / 4, (uint32_t)c->logm, ra, iter); break;
+    default: hipLaunchKernelGGL((k_crt_lean_rnd<NP, 4, WIDE>), grid, block, 0, st, yres, dig, c->d_lean, total / 4, (uint32_t)c->logm, ra, iter); break;
+    }
+}
 int32_t launch_crt_raw(sgfhe_ctx *c, const uint32_t *yres, uint64_t *dig, uint32_t total,
                        uint32_t mode, hipStream_t st, RndArgs ra, uint32_t iter) {
     // the k-loop's own case (deterministic flatten, accumulator present): the integer-only kernel,
     // four coefficients per thread; every other mode, and parameter sets outside its bounds
     // (B < 2^12, Q < 2^30), the general one
     const bool lean = mode == 0u && c->h_lean.nl != 0 && c->use_lean;
+    // the same for the randomised flatten (the k-loop's modes MODE_RANDOM and MODE_RANDOM | MODE_WIDE)
+    const bool lean_rnd = (mode & ~MODE_WIDE) == MODE_RANDOM && c->h_lean.nl != 0 && c->use_lean;
     switch (c->npr) {
 #define X(NP)                                                                                     \
     case NP:                                                                                      \
         if (lean)                                                                                 \
             launch_crt_lean_t<NP>(c, yres, dig, total, st);                                       \
+        else if (lean_rnd && (mode & MODE_WIDE))                                                  \
+            launch_crt_lean_rnd_t<NP, true>(c, yres, dig, total, st, ra, iter);                   \
+        else if (lean_rnd)                                                                        \
+            launch_crt_lean_rnd_t<NP, false>(c, yres, dig, total, st, ra, iter);                  \
         else if (mode == 0u) /* two coefficients per thread */                                   \
             hipLaunchKernelGGL(k_crt_acc2<NP>, dim3((total / 2 + 255) / 256), dim3(256), 0, st,   \
                                yres, dig, c->d_crt, total / 2, (uint32_t)c->logm);                \
@@ -746,6 +762,11 @@ int32_t build_constants(sgfhe_ctx *c) {
             K.t2 = (uint32_t)(nq > 63 ? nq - 63 : 0);
             K.sB = (uint32_t)(nb + 51 - (int)K.t2 - 64);
             K.nl = (uint32_t)NL;
+            // randomised flatten: 2 xmax and (-2 xmax (1 + B)) mod Q  (2 xmax (1 + B) < 3.1 B^2 < 2^96)
+            const u128 xm2 = (u128)2 * cc.xmax;
+            lim((Q - (xm2 * (1 + B)) % Q) % Q, K.cR);
+            K.xm2lo = (uint32_t)xm2;
+            K.xm2hi = (uint32_t)(xm2 >> 32);
         }
         const char *env = getenv("SGFHE_CRT_LEAN");
         c->use_lean = !(env && env[0] == '0');

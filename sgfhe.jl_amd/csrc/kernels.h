@@ -721,6 +721,8 @@ struct CrtLean {
     uint32_t a;               // top limb sum << a, the next >> 29 - a, the next >> 58 - a
     uint32_t t2, sB;          // x >> t2;  final shift of the digit estimate
     uint32_t nl;              // limbs in use (2, 3 or 4); 0 = parameter set outside this kernel's bounds
+    uint32_t cR[4];           // randomised flatten: (-2 xmax (1 + B)) mod Q in 29-bit limbs
+    uint32_t xm2lo, xm2hi;    //   2 xmax
 };
 
 // (x m) >> 64 for x < 2^63.5 and m = m1 2^32 + m0 with m1 <= 2^20
@@ -731,7 +733,7 @@ __device__ __forceinline__ uint64_t mulhi64_lean(uint64_t x, uint32_t m0, uint32
     return (uint64_t)x1 * m1 + (t2 >> 32);
 }
 
-template <int NP, int NL>
+template <int NP, int NL, bool RND = false>
 __device__ __forceinline__ void crt_lean_one(const uint32_t (&y)[NP], uint64_t lo_o, uint64_t hi_o,
                                              const CrtLean *__restrict__ K, uint64_t &lo_n,
                                              uint64_t &hi_n) {
@@ -749,6 +751,7 @@ __device__ __forceinline__ void crt_lean_one(const uint32_t (&y)[NP], uint64_t l
 #pragma unroll
         for (int q = 0; q < NP; q++) l += (uint64_t)(q == NP - 1 ? ylast : y[q]) * K->c[q][k];
         L[k] = l + (uint64_t)alpha * K->cMn[k];
+        if constexpr (RND) L[k] += K->cR[k];
     }
     {   // + hi_old B
         const uint32_t h0 = (uint32_t)hi_o, h1 = (uint32_t)(hi_o >> 32);
@@ -858,6 +861,81 @@ k_crt_lean(const uint32_t *__restrict__ yres, uint64_t *__restrict__ dig,
                                       (uint32_t)(nlo[2] >> 32) | ((uint32_t)(nlo[3] >> 32) << 16)));
     st_off<uint2>(dig, oh + 2u * M, make_uint2((uint32_t)(nhi[0] >> 32) | ((uint32_t)(nhi[1] >> 32) << 16),
                                                (uint32_t)(nhi[2] >> 32) | ((uint32_t)(nhi[3] >> 32) << 16)));
+}
+
+// The randomised flatten (utils.jl:198-241; random_digits above) through the same limb sums.  With
+// r_i the draws in [0, 2 xmax] and (e_lo, e_hi) the old stored digits, the value to flatten is
+//   x2 = (x_old + D - r_0 - r_1 B) mod Q,   x_old == e_hi B + e_lo  (mod Q),
+// so the draws enter as 2 xmax - r_i >= 0 added to the old digits, the constant
+// cR = (-2 xmax (1 + B)) mod Q puts the shift back, and the one quotient step of crt_lean_one gives
+// x2 directly -- no reduction of r_1 B + r_0, no second quotient.  New stored digits: those of x2
+// plus r_i.  Same Philox counters as k_crt_acc, bit-identical output (tests: the oracle; the
+// register widths: tests/rns_model.py CrtLean.digits_random).
+template <int NP, int NL, bool WIDE>
+__global__ void __launch_bounds__(256)
+k_crt_lean_rnd(const uint32_t *__restrict__ yres, uint64_t *__restrict__ dig,
+               const CrtLean *__restrict__ K, uint32_t quads, uint32_t logm, RndArgs ra, uint32_t iter) {
+    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= quads) return;
+    const uint32_t M = 1u << logm;
+    const uint32_t i = (4u * t) & (M - 1);  // multiple of 4
+    const uint32_t bc = (4u * t) >> logm;
+    const uint32_t yo = 4u * ((bc * NP << logm) + i);
+    typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+    uint4 yv[NP];
+#pragma unroll
+    for (int q = 0; q < NP; q++) {
+        const v4u t = __builtin_nontemporal_load(reinterpret_cast<const v4u *>(
+            reinterpret_cast<const char *>(yres) + yo + ((uint32_t)(4 * q) << logm)));
+        yv[q] = make_uint4(t.x, t.y, t.z, t.w);
+    }
+    const uint32_t rec = bc * 16u * M;
+    const uint32_t ol = rec + 4u * i, oh = rec + 8u * M + 2u * i, ot = rec + 12u * M + i;
+    const uint4 l0 = ld_off<uint4>(dig, ol), l1 = ld_off<uint4>(dig, ol + 4u * M);
+    const uint2 h0 = ld_off<uint2>(dig, oh), h1 = ld_off<uint2>(dig, oh + 2u * M);
+    uint32_t t0 = 0, t1 = 0;   // third plane: bits 48..55 of the four stored digits
+    if constexpr (WIDE) { t0 = ld_off<uint32_t>(dig, ot); t1 = ld_off<uint32_t>(dig, ot + M); }
+    const uint32_t l0w[4] = {l0.x, l0.y, l0.z, l0.w}, l1w[4] = {l1.x, l1.y, l1.z, l1.w};
+    const uint32_t h0w[4] = {h0.x & 0xFFFFu, h0.x >> 16, h0.y & 0xFFFFu, h0.y >> 16};
+    const uint32_t h1w[4] = {h1.x & 0xFFFFu, h1.x >> 16, h1.y & 0xFFFFu, h1.y >> 16};
+    const uint64_t xm2 = ((uint64_t)K->xm2hi << 32) | K->xm2lo, span = xm2 + 1;
+    const uint32_t cx = ((bc & 1u) << logm) + i, cz = ra.chunk + (bc >> 1);
+    uint64_t nlo[4], nhi[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        uint32_t y[NP];
+#pragma unroll
+        for (int q = 0; q < NP; q++) y[q] = j == 0 ? yv[q].x : j == 1 ? yv[q].y : j == 2 ? yv[q].z : yv[q].w;
+        const uint4 rv = philox4x32(make_uint4(cx + j, iter, cz, ra.call), ra.key0, ra.key1);
+        const uint64_t r0 = __umul64hi(((uint64_t)rv.y << 32) | rv.x, span);
+        const uint64_t r1 = __umul64hi(((uint64_t)rv.w << 32) | rv.z, span);
+        uint32_t hw0 = h0w[j], hw1 = h1w[j];
+        if constexpr (WIDE) {
+            hw0 |= ((t0 >> (8 * j)) & 0xFFu) << 16;
+            hw1 |= ((t1 >> (8 * j)) & 0xFFu) << 16;
+        }
+        const uint64_t e_lo = l0w[j] | ((uint64_t)hw0 << 32), e_hi = l1w[j] | ((uint64_t)hw1 << 32);
+        crt_lean_one<NP, NL, true>(y, e_lo + (xm2 - r0), e_hi + (xm2 - r1), K, nlo[j], nhi[j]);
+        nlo[j] += r0;
+        nhi[j] += r1;
+    }
+    st_off<uint4>(dig, ol, make_uint4((uint32_t)nlo[0], (uint32_t)nlo[1], (uint32_t)nlo[2], (uint32_t)nlo[3]));
+    st_off<uint4>(dig, ol + 4u * M,
+                  make_uint4((uint32_t)nhi[0], (uint32_t)nhi[1], (uint32_t)nhi[2], (uint32_t)nhi[3]));
+    st_off<uint2>(dig, oh, make_uint2(((uint32_t)(nlo[0] >> 32) & 0xFFFFu) | ((uint32_t)(nlo[1] >> 32) << 16),
+                                      ((uint32_t)(nlo[2] >> 32) & 0xFFFFu) | ((uint32_t)(nlo[3] >> 32) << 16)));
+    st_off<uint2>(dig, oh + 2u * M, make_uint2(((uint32_t)(nhi[0] >> 32) & 0xFFFFu) | ((uint32_t)(nhi[1] >> 32) << 16),
+                                               ((uint32_t)(nhi[2] >> 32) & 0xFFFFu) | ((uint32_t)(nhi[3] >> 32) << 16)));
+    if constexpr (WIDE) {
+        uint32_t w0 = 0, w1 = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            w0 |= ((uint32_t)(nlo[j] >> 48) & 0xFFu) << (8 * j);
+            w1 |= ((uint32_t)(nhi[j] >> 48) & 0xFFu) << (8 * j);
+        }
+        st_off<uint32_t>(dig, ot, w0);
+        st_off<uint32_t>(dig, ot + M, w1);
+    }
 }
 
 // ---- small-batch ("latency") form of the external product --------------------------------------

@@ -648,6 +648,13 @@ class CrtLean:
         assert self.mb <= (1 << 52)
         self.sB = self.nb + 51 - self.t2 - 64
         assert self.sB >= 0 and self.t2 <= 31
+        # randomised flatten (kernels.h k_crt_lean<.., RND>): the draws enter as r'_i = 2 xmax - r_i
+        # >= 0 added to the old digits, and cR = c Q - 2 xmax (1 + B) >= 0 puts the constant back:
+        #   S' = D + (hi_o + r'_1) B + (lo_o + r'_0) + cR  ==  x_old + D - r_0 - r_1 B   (mod Q)
+        self.xmax = C.xmax
+        two = 2 * self.xmax * (1 + B)
+        self.cRv = (-two) % Q
+        self.cR = lim(self.cRv)
 
     @staticmethod
     def mulhi64(x, m):
@@ -658,8 +665,15 @@ class CrtLean:
         t2 = u64(x1 * m0 + t1)
         return u64(x1 * m1 + (t2 >> 32))
 
-    def digits(self, y, lo_o, hi_o):
+    def digits_random(self, y, e_lo, e_hi, r0, r1):
+        """The randomised flatten through the same limb sums: old stored digits (e_lo, e_hi), draws
+        r_i in [0, 2 xmax]; returns the new stored digits."""
+        lo, hq, alpha = self.digits(y, e_lo + 2 * self.xmax - r0, e_hi + 2 * self.xmax - r1, rnd=True)
+        return lo + r0, hq + r1, alpha
+
+    def digits(self, y, lo_o, hi_o, rnd=False):
         C, NL = self.C, self.NL
+        assert lo_o < (1 << 64) and hi_o < (1 << 64)
         acc = 0
         for i in range(C.npr):
             acc = u64(acc + y[i] * self.w[i])
@@ -673,6 +687,8 @@ class CrtLean:
             for i in range(C.npr):
                 L[k] = u64(L[k] + yl[i] * self.c[i][k])
             L[k] = u64(L[k] + alpha * self.cMn[k])
+            if rnd:
+                L[k] = u64(L[k] + self.cR[k])
         h0, h1 = hi_o & 0xFFFFFFFF, hi_o >> 32
         L[0] = u64(L[0] + h0 * self.B0)
         L[1] = u64(L[1] + h0 * self.B1)

@@ -2,6 +2,8 @@
 restructuring (constants, CRT, digit handling) and the pass / swizzle / twiddle indexing of the
 LDS NTT without a GPU."""
 
+import math
+
 import numpy as np
 import pytest
 
@@ -273,3 +275,56 @@ def test_crt_lean_model(name, args):
         assert alpha == E.last_alpha
         assert xn == (xo + D) % C.Q
         assert (lo, hq) == (xn % C.B, xn // C.B)
+
+
+@pytest.mark.parametrize("name,args", list(_lean_cases()), ids=[c[0] for c in _lean_cases()])
+def test_crt_lean_random_model(name, args):
+    """The randomised flatten through k_crt_lean's limb sums (k_crt_lean<.., RND>): the draws enter
+    as 2 xmax - r_i added to the old stored digits, a constant c Q - 2 xmax (1 + B) puts the shift
+    back, and one quotient step gives x2 = (x_old + D - r_0 - r_1 B) mod Q -- equal to
+    random_digits of k_crt_acc (EngineModel.random_digits) for D up to the 4-times-wider exactness
+    bound of that mode, old stored digits up to their maxima (B - 1 + 2 xmax, Q / B + 2 xmax) and
+    draws at 0, 2 xmax and in between; every intermediate inside its register (RM.CrtLean)."""
+    import random
+    rnd = random.Random((hash(name) & 0xFFFF) + 1)
+    if 2 * math.log2(args[3]) + 2 - math.log2(args[2]) >= 50:
+        pytest.skip("the engine refuses the randomised flatten for this base")
+    C = RM.Consts(*args, random_flatten=True)
+    L = RM.CrtLean(C)
+    assert L.ok
+    E = RM.EngineModel.__new__(RM.EngineModel)
+    E.C = C
+    bound = min(int(0.4 * C.Mrns), 8 * C.M * C.B * C.Q)
+    inv = [pow(C.Mrns // p, -1, p) for p in C.primes]
+    xm2 = 2 * C.xmax
+    for it in range(4000):
+        D = rnd.randint(-bound, bound)
+        if it % 11 == 0:
+            D = rnd.choice([bound, -bound, 0, 1, -1])
+        y = []
+        for i, p in enumerate(C.primes):
+            r = D * inv[i] % p
+            r += rnd.randint(0, 5 if r < 0.7 * p else 4) * p
+            y.append(r + C.pk[i]["hoff"])
+        # old stored digits: (lo, hi) of some x2 < Q plus the draws of the previous iteration
+        x2o = rnd.randrange(C.Q)
+        if it % 7 == 0:
+            x2o = rnd.choice([0, C.Q - 1, C.B - 1, C.B % C.Q, (C.Q - C.B) % C.Q])
+        ro = [rnd.choice([0, xm2, rnd.randint(0, xm2)]) for _ in range(2)]
+        e_lo, e_hi = x2o % C.B + ro[0], x2o // C.B + ro[1]
+        r0, r1 = (rnd.choice([0, xm2, rnd.randint(0, xm2)]) for _ in range(2))
+        xo = e_hi * C.B + e_lo                       # what k_crt_acc adds (congruent to xn_old)
+        xn = E.crt_value(y, xo)
+        assert xn == (xo + D) % C.Q
+        x2 = (xn - r0 - r1 * C.B) % C.Q
+        if it % 13 == 0:                             # drive x2 to 0, Q - 1 and the digit boundaries
+            want = rnd.choice([0, C.Q - 1, C.B, C.B - 1])
+            shift = (want - x2) % C.Q
+            x2o2 = (x2o + shift) % C.Q
+            e_lo, e_hi = x2o2 % C.B + ro[0], x2o2 // C.B + ro[1]
+            xo = e_hi * C.B + e_lo
+            xn = E.crt_value(y, xo)
+            x2 = (xn - r0 - r1 * C.B) % C.Q
+            assert x2 == want
+        lo, hq, alpha = L.digits_random(y, e_lo, e_hi, r0, r1)
+        assert (lo, hq) == (x2 % C.B + r0, x2 // C.B + r1)
