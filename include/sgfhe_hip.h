@@ -70,7 +70,7 @@ const char *sgfhe_version(void);
  * SGFHE_ABI_VERSION it was written for and refuses a stale library (julia/SGFHEHip.jl __init__,
  * sgfhe.jl_amd/_lib.py).  Bumped whenever a signature, a struct layout, a flag value or the
  * meaning of an argument changes. */
-#define SGFHE_ABI_VERSION 3u
+#define SGFHE_ABI_VERSION 4u
 uint32_t sgfhe_abi_version(void);
 /* Identity of the kernel sources the library was compiled from: the first 16 hex digits of the
  * SHA-256 over csrc/{*.h, *.hip} (in file-name order), followed by "+<flags>" when the build used
@@ -283,6 +283,33 @@ int32_t sgfhe_host_decrypt_lwe(const sgfhe_params *p, const uint64_t *sk, const 
 /* decrypt(key, ::Union{Ciphertext, PackedCiphertext}) (src/fhe.jl:471-494), N = n or m -> bits[n]. */
 int32_t sgfhe_host_decrypt_rlwe(const sgfhe_params *p, const uint64_t *sk, const uint64_t *a,
                                 const uint64_t *b, size_t N, uint8_t *bits);
+
+/*
+ * The public-key side: PublicKey, _encrypt_public and the
+ * space-optimal public ciphertext, on the host.  q is the public-key modulus of Params(n)
+ * (find_modulus(2 n, r n), src/fhe.jl:57; q < 2^31), Dq = q / 4 (src/fhe.jl:88).  Polynomials over
+ * Z_q are uint64 in [0, q).  Pure functions: the caller passes the reference's draws.
+ */
+/* PublicKey(rng, sk) (src/fhe.jl:146-168) given its draws k0[n] in [0, q) and the centred noise
+ * e[n] in [-e_max, e_max] (e_max the largest integer below Dq / (41 n), :159-160): k1 = k0 s + e.
+ * The reference writes `polynomial - e_max` (:161); the noise is centred on every coefficient
+ * here (DarkIntegers' Polynomial - scalar rule is not checkable in this build; decryption holds
+ * either way). */
+int32_t sgfhe_host_public_key(const sgfhe_params *p, uint64_t q, const uint64_t *sk, const uint64_t *k0,
+                              const int64_t *e, uint64_t *k1);
+/* _encrypt_public(key, rng, message) (src/fhe.jl:386-409) given its draws u[n] in {-1, 0, 1},
+ * w1[n] in [-Dq / (41 n), Dq / (41 n)] and w2[n] in [-Dq / 82, Dq / 82]: -> RLWE (a, b) over Z_r,
+ * b a multiple of 2^(t - 5). */
+int32_t sgfhe_host_encrypt_public(const sgfhe_params *p, uint64_t q, const uint64_t *k0, const uint64_t *k1,
+                                  const int8_t *u, const int64_t *w1, const int64_t *w2,
+                                  const uint8_t *message, uint64_t *a, uint64_t *b);
+/* The bit matrices of encrypt_optimal(key::PublicKey, ...) (src/fhe.jl:420-436):
+ * (a[n], b[n]) -> a_bits[t + 1][n], b_bits[6][n]. */
+int32_t sgfhe_host_pack_public(const sgfhe_params *p, const uint64_t *a, const uint64_t *b,
+                               uint8_t *a_bits, uint8_t *b_bits);
+/* normalize_ciphertext(::PublicEncryptedCiphertext) (src/fhe.jl:444-449). */
+int32_t sgfhe_host_normalize_public(const sgfhe_params *p, const uint8_t *a_bits, const uint8_t *b_bits,
+                                    uint64_t *a, uint64_t *b);
 
 /*
  * Measurement hook for bench.py: HIP-event timings taken on the ctx stream around sampled

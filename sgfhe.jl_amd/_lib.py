@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.environ.get("SGFHE_HIP_LIB") or os.path.join(CSRC, "libsgfhe_hip.so")
 
-ABI_VERSION = 3   # SGFHE_ABI_VERSION of include/sgfhe_hip.h this binding was written for
+ABI_VERSION = 4   # SGFHE_ABI_VERSION of include/sgfhe_hip.h this binding was written for
 
 _u64p = ctypes.POINTER(ctypes.c_uint64)
 _u32p = ctypes.POINTER(ctypes.c_uint32)
@@ -124,6 +124,10 @@ def lib():
         "sgfhe_host_split_ciphertext": (i32, [ctypes.POINTER(SgfheParams), vp, vp, sz, vp, vp]),
         "sgfhe_host_decrypt_lwe": (i32, [ctypes.POINTER(SgfheParams), vp, vp, vp, sz, vp]),
         "sgfhe_host_decrypt_rlwe": (i32, [ctypes.POINTER(SgfheParams), vp, vp, vp, sz, vp]),
+        "sgfhe_host_public_key": (i32, [ctypes.POINTER(SgfheParams), u64, vp, vp, vp, vp]),
+        "sgfhe_host_encrypt_public": (i32, [ctypes.POINTER(SgfheParams), u64, vp, vp, vp, vp, vp, vp, vp, vp]),
+        "sgfhe_host_pack_public": (i32, [ctypes.POINTER(SgfheParams), vp, vp, vp, vp]),
+        "sgfhe_host_normalize_public": (i32, [ctypes.POINTER(SgfheParams), vp, vp, vp, vp]),
         "sgfhe_timing_enable": (i32, [vp, ctypes.c_int]),
         "sgfhe_timing_read": (i32, [vp, ctypes.POINTER(ctypes.c_double), ctypes.c_int]),
     }
@@ -146,4 +150,5 @@ EXPORTED_SYMBOLS = (
     "sgfhe_sync", "sgfhe_external_product", "sgfhe_pack_encrypted_bits", "sgfhe_debug_cmux", "sgfhe_debug_accumulators", "sgfhe_debug_digits", "sgfhe_debug_flatten", "sgfhe_debug_ntt",
     "sgfhe_debug_primes", "sgfhe_host_deterministic_expand", "sgfhe_host_encrypt_private",
     "sgfhe_host_pack_private", "sgfhe_host_normalize_private", "sgfhe_host_split_ciphertext",
-    "sgfhe_host_decrypt_lwe", "sgfhe_host_decrypt_rlwe", "sgfhe_timing_enable", "sgfhe_timing_read")
+    "sgfhe_host_decrypt_lwe", "sgfhe_host_decrypt_rlwe", "sgfhe_host_public_key",
+    "sgfhe_host_encrypt_public", "sgfhe_host_pack_public", "sgfhe_host_normalize_public", "sgfhe_timing_enable", "sgfhe_timing_read")

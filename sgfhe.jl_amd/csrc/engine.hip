@@ -1698,6 +1698,93 @@ int32_t sgfhe_host_decrypt_rlwe(const sgfhe_params *p, const uint64_t *sk, const
     return SGFHE_OK;
 }
 
+// ---- the public-key side (row N4) ------------------------------------------------------------------
+static bool host_q_ok(const sgfhe_params *p, uint64_t q) {
+    // q = find_modulus(2 n, r n) (fhe.jl:57): odd, 2 n | q - 1, above r n, and small enough for the
+    // 64-bit products of rescale (q r < 2^64) and of the short convolution (n q < 2^62)
+    return host_params_ok(p) && q > p->r * p->n && q < (1ull << 31) && (q - 1) % (2 * p->n) == 0;
+}
+static int64_t host_e_max(const sgfhe_params *p, uint64_t q) {
+    const uint64_t Dq = q / 4, d = 41 * p->n;                            // fhe.jl:159-160
+    return (int64_t)(Dq / d) - (Dq % d == 0 ? 1 : 0);
+}
+
+int32_t sgfhe_host_public_key(const sgfhe_params *p, uint64_t q, const uint64_t *sk, const uint64_t *k0,
+                              const int64_t *e, uint64_t *k1) {
+    if (!sk || !k0 || !e || !k1 || !p || !host_q_ok(p, q)) return SGFHE_ERR_INVALID_ARG;
+    const size_t n = p->n;
+    const int64_t e_max = host_e_max(p, q);
+    std::vector<int8_t> s(n);
+    for (size_t i = 0; i < n; i++) {
+        if (k0[i] >= q || e[i] < -e_max || e[i] > e_max) return SGFHE_ERR_INVALID_ARG;
+        s[i] = (int8_t)(sk[i] & 1);
+    }
+    std::vector<int64_t> ks(n);
+    sgfhe_host::negacyclic_mul_short(k0, s.data(), n, q, ks.data());     // fhe.jl:163-164
+    for (size_t i = 0; i < n; i++) {
+        const int64_t v = (ks[i] + e[i]) % (int64_t)q;
+        k1[i] = (uint64_t)(v < 0 ? v + (int64_t)q : v);
+    }
+    return SGFHE_OK;
+}
+
+int32_t sgfhe_host_encrypt_public(const sgfhe_params *p, uint64_t q, const uint64_t *k0, const uint64_t *k1,
+                                  const int8_t *u, const int64_t *w1, const int64_t *w2,
+                                  const uint8_t *message, uint64_t *a, uint64_t *b) {
+    if (!k0 || !k1 || !u || !w1 || !w2 || !message || !a || !b || !p || !host_q_ok(p, q))
+        return SGFHE_ERR_INVALID_ARG;
+    const size_t n = p->n;
+    const uint64_t r = p->r, Dq = q / 4;
+    const int t = (int)host_t(p);                                        // r = 2^(t + 1)
+    if (t < 5) return SGFHE_ERR_INVALID_ARG;                             // fhe.jl:404
+    const int shift = t - 5;
+    const int64_t w1_max = (int64_t)(Dq / (41 * n)), w2_max = (int64_t)(Dq / 82);   // fhe.jl:392,395
+    for (size_t i = 0; i < n; i++)
+        if (k0[i] >= q || k1[i] >= q || u[i] < -1 || u[i] > 1 || w1[i] < -w1_max || w1[i] > w1_max ||
+            w2[i] < -w2_max || w2[i] > w2_max)
+            return SGFHE_ERR_INVALID_ARG;
+    std::vector<int64_t> k0u(n), k1u(n);
+    sgfhe_host::negacyclic_mul_short(k0, u, n, q, k0u.data());           // fhe.jl:399
+    sgfhe_host::negacyclic_mul_short(k1, u, n, q, k1u.data());           // fhe.jl:400
+    for (size_t i = 0; i < n; i++) {
+        int64_t a1 = (k0u[i] + w1[i]) % (int64_t)q;
+        if (a1 < 0) a1 += (int64_t)q;
+        int64_t a2 = (k1u[i] + w2[i] + (int64_t)((message[i] & 1) * Dq)) % (int64_t)q;
+        if (a2 < 0) a2 += (int64_t)q;
+        a[i] = sgfhe_host::rescale(r, (uint64_t)a1, q, true);            // fhe.jl:402
+        b[i] = (sgfhe_host::rescale(r >> shift, (uint64_t)a2, q, false) << shift) & (r - 1);   // :405-406
+    }
+    return SGFHE_OK;
+}
+
+int32_t sgfhe_host_pack_public(const sgfhe_params *p, const uint64_t *a, const uint64_t *b,
+                               uint8_t *a_bits, uint8_t *b_bits) {
+    if (!host_params_ok(p) || !a || !b || !a_bits || !b_bits) return SGFHE_ERR_INVALID_ARG;
+    const size_t n = p->n;
+    const int t = (int)host_t(p);
+    if (t < 5) return SGFHE_ERR_INVALID_ARG;
+    sgfhe_host::unpackbits(a, n, (size_t)t + 1, a_bits);                 // fhe.jl:429
+    std::vector<uint64_t> bp(n);
+    for (size_t i = 0; i < n; i++) bp[i] = (b[i] & (p->r - 1)) >> (t - 5);   // fhe.jl:431
+    sgfhe_host::unpackbits(bp.data(), n, 6, b_bits);                     // fhe.jl:432
+    return SGFHE_OK;
+}
+
+int32_t sgfhe_host_normalize_public(const sgfhe_params *p, const uint8_t *a_bits, const uint8_t *b_bits,
+                                    uint64_t *a, uint64_t *b) {
+    if (!host_params_ok(p) || !a_bits || !b_bits || !a || !b) return SGFHE_ERR_INVALID_ARG;
+    const size_t n = p->n;
+    const int t = (int)host_t(p);
+    if (t < 5) return SGFHE_ERR_INVALID_ARG;
+    sgfhe_host::packbits(a_bits, (size_t)t + 1, n, a);                   // fhe.jl:446
+    sgfhe_host::packbits(b_bits, 6, n, b);                               // fhe.jl:447
+    for (size_t i = 0; i < n; i++) {
+        a[i] &= p->r - 1;
+        b[i] = (b[i] << (t - 5)) & (p->r - 1);
+    }
+    return SGFHE_OK;
+}
+
 int32_t sgfhe_timing_enable(sgfhe_ctx *c, int enable) {
     if (!c) return SGFHE_ERR_INVALID_ARG;
     SGFHE_LOCK(c);

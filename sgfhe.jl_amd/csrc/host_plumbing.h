@@ -138,4 +138,32 @@ inline void extract(const uint64_t *a, size_t N, size_t i, size_t n, uint64_t rm
     }
 }
 
+// ---- polynomials over Z_q, q the public-key modulus (q < 2^31) -------------------------------------
+// k * u mod (x^n + 1, q) for k in [0, q) and a short signed u (|u_i| <= 1: the private key bits,
+// the ternary u of _encrypt_public): `Polynomial * Polynomial` of src/fhe.jl:164,399-400.
+inline void negacyclic_mul_short(const uint64_t *k, const int8_t *u, size_t n, uint64_t q, int64_t *out) {
+    std::vector<int64_t> full(2 * n, 0);
+    for (size_t i = 0; i < n; i++) {
+        const int64_t ui = u[i];
+        if (!ui) continue;
+        for (size_t j = 0; j < n; j++) full[i + j] += (int64_t)k[j] * ui;   // |.| < n q < 2^42
+    }
+    for (size_t i = 0; i < n; i++) {
+        int64_t v = (full[i] - full[i + n]) % (int64_t)q;
+        out[i] = v < 0 ? v + (int64_t)q : v;
+    }
+}
+// rescale(new_max, x, old_max, round_result) (src/utils.jl:78-92): floor or round of
+// x new_max / old_max, the rounded value new_max wrapping to 0; x new_max < 2^64 here
+inline uint64_t rescale(uint64_t new_max, uint64_t x, uint64_t old_max, bool round_result) {
+    const uint64_t prod = x * new_max;
+    uint64_t quo = prod / old_max;
+    if (round_result) {
+        const uint64_t rem = prod % old_max;
+        if (rem >= old_max / 2 + (old_max & 1)) quo++;
+        if (quo == new_max) quo = 0;
+    }
+    return quo;
+}
+
 }  // namespace sgfhe_host

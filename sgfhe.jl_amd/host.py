@@ -89,3 +89,41 @@ def decrypt_rlwe(p, sk, a, b):
     _chk(_lib.lib().sgfhe_host_decrypt_rlwe(ctypes.byref(_params(p)), _ptr(sk), _ptr(a), _ptr(b), len(a),
                                             _ptr(bits)))
     return bits.astype(bool)
+
+
+# ---- the public-key side ------------------------------------------
+
+def public_key(p, sk, k0, e):
+    """PublicKey(rng, sk) (src/fhe.jl:146-168) given its draws k0 in [0, q) and the centred noise e:
+    returns k1 = k0 s + e over Z_q."""
+    sk, k0, e = _arr(sk, np.uint64), _arr(k0, np.uint64), _arr(e, np.int64)
+    k1 = np.zeros(p.n, dtype=np.uint64)
+    _chk(_lib.lib().sgfhe_host_public_key(ctypes.byref(_params(p)), p.q, _ptr(sk), _ptr(k0), _ptr(e), _ptr(k1)))
+    return k1
+
+
+def encrypt_public(p, k0, k1, u, w1, w2, message):
+    """_encrypt_public (src/fhe.jl:386-409) given its draws u in {-1, 0, 1}, w1, w2 -> RLWE (a, b)."""
+    k0, k1 = _arr(k0, np.uint64), _arr(k1, np.uint64)
+    u, w1, w2, msg = _arr(u, np.int8), _arr(w1, np.int64), _arr(w2, np.int64), _arr(message, np.uint8)
+    a, b = np.zeros(p.n, dtype=np.uint64), np.zeros(p.n, dtype=np.uint64)
+    _chk(_lib.lib().sgfhe_host_encrypt_public(ctypes.byref(_params(p)), p.q, _ptr(k0), _ptr(k1), _ptr(u),
+                                              _ptr(w1), _ptr(w2), _ptr(msg), _ptr(a), _ptr(b)))
+    return a, b
+
+
+def pack_public(p, a, b):
+    """The bit matrices of encrypt_optimal(key::PublicKey, ...) (src/fhe.jl:420-436):
+    a_bits [t + 1][n], b_bits [6][n]."""
+    a, b = _arr(a, np.uint64), _arr(b, np.uint64)
+    a_bits, b_bits = np.zeros((p.t + 1, p.n), dtype=np.uint8), np.zeros((6, p.n), dtype=np.uint8)
+    _chk(_lib.lib().sgfhe_host_pack_public(ctypes.byref(_params(p)), _ptr(a), _ptr(b), _ptr(a_bits), _ptr(b_bits)))
+    return a_bits, b_bits
+
+
+def normalize_public(p, a_bits, b_bits):
+    """normalize_ciphertext(::PublicEncryptedCiphertext) (src/fhe.jl:444-449)."""
+    a_bits, b_bits = _arr(a_bits, np.uint8), _arr(b_bits, np.uint8)
+    a, b = np.zeros(p.n, dtype=np.uint64), np.zeros(p.n, dtype=np.uint64)
+    _chk(_lib.lib().sgfhe_host_normalize_public(ctypes.byref(_params(p)), _ptr(a_bits), _ptr(b_bits), _ptr(a), _ptr(b)))
+    return a, b

@@ -244,3 +244,44 @@ def test_bench_ranks_rehearsal_on_one_gpu(ranks):
     assert d["n_gpus"] == ranks and d["config"]["key_broadcast_s"] > 0 and "rehearsal" in d["config"]
     assert d["value"] > 0 and abs(d["value"] - ranks * 512 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
     assert d["host_io"]["equals_device_resident_output"] is True and "cpu_baseline" not in d
+
+
+def test_rccl_world_of_one_broadcast_and_import(tmp_path, S):
+    """The production form of _worker (backend "nccl" = RCCL, device_id given, device-form blob
+    broadcast on the device, import, sharded bootstrap, gather) with the one rank a one-GPU box
+    allows: RCCL is initialised and carries the broadcast / all-gather / barrier calls of
+    sgfhe_jl_amd.distributed on real hardware; what a second device adds is the transport only.
+    The gathered bytes equal the plain one-process call."""
+    import torch.multiprocessing as mp
+    mp.spawn(_worker, args=(1, _free_port(), str(tmp_path)), nprocs=1, join=True)
+    params = S.Params(64)
+    eng = S.Engine(params, device=0)
+    eng.generate_key(np.random.default_rng(5).integers(0, 2, size=params.n, dtype=np.uint64), 9)
+    ref = eng.bootstrap_batch(*_inputs(params, 37))
+    eng.close()
+    assert np.load(os.path.join(str(tmp_path), "full_0.npy")).tobytes() == ref.tobytes()
+
+
+def test_bench_under_torchrun_with_rccl_one_rank():
+    """bench.py started exactly as the driver starts its N > 1 runs (python -m torch.distributed.run
+    --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...), at
+    the N this box has: the rank initialises RCCL with its device, broadcasts the Params(512) key
+    blob (168 MB) through it, takes both barriers and the MAX all-reduce on the device, and prints
+    the one line."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                        "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+                        os.path.join(root, "bench.py"), "--gpus", "1", "--config", "params512", "--batch",
+                        "64", "--steps", "1", "--warmup", "1", "--no-cpu-baseline"],
+                       env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["value"] > 0 and "rehearsal" not in d["config"]
+    assert d["config"]["key_broadcast_s"] > 0          # the broadcast went through RCCL
+    assert d["host_io"]["equals_device_resident_output"] is True
