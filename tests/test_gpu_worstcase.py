@@ -2,7 +2,8 @@
 D = (x^j - 1) sum_row u_row (*) C_row from residues modulo a few 29-bit primes whose product M only
 just covers it (Params(1024): |D| <= 2 m B Q = 0.33 M, five primes, 0.29 bits of head-room over the
 5 m B Q the ctx asks for).  Random inputs stay far from that bound, so these cases drive one
-k-loop iteration (sgfhe_debug_cmux: k_flatten_canon -> k_extprod -> k_crt_acc) with digits at
+k-loop iteration (sgfhe_debug_cmux: k_flatten_canon -> k_extprod -> the k-loop's own CRT kernel,
+k_crt_lean wherever the parameter set admits it) with digits at
 +-B/2, key residues at +-Q/2 and j = m (x^m - 1 = -2) and compare with the big-integer oracle's
 external_product(a, b, (x^j - 1) C .+ G) (src/fhe.jl:519-530,580).
 Run on the GPU box with `pytest -m gpu`."""
