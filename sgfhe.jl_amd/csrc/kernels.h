@@ -217,8 +217,9 @@ struct RndArgs {
 __device__ __forceinline__ uint4 philox4x32(uint4 c, uint32_t k0, uint32_t k1) {
 #pragma unroll
     for (int r = 0; r < 10; r++) {
-        const uint32_t h0 = __umulhi(0xD2511F53u, c.x), l0 = 0xD2511F53u * c.x;
-        const uint32_t h1 = __umulhi(0xCD9E8D57u, c.z), l1 = 0xCD9E8D57u * c.z;
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c.x, p1 = (uint64_t)0xCD9E8D57u * c.z;  // one v_mad_u64_u32 each
+        const uint32_t h0 = (uint32_t)(p0 >> 32), l0 = (uint32_t)p0;
+        const uint32_t h1 = (uint32_t)(p1 >> 32), l1 = (uint32_t)p1;
         c = make_uint4(h1 ^ c.y ^ k0, l1, h0 ^ c.w ^ k1, l0);
         k0 += 0x9E3779B9u;
         k1 += 0xBB67AE85u;
