@@ -1,0 +1,41 @@
+"""csrc/host_plumbing.h (the host side of SURVEY.md section 8f rows N3 / N4) under AddressSanitizer and
+UndefinedBehaviorSanitizer on the CPU: GPU sanitizers are not available on the pool, the host code
+needs no device.  The driver (tests/native/host_plumbing_sanitized.cpp) walks every function over
+sizes around its internal boundaries; any report aborts the run.  No GPU."""
+
+import os
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_host_plumbing_under_asan_and_ubsan(tmp_path):
+    gxx = shutil.which("g++")
+    if not gxx:
+        pytest.skip("no g++")
+    exe = str(tmp_path / "host_plumbing_sanitized")
+    cmd = [gxx, "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+           "-fno-omit-frame-pointer", "-Wall", "-Wextra", "-Werror",
+           "-I", os.path.join(ROOT, "sgfhe.jl_amd", "csrc"),
+           os.path.join(ROOT, "tests", "native", "host_plumbing_sanitized.cpp"), "-o", exe]
+    b = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    if b.returncode != 0 and "sanitize" in b.stderr and "cannot find" in b.stderr:
+        pytest.skip("the sanitizer runtimes are not installed: " + b.stderr[-300:])
+    assert b.returncode == 0, b.stderr[-3000:]
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=1", UBSAN_OPTIONS="print_stacktrace=1")
+    env.pop("LD_PRELOAD", None)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    digest = r.stdout.strip()
+    assert len(digest) == 16 and int(digest, 16) != 0
+    # the same binary without the sanitizers computes the same digest (no dependence on poisoned or
+    # uninitialised memory)
+    exe2 = str(tmp_path / "host_plumbing_plain")
+    subprocess.run([gxx, "-std=c++17", "-O2", "-I", os.path.join(ROOT, "sgfhe.jl_amd", "csrc"),
+                    os.path.join(ROOT, "tests", "native", "host_plumbing_sanitized.cpp"), "-o", exe2],
+                   check=True, timeout=300)
+    r2 = subprocess.run([exe2], capture_output=True, text=True, timeout=300)
+    assert r2.returncode == 0 and r2.stdout.strip() == digest
