@@ -39,3 +39,29 @@ def test_host_plumbing_under_asan_and_ubsan(tmp_path):
                    check=True, timeout=300)
     r2 = subprocess.run([exe2], capture_output=True, text=True, timeout=300)
     assert r2.returncode == 0 and r2.stdout.strip() == digest
+
+
+def test_oracle_c_under_asan_and_ubsan(tmp_path):
+    """The checker itself (oracle/sgfhe_oracle.c) under the sanitizers: key generation, bootstraps in
+    both of its forms, the truth table and one packing at Params(64)."""
+    gcc = shutil.which("gcc")
+    if not gcc:
+        pytest.skip("no gcc")
+    src = [os.path.join(ROOT, "tests", "native", "oracle_sanitized.c"), os.path.join(ROOT, "oracle", "sgfhe_oracle.c")]
+    exe = str(tmp_path / "oracle_sanitized")
+    b = subprocess.run([gcc, "-O1", "-g", "-fopenmp", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+                        "-fno-omit-frame-pointer", "-I", os.path.join(ROOT, "oracle")] + src + ["-o", exe, "-lm"],
+                       capture_output=True, text=True, timeout=600)
+    if b.returncode != 0 and "sanitize" in b.stderr and "cannot find" in b.stderr:
+        pytest.skip("the sanitizer runtimes are not installed")
+    assert b.returncode == 0, b.stderr[-3000:]
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=1", UBSAN_OPTIONS="print_stacktrace=1",
+               OMP_NUM_THREADS="1")
+    env.pop("LD_PRELOAD", None)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    exe2 = str(tmp_path / "oracle_plain")
+    subprocess.run([gcc, "-O2", "-fopenmp", "-I", os.path.join(ROOT, "oracle")] + src + ["-o", exe2, "-lm"],
+                   check=True, timeout=600)
+    r2 = subprocess.run([exe2], capture_output=True, text=True, timeout=900, env=env)
+    assert r2.returncode == 0 and r2.stdout.strip() == r.stdout.strip()
