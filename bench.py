@@ -396,8 +396,15 @@ def main():
         hb1, hb2 = b1.cpu().numpy().view(np.uint64), b2.cpu().numpy().view(np.uint64)
         if dist:
             dist.barrier()
+        # The first call through host pointers also allocates the engine's staging buffers and touches
+        # the pages of a fresh result array; the second is the steady state a gate circuit sees.
         t1 = time.perf_counter()
         hout = eng.bootstrap_batch(ha1, hb1, ha2, hb2)       # sgfhe_bootstrap_batch: H2D, k-loop, D2H
+        hdt_first = time.perf_counter() - t1
+        if dist:
+            dist.barrier()
+        t1 = time.perf_counter()
+        hout = eng.bootstrap_batch(ha1, hb1, ha2, hb2)
         hdt = time.perf_counter() - t1
         same = None if rnd else bool(np.array_equal(hout.view(np.int64), out.cpu().numpy()))
         if dist:
@@ -405,7 +412,8 @@ def main():
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             hdt = float(tmax.item())
         host_io = {"value": world * B / hdt, "unit": "bootstraps/sec", "ms_per_step": hdt * 1e3,
-                   "steps": 1, "equals_device_resident_output": same,
+                   "steps": 1, "first_call_ms": hdt_first * 1e3,
+                   "equals_device_resident_output": same,
                    "note": "inputs and outputs in host memory (sgfhe_bootstrap_batch): includes "
                            "H2D of 2 (n + 1) and D2H of 3 (n + 1) words per bootstrap"}
 
