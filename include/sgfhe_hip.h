@@ -70,7 +70,7 @@ const char *sgfhe_version(void);
  * SGFHE_ABI_VERSION it was written for and refuses a stale library (julia/SGFHEHip.jl __init__,
  * sgfhe.jl_amd/_lib.py).  Bumped whenever a signature, a struct layout, a flag value or the
  * meaning of an argument changes. */
-#define SGFHE_ABI_VERSION 4u
+#define SGFHE_ABI_VERSION 5u
 uint32_t sgfhe_abi_version(void);
 /* Identity of the kernel sources the library was compiled from: the first 16 hex digits of the
  * SHA-256 over csrc/{*.h, *.hip} (in file-name order), followed by "+<flags>" when the build used
@@ -114,21 +114,24 @@ int32_t sgfhe_set_lanes(sgfhe_ctx *ctx, uint32_t lanes);
  * Flatten mode of the external product.  enable = 0 (default): deterministic flatten, the
  * `rng = nothing` branch (src/utils.jl:155-189), bit-exact with the reference.  enable = 1:
  * randomised flatten, the `rng::AbstractRNG` branch (src/utils.jl:198-241): every digit gets a
- * uniform v in [-3B/2, 3B/2] drawn from a Philox4x32-10 counter stream of `seed`; digits lie in
- * (-2B, 2B].  The draw of a coefficient is addressed by (coefficient, iteration, index of the
- * bootstrap in the call, number of the call since this function): results do not depend on chunk
- * size, lanes or the small-batch threshold, and oracle/bigint_oracle.py reproduces them bit for
- * bit.  They decrypt like the reference's but are not bit-comparable with it (Julia's
- * MersenneTwister stream cannot be reproduced).  Applies to later bootstrap / pack calls; needs a
- * ctx whose RNS primes cover it (SGFHE_CTX_RANDOM_FLATTEN), else SGFHE_ERR_UNSUPPORTED.
- * Every Params(n) the reference can build is covered, n = 64 ... 2048 (B up to 2^47: above 2^46
- * the stored digits take a third plane of the digit record).
- * The stream is a statistical one: all perturbations of a call are a function of the 64-bit seed
- * through Philox4x32-10, which is not a cryptographic generator (the reference draws every v_i
- * from the caller's rng, src/utils.jl:229).  Key material does not come from this stream:
- * sgfhe_bkey_generate uses ChaCha20 with a 32-byte seed.
+ * uniform v in [-3B/2, 3B/2] drawn from a ChaCha counter stream (the RFC 8439 block function with
+ * 8 rounds, "ChaCha8") keyed with `key32`; digits lie in (-2B, 2B].  The draw of a coefficient is
+ * addressed by (coefficient, iteration, index of the bootstrap in the call, number of the call
+ * since this function): results do not depend on chunk size, lanes or the small-batch threshold,
+ * and oracle/bigint_oracle.py reproduces them bit for bit.  They decrypt like the reference's
+ * but are not bit-comparable with it (the stream of the caller's Julia rng cannot be reproduced:
+ * a host draws the 32 key bytes from that rng instead, julia/SGFHEHip.jl).  Applies to later
+ * bootstrap / pack calls; needs a ctx whose RNS primes cover it (SGFHE_CTX_RANDOM_FLATTEN), else
+ * SGFHE_ERR_UNSUPPORTED.  Every Params(n) the reference can build is covered, n = 64 ... 2048
+ * (B up to 2^47: above 2^46 the stored digits take a third plane of the digit record).
+ * sgfhe_set_random_flatten_key takes the full 32-byte key (the reference draws every v_i from the
+ * caller's rng, src/utils.jl:229: with a key from a cryptographic source the perturbations are
+ * cryptographically strong); sgfhe_set_random_flatten is the short form for tests and benchmarks,
+ * key = `seed` as 32 little-endian bytes (64 bits of entropy).  (ABI revisions up to 4 drew from
+ * Philox4x32-10 keyed by 64 bits.)
  */
 int32_t sgfhe_set_random_flatten(sgfhe_ctx *ctx, int enable, uint64_t seed);
+int32_t sgfhe_set_random_flatten_key(sgfhe_ctx *ctx, int enable, const uint8_t *key32);
 
 /*
  * Upload a bootstrap key.  `canonical` (host memory) holds value.(p.coeffs) of

@@ -52,16 +52,16 @@ class SplitMix64:
         return self.next() % bound
 
 
-def chacha20_blocks(key32, nonce, nblocks):
-    """ChaCha20 block function (RFC 8439 section 2.3) for block counters 0 .. nblocks-1:
-    key32 = 32 bytes, nonce = three 32-bit words.  Returns an [nblocks][16] array of words.
-    (numpy on whole counter ranges: the generator of the bootstrap key, shared with
-    oracle/sgfhe_oracle.c and the HIP engine's k_keygen_draw.)"""
+def chacha_blocks(key32, w12, w13, w14, w15, rounds=20):
+    """ChaCha block function (RFC 8439 section 2.3, `rounds` rounds) on whole ranges of blocks:
+    key32 = 32 bytes; w12 .. w15 = state words 12 .. 15, each a scalar or an array (broadcast).
+    Returns an [nblocks][16] array of words."""
     import numpy as np
     key = [int.from_bytes(key32[4 * i:4 * i + 4], "little") for i in range(8)]
-    init = [0x61707865, 0x3320646e, 0x79622d32, 0x6b206574] + key + [0] + [int(v) for v in nonce]
-    s = [np.full(nblocks, v, dtype=np.uint32) for v in init]
-    s[12] = np.arange(nblocks, dtype=np.uint32)
+    ws = [np.atleast_1d(np.asarray(v, dtype=np.uint64).astype(np.uint32)) for v in (w12, w13, w14, w15)]
+    nblocks = max(len(v) for v in ws)
+    init = [0x61707865, 0x3320646e, 0x79622d32, 0x6b206574] + key
+    s = [np.full(nblocks, v, dtype=np.uint32) for v in init] + [np.broadcast_to(v, (nblocks,)).copy() for v in ws]
     x = [v.copy() for v in s]
 
     def rotl(v, n):
@@ -73,11 +73,20 @@ def chacha20_blocks(key32, nonce, nblocks):
         x[a] = x[a] + x[b]; x[d] = rotl(x[d] ^ x[a], 8)
         x[c] = x[c] + x[d]; x[b] = rotl(x[b] ^ x[c], 7)
 
+    assert rounds % 2 == 0
     with np.errstate(over="ignore"):
-        for _ in range(10):
+        for _ in range(rounds // 2):
             qr(0, 4, 8, 12); qr(1, 5, 9, 13); qr(2, 6, 10, 14); qr(3, 7, 11, 15)
             qr(0, 5, 10, 15); qr(1, 6, 11, 12); qr(2, 7, 8, 13); qr(3, 4, 9, 14)
         return np.stack([x[i] + s[i] for i in range(16)], axis=1)
+
+
+def chacha20_blocks(key32, nonce, nblocks):
+    """ChaCha20 (RFC 8439) for block counters 0 .. nblocks-1, nonce = three 32-bit words: the
+    generator of the bootstrap key, shared with oracle/sgfhe_oracle.c and the HIP engine's
+    k_keygen_draw."""
+    import numpy as np
+    return chacha_blocks(key32, np.arange(nblocks, dtype=np.uint64), nonce[0], nonce[1], nonce[2], 20)
 
 
 def seed_bytes(seed):
@@ -319,50 +328,54 @@ def flatten_poly(a, B, ell, Q, draws=None):
 
 
 # ----------------------------------------------------------------------------------------------
-# The randomness of the HIP engine's randomised flatten, restated: Philox4x32-10 addressed by
-# counter = (x: (c << log2 m) + j for coefficient j of accumulator c (0 = a, 1 = b),
-#            y: k for the flatten feeding k-loop iteration k (0-based); 2^31 | i for the flatten of
-#               as_i in pack_encrypted_bits,
-#            z: index of the bootstrap within the call (of the ciphertext, for packing),
-#            w: number of the call since the seed was set),        key = the 64-bit seed.
-# The 128 output bits give r_0 = (lo64 * span) >> 64, r_1 = (hi64 * span) >> 64 with
-# span = 2 xmax + 1, and the draws x_i = r_i - xmax (sgfhe.jl_amd/csrc/kernels.h random_digits).
-# The reference draws from Julia's MersenneTwister, which cannot be reproduced here (SURVEY.md
-# F6): this pins the engine's random mode to the reference's *algorithm* on the engine's stream.
+# The randomness of the HIP engine's randomised flatten, restated: a ChaCha counter stream (the
+# RFC 8439 block function with RND_ROUNDS = 8 rounds, "ChaCha8") keyed with 32 bytes.  The 128
+# bits of coefficient x are words 4 (x mod 4) .. + 3 of the block whose state words 12 .. 15 are
+#   (x div 4   with x = (c << log2 m) + j for coefficient j of accumulator c (0 = a, 1 = b),
+#    y: k for the flatten feeding k-loop iteration k (0-based); 2^31 | i for the flatten of
+#       as_i in pack_encrypted_bits,
+#    z: index of the bootstrap within the call (of the ciphertext, for packing),
+#    w: number of the call since the key was set).
+# They give r_0 = (lo64 * span) >> 64, r_1 = (hi64 * span) >> 64 with span = 2 xmax + 1, and the
+# draws x_i = r_i - xmax (sgfhe.jl_amd/csrc/kernels.h rnd128 / random_digits).
+# The reference draws from the caller's Julia rng, whose stream cannot be reproduced here
+# (SURVEY.md F6): this pins the engine's random mode to the reference's *algorithm* on the
+# engine's stream.
 # ----------------------------------------------------------------------------------------------
 
-def philox4x32(ctr, seed):
-    c = [int(v) & 0xFFFFFFFF for v in ctr]
-    k0, k1 = seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF
-    for _ in range(10):
-        p0 = 0xD2511F53 * c[0]
-        p1 = 0xCD9E8D57 * c[2]
-        c = [((p1 >> 32) ^ c[1] ^ k0) & 0xFFFFFFFF, p1 & 0xFFFFFFFF,
-             ((p0 >> 32) ^ c[3] ^ k1) & 0xFFFFFFFF, p0 & 0xFFFFFFFF]
-        k0 = (k0 + 0x9E3779B9) & 0xFFFFFFFF
-        k1 = (k1 + 0xBB67AE85) & 0xFFFFFFFF
-    return c
+RND_ROUNDS = 8
 
 
-class PhiloxFlatten:
+def rnd128(key32, ctr, rounds=RND_ROUNDS):
+    """The four 32-bit words of the draw addressed by ctr = (x, y, z, w)."""
+    x, y, z, w = (int(v) & 0xFFFFFFFF for v in ctr)
+    blk = chacha_blocks(key32, x >> 2, y, z, w, rounds)[0]
+    return [int(v) for v in blk[4 * (x & 3):4 * (x & 3) + 4]]
+
+
+class ChaChaFlatten:
     """Draw source of one bootstrap: rng(c, y)(j, i) is the draw for digit i of coefficient j of
-    accumulator c in the flatten tagged y."""
+    accumulator c in the flatten tagged y.  seed: the 32-byte key, or an int taken as 32
+    little-endian bytes (sgfhe_set_random_flatten)."""
 
     def __init__(self, p, seed, boot=0, call=0):
-        self.p, self.seed, self.boot, self.call = p, seed, boot, call
+        self.p, self.key, self.boot, self.call = p, seed_bytes(seed), boot, call
         self.xmax = flatten_xmax(p.B)
         self.logm = p.m.bit_length() - 1
 
     def draws(self, c, y):
+        import numpy as np
         span = 2 * self.xmax + 1
-        cache = {}
+        m = self.p.m
+        # every block of the polynomial at once (coefficients 4 q .. 4 q + 3 share block q)
+        x0 = (c << self.logm) >> 2
+        blocks = chacha_blocks(self.key, np.arange(x0, x0 + (m + 3) // 4, dtype=np.uint64), y, self.boot,
+                               self.call, RND_ROUNDS)
+        words = blocks.reshape(-1).tolist()
 
         def f(j, i):
-            if j not in cache:
-                rv = philox4x32(((c << self.logm) + j, y, self.boot, self.call), self.seed)
-                cache.clear()
-                cache[j] = ((((rv[1] << 32) | rv[0]) * span) >> 64, (((rv[3] << 32) | rv[2]) * span) >> 64)
-            return cache[j][i] - self.xmax
+            lo, hi = words[4 * j + 2 * i], words[4 * j + 2 * i + 1]
+            return ((((hi << 32) | lo) * span) >> 64) - self.xmax
         return f
 
 
@@ -468,7 +481,7 @@ def mul_by_xj_minus_one(poly, j, Q):
 
 def bootstrap_internal(p, bkey, lwe1, lwe2, trace=None, rng=None):
     """src/fhe.jl:559-595.  Returns three LWEs over Z_Q: (AND, OR, XOR).  rng = None is the
-    reference's `rng = nothing`; a PhiloxFlatten selects the randomised flatten."""
+    reference's `rng = nothing`; a ChaChaFlatten selects the randomised flatten."""
     Q = p.Q
     ua = [(x + y) % p.r for x, y in zip(lwe1[0], lwe2[0])]               # fhe.jl:566
     ub = (lwe1[1] + lwe2[1]) % p.r
@@ -550,20 +563,20 @@ def reduce_modulus_poly(new_modulus, poly, old_modulus):
 
 def pack_encrypted_bits(p, bkey, enc_bits, seed=None, ct=0, call=0):
     """src/fhe.jl:660-696.  enc_bits: n LWEs (a, b) over Z_r.  seed = None: rng = nothing; else
-    the engine's Philox stream (ciphertext `ct` of call `call`): bootstrap j of the group is
+    the engine's ChaCha stream (ciphertext `ct` of call `call`): bootstrap j of the group is
     bootstrap ct * n + j of the call, and the flatten of as_i draws with y = 2^31 | i, z = ct.
     Returns the RLWE (w, v) over Z_r, two lists of m coefficients."""
     Q = p.Q
     assert len(enc_bits) == p.n                                           # fhe.jl:667
     enc_trivial = ([0] * p.n, p.Dr)                                       # fhe.jl:669-671
-    rngs = [None if seed is None else PhiloxFlatten(p, seed, ct * p.n + j, call) for j in range(p.n)]
+    rngs = [None if seed is None else ChaChaFlatten(p, seed, ct * p.n + j, call) for j in range(p.n)]
     new_lwes = [bootstrap_internal(p, bkey, enc_trivial, eb, rng=rngs[j])[0]
                 for j, eb in enumerate(enc_bits)]                         # fhe.jl:673
     as_ = [resize([new_lwes[j][0][i] for j in range(p.n)], p.m) for i in range(p.n)]  # :675-677
     b = resize([lw[1] for lw in new_lwes], p.m)                           # fhe.jl:678
     w_tilde = [0] * p.m
     v_tilde = [0] * p.m
-    pack_rng = None if seed is None else PhiloxFlatten(p, seed, ct, call)
+    pack_rng = None if seed is None else ChaChaFlatten(p, seed, ct, call)
     for i in range(p.n):                                                  # fhe.jl:683-687
         draws = None if seed is None else pack_rng.draws(0, (1 << 31) | i)
         w, v = shortened_external_product(as_[i], bkey[i], p.B, p.ell, Q, draws)

@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.environ.get("SGFHE_HIP_LIB") or os.path.join(CSRC, "libsgfhe_hip.so")
 
-ABI_VERSION = 4   # SGFHE_ABI_VERSION of include/sgfhe_hip.h this binding was written for
+ABI_VERSION = 5   # SGFHE_ABI_VERSION of include/sgfhe_hip.h this binding was written for
 
 _u64p = ctypes.POINTER(ctypes.c_uint64)
 _u32p = ctypes.POINTER(ctypes.c_uint32)
@@ -99,6 +99,7 @@ def lib():
         "sgfhe_set_lanes": (i32, [vp, u32]),
         "sgfhe_set_small_batch_max": (i32, [vp, u32]),
         "sgfhe_set_random_flatten": (i32, [vp, ctypes.c_int, u64]),
+        "sgfhe_set_random_flatten_key": (i32, [vp, ctypes.c_int, ctypes.c_char_p]),
         "sgfhe_bkey_upload": (i32, [vp, vp, sz]),
         "sgfhe_bkey_upload_rns2": (i32, [vp, vp, sz, u64, u64]),
         "sgfhe_rns2_convert": (i32, [vp, ctypes.c_int, vp, sz, u64, u64, vp]),
@@ -144,7 +145,7 @@ def lib():
 
 EXPORTED_SYMBOLS = (
     "sgfhe_version", "sgfhe_abi_version", "sgfhe_build_id", "sgfhe_ctx_create", "sgfhe_ctx_create_ex", "sgfhe_ctx_destroy", "sgfhe_last_error_string",
-    "sgfhe_set_chunk", "sgfhe_set_lanes", "sgfhe_set_small_batch_max", "sgfhe_set_random_flatten", "sgfhe_bkey_upload", "sgfhe_bkey_upload_rns2", "sgfhe_rns2_convert", "sgfhe_bkey_generate",
+    "sgfhe_set_chunk", "sgfhe_set_lanes", "sgfhe_set_small_batch_max", "sgfhe_set_random_flatten", "sgfhe_set_random_flatten_key", "sgfhe_bkey_upload", "sgfhe_bkey_upload_rns2", "sgfhe_rns2_convert", "sgfhe_bkey_generate",
     "sgfhe_bkey_device_form_bytes", "sgfhe_bkey_export_device_form",
     "sgfhe_bkey_import_device_form", "sgfhe_bootstrap_batch", "sgfhe_bootstrap_batch_device",
     "sgfhe_sync", "sgfhe_external_product", "sgfhe_pack_encrypted_bits", "sgfhe_debug_cmux", "sgfhe_debug_accumulators", "sgfhe_debug_digits", "sgfhe_debug_flatten", "sgfhe_debug_ntt",

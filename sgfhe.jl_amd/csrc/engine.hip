@@ -100,7 +100,7 @@ struct sgfhe_ctx {
     uint32_t chunk = 0, cap = 0, lanes = 2;
     // randomised flatten (rng != nothing, utils.jl:198-241)
     bool rnd = false, rnd_ok = false;
-    uint64_t rnd_seed = 0;
+    ChaChaKey rnd_key = {};   // 32-byte key of the draw stream (sgfhe_set_random_flatten[_key])
     uint32_t rnd_call = 0, last_call = 0;
     uint32_t create_flags = 0;
     // RNS2Number form of Z_Q (src/rns.jl): set by sgfhe_bkey_upload_rns2 / sgfhe_rns2_convert
@@ -379,7 +379,7 @@ int32_t launch_crt_raw(sgfhe_ctx *c, const uint32_t *yres, uint64_t *dig, uint32
     return SGFHE_OK;
 }
 int32_t launch_crt(sgfhe_ctx *c, const sgfhe_ctx::Lane &L, uint32_t cpad, uint32_t mode,
-                   hipStream_t st, RndArgs ra = RndArgs{0, 0, 0, 0}, uint32_t iter = 0) {
+                   hipStream_t st, RndArgs ra = RndArgs{}, uint32_t iter = 0) {
     return launch_crt_raw(c, L.yres, L.dig, cpad * 2 * c->M, mode, st, ra, iter);
 }
 
@@ -560,7 +560,7 @@ int32_t bootstrap_device(sgfhe_ctx *c, const uint64_t *a1, const uint64_t *b1, c
             J.cb = (uint32_t)((batch - c0 < chunk) ? batch - c0 : chunk);
             J.cpad = round_up8(J.cb);
             J.c0 = c0;
-            J.ra = RndArgs{(uint32_t)c->rnd_seed, (uint32_t)(c->rnd_seed >> 32), call, (uint32_t)c0};
+            J.ra = RndArgs{c->rnd_key, call, (uint32_t)c0};
             J.sampled = li == 0 && J.cpad == c->last_chunk;
             const uint32_t tot = J.cpad * M;
             hipLaunchKernelGGL(k_init, dim3((tot + 255) / 256), dim3(256), 0, J.st, a1 + c0 * n, b1 + c0,
@@ -1036,17 +1036,35 @@ int32_t sgfhe_set_chunk(sgfhe_ctx *c, uint32_t chunk) {
     return SGFHE_OK;
 }
 
-int32_t sgfhe_set_random_flatten(sgfhe_ctx *c, int enable, uint64_t seed) {
-    if (!c) return SGFHE_ERR_INVALID_ARG;
-    SGFHE_LOCK(c);
+static int32_t set_random_flatten(sgfhe_ctx *c, int enable, const ChaChaKey &key) {
     if (enable && !c->rnd_ok)
         return fail(c, SGFHE_ERR_UNSUPPORTED,
                     "randomised flatten: 20 m B Q exceeds the product of this ctx's RNS primes (or B^2 > 2^48 Q); "
                     "create the ctx with sgfhe_ctx_create_ex(..., SGFHE_CTX_RANDOM_FLATTEN, ...)");
     c->rnd = enable != 0;
-    c->rnd_seed = seed;
+    c->rnd_key = key;
     c->rnd_call = 0;
     return SGFHE_OK;
+}
+
+int32_t sgfhe_set_random_flatten(sgfhe_ctx *c, int enable, uint64_t seed) {
+    if (!c) return SGFHE_ERR_INVALID_ARG;
+    SGFHE_LOCK(c);
+    ChaChaKey key = {};   // the seed as 32 little-endian bytes
+    key.k[0] = (uint32_t)seed;
+    key.k[1] = (uint32_t)(seed >> 32);
+    return set_random_flatten(c, enable, key);
+}
+
+int32_t sgfhe_set_random_flatten_key(sgfhe_ctx *c, int enable, const uint8_t *key32) {
+    if (!c || (enable && !key32)) return SGFHE_ERR_INVALID_ARG;
+    SGFHE_LOCK(c);
+    ChaChaKey key = {};
+    if (key32)
+        for (int i = 0; i < 8; i++)
+            key.k[i] = (uint32_t)key32[4 * i] | ((uint32_t)key32[4 * i + 1] << 8) |
+                       ((uint32_t)key32[4 * i + 2] << 16) | ((uint32_t)key32[4 * i + 3] << 24);
+    return set_random_flatten(c, enable, key);
 }
 
 int32_t sgfhe_set_small_batch_max(sgfhe_ctx *c, uint32_t max_bootstraps) {
@@ -1135,7 +1153,7 @@ int32_t sgfhe_bkey_generate(sgfhe_ctx *c, const uint64_t *sk, size_t n_sk, const
             if (rc) break;
             // CRT of the exact product, canonical residues into d_prod ([row][m] 16-byte values)
             if ((rc = launch_crt_raw(c, d_y, reinterpret_cast<uint64_t *>(d_prod), tot,
-                                     MODE_NOACC | MODE_CANON, c->stream, RndArgs{0, 0, 0, 0}, 0u)))
+                                     MODE_NOACC | MODE_CANON, c->stream, RndArgs{}, 0u)))
                 break;
             hipLaunchKernelGGL(k_keygen_finish, dim3((tot + 255) / 256), dim3(256), 0, c->stream, d_acan,
                                d_prod, d_e, d_sk, d_canon, c->d_crt, row0, R, (uint32_t)c->logm);
@@ -1508,7 +1526,7 @@ int32_t sgfhe_pack_encrypted_bits(sgfhe_ctx *c, const uint64_t *a, const uint64_
     const size_t n = c->n, M = c->M;
     const size_t nb = count * n;  // bootstraps
     // rng != nothing: the n bootstraps and the flatten of every as_i (all m coefficients of the
-    // resized polynomial, utils.jl:253-264) draw from the ctx's Philox stream (fhe.jl:673,683-684)
+    // resized polynomial, utils.jl:253-264) draw from the ctx's ChaCha stream (fhe.jl:673,683-684)
     const uint32_t mode = c->rnd ? MODE_RANDOM : 0u;
     const uint32_t G = c->rnd ? c->pack_G_rnd : c->pack_G;
     if (!G) return fail(c, SGFHE_ERR_UNSUPPORTED, "pack_encrypted_bits: exactness bound of the RNS primes");
@@ -1535,7 +1553,7 @@ int32_t sgfhe_pack_encrypted_bits(sgfhe_ctx *c, const uint64_t *a, const uint64_
         rc = bootstrap_device(c, d_a1, d_b1, d_a2, d_b2, nb, (uint64_t *)d_raw, SGFHE_FLAG_RAW_MODQ,
                               c->n, nullptr, c->stream);
         if (rc) break;
-        const RndArgs ra = {(uint32_t)c->rnd_seed, (uint32_t)(c->rnd_seed >> 32), c->last_call, 0u};
+        const RndArgs ra = {c->rnd_key, c->last_call, 0u};
         const size_t tf = count * n * len;
         hipLaunchKernelGGL(k_pack_flatten, dim3((unsigned)((tf + 255) / 256)), dim3(256), 0, c->stream,
                            d_raw, d_pdig, c->d_crt, (uint32_t)count, (uint32_t)n, (uint32_t)c->logm,

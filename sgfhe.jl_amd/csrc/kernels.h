@@ -199,39 +199,73 @@ __device__ __forceinline__ void store_digits(uint64_t *__restrict__ dig, size_t 
 }
 
 // ---- randomised flatten (utils.jl:198-241) ----------------------------------------------------------
-// Philox4x32-10 counter-based generator: (counter, key) -> 128 random bits.  Functional parity
-// only: the reference draws from Julia's MersenneTwister, which is not reproducible here.
+// The draws come from a ChaCha counter stream (the RFC 8439 block function with SGFHE_RND_ROUNDS
+// rounds, 8 by default: "ChaCha8") keyed with the caller's 32 bytes, so the digit perturbations are
+// cryptographically strong when the key is.  (Rounds 1-3 used Philox4x32-10 keyed by 64 bits: a
+// statistical generator.)  Functional parity only: the reference draws from the caller's Julia
+// rng, whose stream cannot be reproduced here.
 // The draw for a digit pair is addressed by a counter that does not depend on how a batch is cut
-// into chunks or scheduled:
-//   counter = (x: coefficient index (c << log2 m) + i of the accumulator pair (c = 0: a, 1: b),
-//              y: 0 for the initial accumulators, k + 1 after k-loop iteration k
-//                 (pack_encrypted_bits' flatten of as_i: 2^31 | i),
-//              z: index of the bootstrap within the call (of the ciphertext, for packing),
-//              w: number of the call since sgfhe_set_random_flatten),   key = seed.
+// into chunks or scheduled: the 128 bits of coefficient x are words 4 (x mod 4) .. + 3 of the block
+// whose state words 12 .. 15 are
+//   (x div 4   with x = coefficient index (c << log2 m) + i of the accumulator pair (c = 0: a, 1: b),
+//    y: 0 for the initial accumulators, k + 1 after k-loop iteration k
+//       (pack_encrypted_bits' flatten of as_i: 2^31 | i),
+//    z: index of the bootstrap within the call (of the ciphertext, for packing),
+//    w: number of the call since sgfhe_set_random_flatten),
+// so a thread of k_crt_lean_rnd (four adjacent coefficients) computes exactly one block.
 // oracle/bigint_oracle.py restates the same stream, so the randomised mode is bit-comparable with
-// the oracle (not with Julia's MersenneTwister, which cannot be reproduced here).
+// the oracle.
+#ifndef SGFHE_RND_ROUNDS
+#define SGFHE_RND_ROUNDS 8
+#endif
+struct ChaChaKey {
+    uint32_t k[8];
+};
+// ChaCha block function (RFC 8439 section 2.3 with ROUNDS rounds): state words 12 .. 15 = c12 .. c15
+template <int ROUNDS>
+__device__ __forceinline__ void chacha_block(const ChaChaKey &key, uint32_t c12, uint32_t c13,
+                                             uint32_t c14, uint32_t c15, uint32_t (&out)[16]) {
+    static_assert(ROUNDS % 2 == 0, "double rounds");
+    const uint32_t s[16] = {0x61707865u, 0x3320646eu, 0x79622d32u, 0x6b206574u,
+                            key.k[0], key.k[1], key.k[2], key.k[3],
+                            key.k[4], key.k[5], key.k[6], key.k[7], c12, c13, c14, c15};
+    uint32_t x[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) x[i] = s[i];
+#define SGFHE_QR(a, b, c, d)                                                             \
+    x[a] += x[b]; x[d] = __builtin_rotateleft32(x[d] ^ x[a], 16);                        \
+    x[c] += x[d]; x[b] = __builtin_rotateleft32(x[b] ^ x[c], 12);                        \
+    x[a] += x[b]; x[d] = __builtin_rotateleft32(x[d] ^ x[a], 8);                         \
+    x[c] += x[d]; x[b] = __builtin_rotateleft32(x[b] ^ x[c], 7);
+#pragma unroll
+    for (int r = 0; r < ROUNDS / 2; r++) {
+        SGFHE_QR(0, 4, 8, 12) SGFHE_QR(1, 5, 9, 13) SGFHE_QR(2, 6, 10, 14) SGFHE_QR(3, 7, 11, 15)
+        SGFHE_QR(0, 5, 10, 15) SGFHE_QR(1, 6, 11, 12) SGFHE_QR(2, 7, 8, 13) SGFHE_QR(3, 4, 9, 14)
+    }
+#undef SGFHE_QR
+#pragma unroll
+    for (int i = 0; i < 16; i++) out[i] = x[i] + s[i];
+}
 struct RndArgs {
-    uint32_t key0, key1;   // seed
+    ChaChaKey key;         // 32-byte key of the draw stream
     uint32_t call, chunk;  // per-call counter, index of the chunk's first bootstrap in the call
 };
-__device__ __forceinline__ uint4 philox4x32(uint4 c, uint32_t k0, uint32_t k1) {
-#pragma unroll
-    for (int r = 0; r < 10; r++) {
-        const uint64_t p0 = (uint64_t)0xD2511F53u * c.x, p1 = (uint64_t)0xCD9E8D57u * c.z;  // one v_mad_u64_u32 each
-        const uint32_t h0 = (uint32_t)(p0 >> 32), l0 = (uint32_t)p0;
-        const uint32_t h1 = (uint32_t)(p1 >> 32), l1 = (uint32_t)p1;
-        c = make_uint4(h1 ^ c.y ^ k0, l1, h0 ^ c.w ^ k1, l0);
-        k0 += 0x9E3779B9u;
-        k1 += 0xBB67AE85u;
-    }
-    return c;
+// the 128 bits of one coefficient (ctr.x = its index): a quarter of its quad's block
+__device__ __forceinline__ uint4 rnd128(const RndArgs &ra, uint4 ctr) {
+    uint32_t w[16];
+    chacha_block<SGFHE_RND_ROUNDS>(ra.key, ctr.x >> 2, ctr.y, ctr.z, ctr.w, w);
+    const uint32_t q = ctr.x & 3u;
+    return make_uint4(q == 0 ? w[0] : q == 1 ? w[4] : q == 2 ? w[8] : w[12],
+                      q == 0 ? w[1] : q == 1 ? w[5] : q == 2 ? w[9] : w[13],
+                      q == 0 ? w[2] : q == 1 ? w[6] : q == 2 ? w[10] : w[14],
+                      q == 0 ? w[3] : q == 1 ? w[7] : q == 2 ? w[11] : w[15]);
 }
 // Digits of the randomised flatten of acc, given xn = (acc + (s + xmax)(1 + B)) mod Q:
 //   r_i = v_i + xmax uniform in [0, 2 xmax];  x2 = (xn - r_0 - r_1 B) mod Q = a' of utils.jl:179
 //   for the shifted value;  (lo, hi) = divmod(x2, B);  e_i = (lo, hi) + r_i  ( = u_i + s + xmax ).
 __device__ __forceinline__ ulonglong2 random_digits(u128 xn, const CrtConst *CC, const RndArgs &ra,
                                                     uint4 ctr) {
-    const uint4 rv = philox4x32(ctr, ra.key0, ra.key1);
+    const uint4 rv = rnd128(ra, ctr);
     const uint64_t span = 2 * CC->xmax + 1;
     const uint64_t r0 = (uint64_t)(((u128)(((uint64_t)rv.y << 32) | rv.x) * span) >> 64);
     const uint64_t r1 = (uint64_t)(((u128)(((uint64_t)rv.w << 32) | rv.z) * span) >> 64);
@@ -870,7 +904,7 @@ k_crt_lean(const uint32_t *__restrict__ yres, uint64_t *__restrict__ dig,
 // so the draws enter as 2 xmax - r_i >= 0 added to the old digits, the constant
 // cR = (-2 xmax (1 + B)) mod Q puts the shift back, and the one quotient step of crt_lean_one gives
 // x2 directly -- no reduction of r_1 B + r_0, no second quotient.  New stored digits: those of x2
-// plus r_i.  Same Philox counters as k_crt_acc, bit-identical output (tests: the oracle; the
+// plus r_i.  Same stream addressing as k_crt_acc (random_digits), bit-identical output (tests: the oracle; the
 // register widths: tests/rns_model.py CrtLean.digits_random).
 template <int NP, int NL, bool WIDE>
 __global__ void __launch_bounds__(256)
@@ -901,15 +935,16 @@ k_crt_lean_rnd(const uint32_t *__restrict__ yres, uint64_t *__restrict__ dig,
     const uint32_t h1w[4] = {h1.x & 0xFFFFu, h1.x >> 16, h1.y & 0xFFFFu, h1.y >> 16};
     const uint64_t xm2 = ((uint64_t)K->xm2hi << 32) | K->xm2lo, span = xm2 + 1;
     const uint32_t cx = ((bc & 1u) << logm) + i, cz = ra.chunk + (bc >> 1);
+    uint32_t rw[16];   // the draws of the thread's four coefficients: one block of the stream
+    chacha_block<SGFHE_RND_ROUNDS>(ra.key, cx >> 2, iter, cz, ra.call, rw);
     uint64_t nlo[4], nhi[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         uint32_t y[NP];
 #pragma unroll
         for (int q = 0; q < NP; q++) y[q] = j == 0 ? yv[q].x : j == 1 ? yv[q].y : j == 2 ? yv[q].z : yv[q].w;
-        const uint4 rv = philox4x32(make_uint4(cx + j, iter, cz, ra.call), ra.key0, ra.key1);
-        const uint64_t r0 = __umul64hi(((uint64_t)rv.y << 32) | rv.x, span);
-        const uint64_t r1 = __umul64hi(((uint64_t)rv.w << 32) | rv.z, span);
+        const uint64_t r0 = __umul64hi(((uint64_t)rw[4 * j + 1] << 32) | rw[4 * j], span);
+        const uint64_t r1 = __umul64hi(((uint64_t)rw[4 * j + 3] << 32) | rw[4 * j + 2], span);
         uint32_t hw0 = h0w[j], hw1 = h1w[j];
         if constexpr (WIDE) {
             hw0 |= ((t0 >> (8 * j)) & 0xFFu) << 16;
@@ -1371,30 +1406,9 @@ k_pack_finish(const uint32_t *__restrict__ yg, const ulonglong2 *__restrict__ ra
 // -> k_keygen_finish (b = a (*) s + e, + s_k G on the constant terms) -> k_key_transform.
 // ==================================================================================================
 
-struct ChaChaKey {
-    uint32_t k[8];
-};
 __device__ __forceinline__ void chacha20_block(const ChaChaKey &key, uint32_t counter, uint32_t n0,
                                                uint32_t n1, uint32_t n2, uint32_t (&out)[16]) {
-    const uint32_t s[16] = {0x61707865u, 0x3320646eu, 0x79622d32u, 0x6b206574u,
-                            key.k[0], key.k[1], key.k[2], key.k[3],
-                            key.k[4], key.k[5], key.k[6], key.k[7], counter, n0, n1, n2};
-    uint32_t x[16];
-#pragma unroll
-    for (int i = 0; i < 16; i++) x[i] = s[i];
-#define SGFHE_QR(a, b, c, d)                                                             \
-    x[a] += x[b]; x[d] = __builtin_rotateleft32(x[d] ^ x[a], 16);                        \
-    x[c] += x[d]; x[b] = __builtin_rotateleft32(x[b] ^ x[c], 12);                        \
-    x[a] += x[b]; x[d] = __builtin_rotateleft32(x[d] ^ x[a], 8);                         \
-    x[c] += x[d]; x[b] = __builtin_rotateleft32(x[b] ^ x[c], 7);
-#pragma unroll
-    for (int r = 0; r < 10; r++) {
-        SGFHE_QR(0, 4, 8, 12) SGFHE_QR(1, 5, 9, 13) SGFHE_QR(2, 6, 10, 14) SGFHE_QR(3, 7, 11, 15)
-        SGFHE_QR(0, 5, 10, 15) SGFHE_QR(1, 6, 11, 12) SGFHE_QR(2, 7, 8, 13) SGFHE_QR(3, 4, 9, 14)
-    }
-#undef SGFHE_QR
-#pragma unroll
-    for (int i = 0; i < 16; i++) out[i] = x[i] + s[i];
+    chacha_block<20>(key, counter, n0, n1, n2, out);
 }
 // (hi 2^64 + lo) mod Q for 2^16 <= Q < 2^94: long division in base 2^32 (quotients < 2^32 are
 // exact through the double-precision estimate of mod_wide)

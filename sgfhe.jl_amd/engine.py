@@ -125,9 +125,16 @@ class Engine:
         self._chk(self._L.sgfhe_set_small_batch_max(self._h, max_bootstraps))
 
     def set_random_flatten(self, enable, seed=0):
-        """rng != nothing branch of flatten (utils.jl:198-241): Philox stream of `seed`."""
-        self._chk(self._L.sgfhe_set_random_flatten(self._h, int(bool(enable)),
-                                                   seed & 0xFFFFFFFFFFFFFFFF))
+        """rng != nothing branch of flatten (utils.jl:198-241): the draws come from a ChaCha8 counter
+        stream keyed with `seed` -- 32 bytes (sgfhe_set_random_flatten_key), or an int taken as 32
+        little-endian bytes (tests, benchmarks; the convention of generate_key)."""
+        if isinstance(seed, (bytes, bytearray)):
+            if len(seed) != 32:
+                raise ValueError("random-flatten key: 32 bytes")
+            key = bytes(seed)
+        else:
+            key = int(seed).to_bytes(32, "little")
+        self._chk(self._L.sgfhe_set_random_flatten_key(self._h, int(bool(enable)), key))
 
     def _lwe_args(self, a1, b1, a2, b2):
         n = self.params.n

@@ -21,7 +21,7 @@ const libsgfhe_hip = get(ENV, "SGFHE_HIP_LIB", "libsgfhe_hip.so")
 
 # Revision of include/sgfhe_hip.h these ccalls were written for (SGFHE_ABI_VERSION): a library
 # built from another revision is refused when the module loads.
-const ABI_VERSION = UInt32(4)
+const ABI_VERSION = UInt32(5)
 
 function __init__()
     got = ccall((:sgfhe_abi_version, libsgfhe_hip), UInt32, ())
@@ -99,12 +99,12 @@ lwe_words(bits::AbstractVector{EncryptedBit}, n) =
      UInt64[reinterpret(UInt64, [b.lwe.b])[1] for b in bits])
 
 # rng = nothing: deterministic flatten (src/utils.jl:155-189), bit-exact with the CPU path.
-# rng::AbstractRNG: randomised flatten (src/utils.jl:198-241) from a device Philox stream seeded
-# by one draw of `rng` -- same distribution, not the same stream as the CPU path.
+# rng::AbstractRNG: randomised flatten (src/utils.jl:198-241) from a device ChaCha8 counter stream
+# keyed with 32 bytes of `rng` -- same distribution, not the same stream as the CPU path.
 function set_flatten_mode(hkey, rng)
-    seed = rng === nothing ? UInt64(0) : rand(rng, UInt64)
-    check(hkey.ctx, ccall((:sgfhe_set_random_flatten, libsgfhe_hip), Int32,
-                          (Ptr{Cvoid}, Cint, UInt64), hkey.ctx, rng === nothing ? 0 : 1, seed))
+    key = rng === nothing ? zeros(UInt8, 32) : rand(rng, UInt8, 32)
+    check(hkey.ctx, ccall((:sgfhe_set_random_flatten_key, libsgfhe_hip), Int32,
+                          (Ptr{Cvoid}, Cint, Ptr{UInt8}), hkey.ctx, rng === nothing ? 0 : 1, key))
 end
 
 """

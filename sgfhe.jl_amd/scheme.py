@@ -383,11 +383,11 @@ def decrypt(key, ct):
 
 def _set_flatten_mode(bkey, rng):
     """rng = None: deterministic flatten (bit-exact with the reference's `rng = nothing`); a numpy
-    Generator: randomised flatten on the device, seeded from it."""
+    Generator: randomised flatten on the device, its ChaCha8 draw stream keyed with 32 bytes of it."""
     if rng is None:
         bkey.engine.set_random_flatten(False)
     else:
-        bkey.engine.set_random_flatten(True, int(rng.integers(0, 1 << 63, dtype=np.uint64)))
+        bkey.engine.set_random_flatten(True, rng.bytes(32))
 
 
 def bootstrap(bkey, rng, enc_bit1, enc_bit2):

@@ -739,16 +739,41 @@ def ntt_reference(poly, psi, p):
 
 # ---- kernels.h: one k-loop iteration ---------------------------------------------------------------
 
-def philox4x32(ctr, k0, k1):
-    """Philox4x32-10 (kernels.h philox4x32): ctr = (x, y, z, w) -> four 32-bit words."""
-    c = [int(v) & MASK32 for v in ctr]
-    for _ in range(10):
-        p0 = 0xD2511F53 * c[0]
-        p1 = 0xCD9E8D57 * c[2]
-        c = [((p1 >> 32) ^ c[1] ^ k0) & MASK32, p1 & MASK32, ((p0 >> 32) ^ c[3] ^ k1) & MASK32, p0 & MASK32]
-        k0 = (k0 + 0x9E3779B9) & MASK32
-        k1 = (k1 + 0xBB67AE85) & MASK32
-    return c
+def chacha_block(key_words, c12, c13, c14, c15, rounds=8):
+    """chacha_block<ROUNDS> of kernels.h (RFC 8439 block function): 16 output words."""
+    s = [0x61707865, 0x3320646e, 0x79622d32, 0x6b206574] + [int(k) & MASK32 for k in key_words] + \
+        [int(c) & MASK32 for c in (c12, c13, c14, c15)]
+    x = list(s)
+
+    def rotl(v, n):
+        return ((v << n) | (v >> (32 - n))) & MASK32
+
+    def qr(a, b, c, d):
+        x[a] = (x[a] + x[b]) & MASK32; x[d] = rotl(x[d] ^ x[a], 16)
+        x[c] = (x[c] + x[d]) & MASK32; x[b] = rotl(x[b] ^ x[c], 12)
+        x[a] = (x[a] + x[b]) & MASK32; x[d] = rotl(x[d] ^ x[a], 8)
+        x[c] = (x[c] + x[d]) & MASK32; x[b] = rotl(x[b] ^ x[c], 7)
+
+    for _ in range(rounds // 2):
+        qr(0, 4, 8, 12); qr(1, 5, 9, 13); qr(2, 6, 10, 14); qr(3, 7, 11, 15)
+        qr(0, 5, 10, 15); qr(1, 6, 11, 12); qr(2, 7, 8, 13); qr(3, 4, 9, 14)
+    return [(x[i] + s[i]) & MASK32 for i in range(16)]
+
+
+_rnd_cache = {}
+
+
+def rnd128(key, ctr):
+    """rnd128 of kernels.h: the four words of the draw addressed by ctr = (x, y, z, w); key = the
+    seed of sgfhe_set_random_flatten (an int: 32 little-endian bytes).  Coefficients 4 q .. 4 q + 3
+    share block q."""
+    x, y, z, w = (int(v) & MASK32 for v in ctr)
+    tag = (key, x >> 2, y, z, w)
+    if tag not in _rnd_cache:
+        _rnd_cache.clear()
+        _rnd_cache[tag] = chacha_block([(key >> (32 * i)) & MASK32 for i in range(8)], x >> 2, y, z, w)
+    blk = _rnd_cache[tag]
+    return blk[4 * (x & 3):4 * (x & 3) + 4]
 
 
 class EngineModel:
@@ -837,7 +862,7 @@ class EngineModel:
         """random_digits of kernels.h: stored digits e_i = u_i + s + xmax of the randomised flatten of
         the accumulator whose shifted value is xn = (acc + (s + xmax)(1 + B)) mod Q."""
         C = self.C
-        rv = philox4x32(ctr, key & MASK32, (key >> 32) & MASK32)
+        rv = rnd128(key, ctr)
         span = 2 * C.xmax + 1
         r0 = (((rv[1] << 32) | rv[0]) * span) >> 64
         r1 = (((rv[3] << 32) | rv[2]) * span) >> 64

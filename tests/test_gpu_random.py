@@ -1,5 +1,5 @@
 """Randomised flatten (`rng::AbstractRNG` branch, src/utils.jl:198-241) on the HIP engine against
-the oracle's literal restatement on the same Philox stream: accumulators, raw and ModRed outputs
+the oracle's literal restatement on the same ChaCha8 stream: accumulators, raw and ModRed outputs
 and the digits themselves bit for bit, the reference's digit limits (test/internals.test.jl:48-112,
 use_rng = true) on the device digits, and randomised pack_encrypted_bits (test/api.test.jl:86-108).
 Run on the GPU box with `pytest -m gpu`."""
@@ -32,7 +32,7 @@ def _setup(S, oc, params, key_seed, noise=None, random_flatten=False):
 
 def _oracle_run(bp, bk, a1, b1, a2, b2, boot, call, checkpoints):
     """Oracle bootstrap of one input pair as bootstrap `boot` of call `call`."""
-    rng = BO.PhiloxFlatten(bp, SEED, boot, call)
+    rng = BO.ChaChaFlatten(bp, SEED, boot, call)
     acc = {}
 
     def trace(k, a, b):

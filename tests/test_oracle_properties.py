@@ -93,17 +93,29 @@ def test_flatten_random_exhaustive(B, ell):
             assert all(x <= lim_hi or x >= lim_lo for x in d)
 
 
-def test_philox_known_answer_and_draw_range():
-    """Philox4x32-10 against the Random123 known-answer vectors; the engine's draw mapping stays
-    inside [-xmax, xmax] and reaches both ends of it."""
-    assert BO.philox4x32((0, 0, 0, 0), 0) == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
-    assert BO.philox4x32((0xffffffff,) * 4, 0xffffffffffffffff) == [0x408f276d, 0x41c83b0e,
-                                                                     0xa20bc7c6, 0x6d5451fd]
-    assert BO.philox4x32((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344),
-                         (0x299f31d0 << 32) | 0xa4093822) == [0xd16cfe09, 0x94fdcceb, 0x5001e420,
-                                                              0x24126ea1]
+def test_draw_stream_known_answers_and_draw_range():
+    """The draw stream's block function against published ChaCha vectors: ChaCha8 and ChaCha20 of
+    the all-zero key / counter / nonce (draft-strombergson-chacha-test-vectors, TC1, 256-bit key)
+    and the RFC 8439 section 2.3.2 block; the addressing of rnd128 (coefficient x = a quarter of
+    block x div 4); the engine's draw mapping stays inside [-xmax, xmax] and reaches both ends."""
+    z = bytes(32)
+    assert BO.chacha_blocks(z, 0, 0, 0, 0, 8)[0].astype("<u4").tobytes().hex() == (
+        "3e00ef2f895f40d67f5bb8e81f09a5a12c840ec3ce9a7f3b181be188ef711a1e"
+        "984ce172b9216f419f445367456d5619314a42a3da86b001387bfdb80e0cfe42")
+    assert BO.chacha_blocks(z, 0, 0, 0, 0, 20)[0].astype("<u4").tobytes().hex() == (
+        "76b8e0ada0f13d90405d6ae55386bd28bdd219b8a08ded1aa836efcc8b770dc7"
+        "da41597c5157488d7724e03fb8d84a376a43b8f41518a11cc387b669b2ee6586")
+    rfc = BO.chacha_blocks(bytes(range(32)), 1, 0x09000000, 0x4a000000, 0, 20)[0]
+    assert [int(v) for v in rfc[:4]] == [0xe4e7f110, 0x15593bd1, 0x1fdd0f50, 0xc47120a3]
+    assert int(rfc[15]) == 0x4e3c50a2
+    assert BO.RND_ROUNDS == 8
+    key = bytes(range(100, 132))
+    blk = [int(v) for v in BO.chacha_blocks(key, 0x123, 7, 8, 9, 8)[0]]
+    for q in range(4):
+        assert BO.rnd128(key, (4 * 0x123 + q, 7, 8, 9)) == blk[4 * q:4 * q + 4]
+    assert BO.seed_bytes(5) == (5).to_bytes(32, "little")
     p = BO.Params.custom(8, 17, 5)                                 # tiny base: both ends show up
-    g = BO.PhiloxFlatten(p, 12345)
+    g = BO.ChaChaFlatten(p, 12345)
     vals = [g.draws(c, y)(j, i) for c in (0, 1) for y in range(8) for j in range(64) for i in (0, 1)]
     assert min(vals) == -g.xmax and max(vals) == g.xmax and g.xmax == 6
 
@@ -313,7 +325,7 @@ def test_chacha20_key_stream_vectors(oc):
         o.bootstrap_key(sk, b"short")
 
 
-# ---- test/api.test.jl:45-83 / :86-108 with use_rng = true, on the engine's Philox stream -----------
+# ---- test/api.test.jl:45-83 / :86-108 with use_rng = true, on the engine's ChaCha8 stream -----------
 
 def test_randomised_bootstrap_and_pack_decrypt():
     """bootstrap(bkey, rng, ...) and pack_encrypted_bits(bkey, rng, ...) with the randomised
@@ -329,10 +341,10 @@ def test_randomised_bootstrap_and_pack_decrypt():
         for y2 in (0, 1):
             l1, l2 = BO.lwe_encrypt_bit(p, sk, y1, g), BO.lwe_encrypt_bit(p, sk, y2, g)
             det = BO.bootstrap(p, bk, l1, l2)
-            rnd = BO.bootstrap(p, bk, l1, l2, rng=BO.PhiloxFlatten(p, 5, boot=3, call=1))
+            rnd = BO.bootstrap(p, bk, l1, l2, rng=BO.ChaChaFlatten(p, 5, boot=3, call=1))
             assert rnd != det
-            assert rnd == BO.bootstrap(p, bk, l1, l2, rng=BO.PhiloxFlatten(p, 5, boot=3, call=1))
-            assert rnd != BO.bootstrap(p, bk, l1, l2, rng=BO.PhiloxFlatten(p, 5, boot=4, call=1))
+            assert rnd == BO.bootstrap(p, bk, l1, l2, rng=BO.ChaChaFlatten(p, 5, boot=3, call=1))
+            assert rnd != BO.bootstrap(p, bk, l1, l2, rng=BO.ChaChaFlatten(p, 5, boot=4, call=1))
             assert [BO.lwe_decrypt_bit(p, sk, o) for o in rnd] == [y1 & y2, y1 | y2, y1 ^ y2]
     bits = [1, 0, 0, 1, 1, 1, 0, 1]
     lwes = [BO.lwe_encrypt_bit(p, sk, b, g) for b in bits]

@@ -131,7 +131,7 @@ def test_pipeline_matches_oracle():
 
 
 def test_pipeline_matches_oracle_randomised():
-    """The same with the randomised flatten: the model's Philox digits (device counter layout,
+    """The same with the randomised flatten: the model's ChaCha8 digits (device counter layout,
     shifted representation e = u + s + xmax) against the oracle's literal restatement of
     src/utils.jl:198-241 on the same stream -- accumulators after every k, and the stored digits
     equal the oracle's flatten output shifted, inside (-2B, 2B]."""
@@ -149,7 +149,7 @@ def test_pipeline_matches_oracle_randomised():
     l1 = BO.lwe_encrypt_bit(p, sk, 1, g)
     l2 = BO.lwe_encrypt_bit(p, sk, 0, g)
     seed, boot, call = 0x1234567890ABCDEF, 11, 2
-    rng = BO.PhiloxFlatten(p, seed, boot, call)
+    rng = BO.ChaChaFlatten(p, seed, boot, call)
     trace = []
     BO.bootstrap_internal(p, bk, l1, l2, trace=lambda k, a, b: trace.append((list(a), list(b))), rng=rng)
     ua = [(x + y) % p.r for x, y in zip(l1[0], l2[0])]
