@@ -10,7 +10,7 @@ src/rns.jl:51-60) -- the big-integer oracle would need hours for the 1 GiB key -
 the big-integer oracle where that is affordable: every key polynomial product of slices 0 and 1
 and the accumulators after the first two iterations are recomputed with Kronecker products.
 
-Usage: python tests/golden/make_golden.py [p64] [extprod] [tables] [p512] [p1024] [pack64] [cfg4]
+Usage: python tests/golden/make_golden.py [p64] [p64rnd] [extprod] [tables] [p512] [p1024] [pack64] [cfg4]
 """
 
 import hashlib
@@ -79,6 +79,40 @@ def bootstrap_case(n, sk_seed, key_seed, in_seed, pairs, checkpoints, full_outpu
             "prng": "SplitMix64 (oracle/bigint_oracle.py)", "sk_seed": sk_seed,
             "key_seed": key_seed, "in_seed": in_seed, "sk": sk, "key_sha256": key_hash(bk),
             "cases": cases}
+
+
+def random_flatten_case():
+    """Params(64) with the randomised flatten (src/utils.jl:198-241) on the engine's ChaCha8 draw
+    stream: the key and inputs of p64's cases (1, 0) and (1, 1) as ONE call of two bootstraps
+    (bootstrap j draws with index j, call 0).  Pins the stream's definition (key bytes, counter
+    layout, draw mapping) as well as the algorithm."""
+    p = O.Params.make(64)
+    sk = O.private_key(p, 1)
+    bk = O.bootstrap_key(p, sk, 2)
+    g = O.SplitMix64(3)
+    lwes = {}
+    for pair in [(0, 0), (0, 1), (1, 0), (1, 1)]:                  # the draws of bootstrap_case
+        lwes[pair] = (O.lwe_encrypt_bit(p, sk, pair[0], g), O.lwe_encrypt_bit(p, sk, pair[1], g))
+    fkey = bytes(range(7, 39))
+    cases = []
+    for j, pair in enumerate([(1, 0), (1, 1)]):
+        l1, l2 = lwes[pair]
+        cps = {}
+
+        def trace(k, a, b):
+            if (k + 1) in (1, 2, 64):
+                cps[str(k + 1)] = [h_ints(a), h_ints(b)]
+        raw = O.bootstrap_internal(p, bk, l1, l2, trace=trace, rng=O.ChaChaFlatten(p, fkey, boot=j, call=0))
+        out = [([O.reduce_modulus(p.r, x, p.Q) for x in a], O.reduce_modulus(p.r, b, p.Q)) for a, b in raw]
+        y1, y2 = pair
+        assert [O.lwe_decrypt_bit(p, sk, o) for o in out] == [y1 & y2, y1 | y2, y1 ^ y2]
+        cases.append({"bits": list(pair), "lwe1": {"a": l1[0], "b": l1[1]}, "lwe2": {"a": l2[0], "b": l2[1]},
+                      "acc_sha256_after": cps, "raw_sha256": [h_ints(a + [b]) for a, b in raw],
+                      "out": [a + [b] for a, b in out]})
+    return {"params": {"n": p.n, "r": p.r, "m": p.m, "Q": str(p.Q), "B": str(p.B)},
+            "sk_seed": 1, "key_seed": 2, "in_seed": 3, "key_sha256": key_hash(bk),
+            "flatten_key_hex": fkey.hex(), "stream": "ChaCha8, oracle/bigint_oracle.py ChaChaFlatten",
+            "call": 0, "cases": cases}
 
 
 def extprod_case():
@@ -208,7 +242,7 @@ def cfg4_case():
 
 
 def main():
-    what = sys.argv[1:] or ["p64", "extprod", "tables", "p512", "p1024", "pack64", "cfg4"]
+    what = sys.argv[1:] or ["p64", "p64rnd", "extprod", "tables", "p512", "p1024", "pack64", "cfg4"]
     pairs4 = [(0, 0), (0, 1), (1, 0), (1, 1)]
     for w in what:
         print(w, flush=True)
@@ -220,6 +254,8 @@ def main():
             d = bootstrap_case(1024, 21, 22, 23, [(1, 1)], {1, 2, 512, 1024})
         elif w == "extprod":
             d = extprod_case()
+        elif w == "p64rnd":
+            d = random_flatten_case()
         elif w == "tables":
             d = tables()
         elif w == "pack64":

@@ -86,6 +86,25 @@ def test_params64_golden(oc):
     _check_bootstrap_golden(oc, "p64", full=True)
 
 
+def test_params64_random_flatten_golden():
+    """The randomised flatten on the ChaCha8 draw stream (golden/p64rnd.json): the big-integer
+    restatement reproduces the committed outputs, and the inputs are p64.json's."""
+    d, d0 = load("p64rnd"), load("p64")
+    p = BO.Params.make(64)
+    sk = BO.private_key(p, d["sk_seed"])
+    bk = BO.bootstrap_key(p, sk, d["key_seed"])
+    fkey = bytes.fromhex(d["flatten_key_hex"])
+    by_bits = {tuple(c["bits"]): c for c in d0["cases"]}
+    for j, case in enumerate(d["cases"]):
+        assert case["lwe1"] == by_bits[tuple(case["bits"])]["lwe1"]
+        assert case["raw_sha256"] != by_bits[tuple(case["bits"])]["raw_sha256"]    # not the deterministic result
+        l1, l2 = (case["lwe1"]["a"], case["lwe1"]["b"]), (case["lwe2"]["a"], case["lwe2"]["b"])
+        raw = BO.bootstrap_internal(p, bk, l1, l2, rng=BO.ChaChaFlatten(p, fkey, boot=j, call=d["call"]))
+        assert [h_ints(a + [b]) for a, b in raw] == case["raw_sha256"]
+        out = [[BO.reduce_modulus(p.r, x, p.Q) for x in a] + [BO.reduce_modulus(p.r, b, p.Q)] for a, b in raw]
+        assert out == case["out"]
+
+
 def test_params512_golden(oc):
     _check_bootstrap_golden(oc, "p512", full=True)
 

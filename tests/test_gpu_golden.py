@@ -25,6 +25,49 @@ def _u128_ints(arr):
     return [int(lo) | (int(hi) << 64) for lo, hi in flat]
 
 
+def test_engine_matches_random_flatten_golden(S, oc):
+    """golden/p64rnd.json: two bootstraps in ONE call with the randomised flatten on the ChaCha8
+    draw stream of a 32-byte key -- accumulators after 1, 2 and 64 iterations, raw and ModRed
+    outputs equal the committed big-integer results."""
+    d = json.load(open(os.path.join(G, "p64rnd.json")))
+    params = S.Params(64)
+    o = oc.Oracle.from_params(params)
+    sk = o.private_key(d["sk_seed"])
+    bkey = o.bootstrap_key(sk, d["key_seed"])
+    assert hashlib.sha256(np.ascontiguousarray(bkey).tobytes()).hexdigest() == d["key_sha256"]
+    fkey = bytes.fromhex(d["flatten_key_hex"])
+    a1 = np.array([c["lwe1"]["a"] for c in d["cases"]], dtype=np.uint64)
+    a2 = np.array([c["lwe2"]["a"] for c in d["cases"]], dtype=np.uint64)
+    b1, b2 = [c["lwe1"]["b"] for c in d["cases"]], [c["lwe2"]["b"] for c in d["cases"]]
+    eng = S.Engine(params)
+    try:
+        eng.upload_key(bkey)
+        for k in ("1", "2", "64"):
+            eng.set_random_flatten(True, fkey)                      # call number back to 0
+            acc = eng.debug_accumulators(a1, b1, a2, b2, int(k))
+            for j, case in enumerate(d["cases"]):
+                assert [h_ints(_u128_ints(acc[j, 0])), h_ints(_u128_ints(acc[j, 1]))] == case["acc_sha256_after"][k]
+        eng.set_random_flatten(True, fkey)
+        raw = eng.bootstrap_batch(a1, b1, a2, b2, raw=True)
+        eng.set_random_flatten(True, fkey)
+        out = eng.bootstrap_batch(a1, b1, a2, b2)
+        for j, case in enumerate(d["cases"]):
+            for g in range(3):
+                assert h_ints(_u128_ints(raw[j, g])) == case["raw_sha256"][g]
+                assert [int(v) for v in out[j, g]] == case["out"][g]
+        # the 64-bit short form is the same key with zero upper bytes, not this key
+        eng.set_random_flatten(True, int.from_bytes(fkey[:8], "little"))
+        assert not np.array_equal(eng.bootstrap_batch(a1, b1, a2, b2), out)
+        eng.set_random_flatten(True, int.from_bytes(fkey[:8], "little"))
+        short = eng.bootstrap_batch(a1, b1, a2, b2)
+        assert eng._L.sgfhe_set_random_flatten(eng._h, 1, int.from_bytes(fkey[:8], "little")) == 0   # the C short form
+        assert np.array_equal(eng.bootstrap_batch(a1, b1, a2, b2), short)
+        with pytest.raises(ValueError):
+            eng.set_random_flatten(True, b"short")
+    finally:
+        eng.close()
+
+
 @pytest.mark.parametrize("name", ["p64", "p512", "p1024"])
 def test_engine_matches_golden(S, oc, name):
     path = os.path.join(G, name + ".json")
