@@ -120,6 +120,14 @@ struct sgfhe_ctx {
     // not pay a hipMalloc / hipFree pair (hipFree synchronises the device)
     uint64_t *io_in = nullptr, *io_out = nullptr;
     size_t io_in_words = 0, io_out_words = 0;
+    // ... and their page-locked host mirrors.  hipMemcpyAsync on pageable memory above about 1 MB
+    // pins the caller's pages for the copy, a fixed cost of several milliseconds per copy
+    // (profiles/r03_latency.txt: 256 gates 155.6 ms through host pointers against 127.6 ms from
+    // device buffers, 64 gates 43.6 against 43.4); below PIN_MAX_BYTES per buffer the engine
+    // copies through its own pinned buffers instead (one CPU memcpy + one true DMA).
+    uint64_t *pin_in = nullptr, *pin_out = nullptr;
+    size_t pin_in_words = 0, pin_out_words = 0;
+    bool use_pin = true;   // SGFHE_HOST_PIN=0 in the environment: direct copies (A/B measurements)
     // timing
     bool timing = false;
     struct EvTriple { hipEvent_t e0, e1, e2; };  // ext = e0 -> e1, crt = e1 -> e2
@@ -138,6 +146,7 @@ struct sgfhe_ctx {
     uint32_t attr_done = 0;
 };
 enum : uint32_t { ATTR_EXTPROD = 1u, ATTR_SMALL = 2u, ATTR_SHORTPROD = 4u };
+static constexpr size_t PIN_MAX_BYTES = (size_t)48 << 20;   // per buffer: above it the CPU memcpy costs more than the pinning
 
 namespace {
 
@@ -770,6 +779,8 @@ int32_t build_constants(sgfhe_ctx *c) {
         }
         const char *env = getenv("SGFHE_CRT_LEAN");
         c->use_lean = !(env && env[0] == '0');
+        env = getenv("SGFHE_HOST_PIN");
+        c->use_pin = !(env && env[0] == '0');
     }
 
     // twiddle tables and per-prime constants (all residues centred: |.| <= (p - 1) / 2)
@@ -1015,6 +1026,8 @@ int32_t sgfhe_ctx_destroy(sgfhe_ctx *c) {
     if (c->d_lean) (void)hipFree(c->d_lean);
     if (c->io_in) (void)hipFree(c->io_in);
     if (c->io_out) (void)hipFree(c->io_out);
+    if (c->pin_in) (void)hipHostFree(c->pin_in);
+    if (c->pin_out) (void)hipHostFree(c->pin_out);
     if (c->d_bad) (void)hipFree(c->d_bad);
     if (c->d_tw) (void)hipFree(c->d_tw);
     if (c->d_key) (void)hipFree(c->d_key);
@@ -1346,6 +1359,24 @@ static int32_t bootstrap_host(sgfhe_ctx *c, const uint64_t *a1, const uint64_t *
     }
     d_in = c->io_in;
     if (out) d_out = c->io_out;
+    // page-locked mirrors, grown on demand; a failed allocation falls back to direct copies
+    const size_t a_bytes = batch * n * 8;
+    bool stage_in = c->use_pin && a_bytes <= PIN_MAX_BYTES;
+    bool stage_out = c->use_pin && out && out_words * 8 <= PIN_MAX_BYTES;
+    if (stage_in && in_words > c->pin_in_words) {
+        if (c->pin_in) (void)hipHostFree(c->pin_in);
+        c->pin_in = nullptr;
+        c->pin_in_words = 0;
+        if (hipHostMalloc(&c->pin_in, in_words * 8, hipHostMallocDefault) == hipSuccess) c->pin_in_words = in_words;
+        else { (void)hipGetLastError(); c->pin_in = nullptr; stage_in = false; }
+    }
+    if (stage_out && out_words > c->pin_out_words) {
+        if (c->pin_out) (void)hipHostFree(c->pin_out);
+        c->pin_out = nullptr;
+        c->pin_out_words = 0;
+        if (hipHostMalloc(&c->pin_out, out_words * 8, hipHostMallocDefault) == hipSuccess) c->pin_out_words = out_words;
+        else { (void)hipGetLastError(); c->pin_out = nullptr; stage_out = false; }
+    }
     int32_t rc = SGFHE_OK;
     hipError_t e = hipSuccess;
     uint64_t *d_a1 = d_in, *d_a2 = d_in + batch * n, *d_b1 = d_in + 2 * batch * n,
@@ -1353,20 +1384,30 @@ static int32_t bootstrap_host(sgfhe_ctx *c, const uint64_t *a1, const uint64_t *
     do {
         if (acc && (e = hipMalloc(&d_acc, acc_words * 8)) != hipSuccess) break;
         if (digs && (e = hipMalloc(&d_dig, dig_words * 8)) != hipSuccess) break;
-        if ((e = hipMemcpyAsync(d_a1, a1, batch * n * 8, hipMemcpyHostToDevice, c->stream))) break;
-        if ((e = hipMemcpyAsync(d_a2, a2, batch * n * 8, hipMemcpyHostToDevice, c->stream))) break;
-        if ((e = hipMemcpyAsync(d_b1, b1, batch * 8, hipMemcpyHostToDevice, c->stream))) break;
-        if ((e = hipMemcpyAsync(d_b2, b2, batch * 8, hipMemcpyHostToDevice, c->stream))) break;
+        if (stage_in) {   // same layout as the device buffer: one DMA
+            memcpy(c->pin_in, a1, a_bytes);
+            memcpy(c->pin_in + batch * n, a2, a_bytes);
+            memcpy(c->pin_in + 2 * batch * n, b1, batch * 8);
+            memcpy(c->pin_in + 2 * batch * n + batch, b2, batch * 8);
+            if ((e = hipMemcpyAsync(d_in, c->pin_in, in_words * 8, hipMemcpyHostToDevice, c->stream))) break;
+        } else {
+            if ((e = hipMemcpyAsync(d_a1, a1, a_bytes, hipMemcpyHostToDevice, c->stream))) break;
+            if ((e = hipMemcpyAsync(d_a2, a2, a_bytes, hipMemcpyHostToDevice, c->stream))) break;
+            if ((e = hipMemcpyAsync(d_b1, b1, batch * 8, hipMemcpyHostToDevice, c->stream))) break;
+            if ((e = hipMemcpyAsync(d_b2, b2, batch * 8, hipMemcpyHostToDevice, c->stream))) break;
+        }
         rc = bootstrap_device(c, d_a1, d_b1, d_a2, d_b2, batch, d_out, flags, n_iters, d_acc,
                               c->stream, d_dig);
         if (rc) break;
         if (digs && (e = hipMemcpyAsync(digs, d_dig, dig_words * 8, hipMemcpyDeviceToHost, c->stream)))
             break;
-        if (out && (e = hipMemcpyAsync(out, d_out, out_words * 8, hipMemcpyDeviceToHost, c->stream)))
+        if (out && (e = hipMemcpyAsync(stage_out ? c->pin_out : out, d_out, out_words * 8,
+                                       hipMemcpyDeviceToHost, c->stream)))
             break;
         if (acc && (e = hipMemcpyAsync(acc, d_acc, acc_words * 8, hipMemcpyDeviceToHost, c->stream)))
             break;
         e = hipStreamSynchronize(c->stream);
+        if (e == hipSuccess && stage_out) memcpy(out, c->pin_out, out_words * 8);
     } while (0);
     if (e != hipSuccess && rc == SGFHE_OK) rc = fail(c, SGFHE_ERR_HIP, hipGetErrorString(e));
     if (d_acc) (void)hipFree(d_acc);   // debug hooks only

@@ -238,3 +238,15 @@ def test_key_generation_rejects_noise_out_of_range(S):
     eng.close()
     with pytest.raises(ValueError):
         oracle_c.Oracle.from_params(params).bootstrap_key(sk, 5, noise=1 << 30)
+
+
+def test_random_flatten_key_arguments(S):
+    """sgfhe_set_random_flatten_key: a missing key is SGFHE_ERR_INVALID_ARG when the mode is
+    switched on and accepted when it is switched off; a ctx handle is required."""
+    eng = S.Engine(S.Params(64))
+    L = S.lib()
+    assert L.sgfhe_set_random_flatten_key(eng._h, 1, None) == -1
+    assert L.sgfhe_set_random_flatten_key(eng._h, 0, None) == 0
+    assert L.sgfhe_set_random_flatten_key(None, 1, bytes(32)) == -1
+    assert L.sgfhe_set_random_flatten_key(eng._h, 1, bytes(32)) == 0
+    eng.close()
