@@ -404,7 +404,7 @@ def main():
         if dist:
             dist.barrier()
         t1 = time.perf_counter()
-        hout = eng.bootstrap_batch(ha1, hb1, ha2, hb2)
+        hout = eng.bootstrap_batch(ha1, hb1, ha2, hb2, out=hout)
         hdt = time.perf_counter() - t1
         same = None if rnd else bool(np.array_equal(hout.view(np.int64), out.cpu().numpy()))
         if dist:

@@ -150,15 +150,21 @@ class Engine:
         keep = (a1, a2, b1, b2)
         return batch, (p1, q1, p2, q2), keep
 
-    def bootstrap_batch(self, a1, b1, a2, b2, raw=False, rns2=False):
+    def bootstrap_batch(self, a1, b1, a2, b2, raw=False, rns2=False, out=None):
         """bootstrap(bkey, nothing, ., .) (fhe.jl:608-621) over a batch of LWE pairs.
         Returns [batch][3][n+1] uint64 (AND, OR, XOR; a then b), or [batch][3][n+1][2] residues
         mod Q with raw=True (_bootstrap_internal, fhe.jl:559-595): {lo, hi} of the canonical
-        value, or with rns2=True the RNS2Number limb pair (v1, v2) (src/rns.jl:16-18)."""
+        value, or with rns2=True the RNS2Number limb pair (v1, v2) (src/rns.jl:16-18).
+        `out`: a C-contiguous uint64 array of that shape to write into (a caller in a loop keeps
+        its result buffer and its already-touched pages)."""
         batch, (p1, q1, p2, q2), _keep = self._lwe_args(a1, b1, a2, b2)
         n = self.params.n
         raw = raw or rns2
-        out = np.zeros((batch, 3, n + 1, 2) if raw else (batch, 3, n + 1), dtype=np.uint64)
+        shape = (batch, 3, n + 1, 2) if raw else (batch, 3, n + 1)
+        if out is None:
+            out = np.zeros(shape, dtype=np.uint64)
+        elif out.shape != shape or out.dtype != np.uint64 or not out.flags["C_CONTIGUOUS"]:
+            raise ValueError("bootstrap_batch: out must be a C-contiguous uint64 array of shape %r" % (shape,))
         if batch:
             self._chk(self._L.sgfhe_bootstrap_batch(
                 self._h, p1, q1, p2, q2, batch, out.ctypes.data_as(ctypes.c_void_p),
