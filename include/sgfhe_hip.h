@@ -178,7 +178,12 @@ int32_t sgfhe_bkey_import_device_form(sgfhe_ctx *ctx, const void *src_device);
  *   b1, b2 : [batch]    uint64 in [0, r)   (EncryptedBit.lwe.b)
  *   out    : [batch][3][n + 1] uint64: a[0..n) then b; gate order AND, OR, XOR
  *            (with SGFHE_FLAG_RAW_MODQ: [batch][3][n + 1][2], residues mod Q)
- * Deterministic flatten (rng = nothing, src/utils.jl:155-189).  Host pointers; synchronous.
+ * Deterministic flatten (rng = nothing, src/utils.jl:155-189) unless sgfhe_set_random_flatten[_key]
+ * selected the other.  Host pointers; synchronous.  Buffers of up to 48 MB travel through
+ * page-locked staging buffers the ctx keeps (one memcpy and one DMA per direction); larger ones are
+ * copied directly.  A caller in a loop should keep its `out` buffer: releasing a multi-megabyte
+ * array between calls (munmap) can stall the next call's kernels by tens of milliseconds.
+ * SGFHE_DEBUG_IO=1 in the environment prints the phases of every call to stderr.
  */
 int32_t sgfhe_bootstrap_batch(sgfhe_ctx *ctx, const uint64_t *a1, const uint64_t *b1,
                               const uint64_t *a2, const uint64_t *b2, size_t batch, uint64_t *out,

@@ -8,6 +8,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <chrono>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -1367,20 +1368,27 @@ static int32_t bootstrap_host(sgfhe_ctx *c, const uint64_t *a1, const uint64_t *
         if (c->pin_in) (void)hipHostFree(c->pin_in);
         c->pin_in = nullptr;
         c->pin_in_words = 0;
-        if (hipHostMalloc(&c->pin_in, in_words * 8, hipHostMallocDefault) == hipSuccess) c->pin_in_words = in_words;
+        const hipError_t pe = hipHostMalloc(&c->pin_in, in_words * 8, hipHostMallocDefault);
+        if (pe == hipSuccess) c->pin_in_words = in_words;
         else { (void)hipGetLastError(); c->pin_in = nullptr; stage_in = false; }
+        if (getenv("SGFHE_DEBUG_IO")) fprintf(stderr, "[sgfhe io] pin_in %zu bytes: %s\n", in_words * 8, hipGetErrorString(pe));
     }
     if (stage_out && out_words > c->pin_out_words) {
         if (c->pin_out) (void)hipHostFree(c->pin_out);
         c->pin_out = nullptr;
         c->pin_out_words = 0;
-        if (hipHostMalloc(&c->pin_out, out_words * 8, hipHostMallocDefault) == hipSuccess) c->pin_out_words = out_words;
+        const hipError_t pe = hipHostMalloc(&c->pin_out, out_words * 8, hipHostMallocDefault);
+        if (pe == hipSuccess) c->pin_out_words = out_words;
         else { (void)hipGetLastError(); c->pin_out = nullptr; stage_out = false; }
+        if (getenv("SGFHE_DEBUG_IO")) fprintf(stderr, "[sgfhe io] pin_out %zu bytes: %s\n", out_words * 8, hipGetErrorString(pe));
     }
     int32_t rc = SGFHE_OK;
     hipError_t e = hipSuccess;
     uint64_t *d_a1 = d_in, *d_a2 = d_in + batch * n, *d_b1 = d_in + 2 * batch * n,
              *d_b2 = d_b1 + batch;
+    const bool dbg = getenv("SGFHE_DEBUG_IO") != nullptr;
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t0 = now(), t1 = 0, t2 = 0, t3 = 0, t4 = 0;
     do {
         if (acc && (e = hipMalloc(&d_acc, acc_words * 8)) != hipSuccess) break;
         if (digs && (e = hipMalloc(&d_dig, dig_words * 8)) != hipSuccess) break;
@@ -1396,9 +1404,11 @@ static int32_t bootstrap_host(sgfhe_ctx *c, const uint64_t *a1, const uint64_t *
             if ((e = hipMemcpyAsync(d_b1, b1, batch * 8, hipMemcpyHostToDevice, c->stream))) break;
             if ((e = hipMemcpyAsync(d_b2, b2, batch * 8, hipMemcpyHostToDevice, c->stream))) break;
         }
+        t1 = now();
         rc = bootstrap_device(c, d_a1, d_b1, d_a2, d_b2, batch, d_out, flags, n_iters, d_acc,
                               c->stream, d_dig);
         if (rc) break;
+        t2 = now();
         if (digs && (e = hipMemcpyAsync(digs, d_dig, dig_words * 8, hipMemcpyDeviceToHost, c->stream)))
             break;
         if (out && (e = hipMemcpyAsync(stage_out ? c->pin_out : out, d_out, out_words * 8,
@@ -1407,7 +1417,12 @@ static int32_t bootstrap_host(sgfhe_ctx *c, const uint64_t *a1, const uint64_t *
         if (acc && (e = hipMemcpyAsync(acc, d_acc, acc_words * 8, hipMemcpyDeviceToHost, c->stream)))
             break;
         e = hipStreamSynchronize(c->stream);
+        t3 = now();
         if (e == hipSuccess && stage_out) memcpy(out, c->pin_out, out_words * 8);
+        t4 = now();
+        if (dbg)
+            fprintf(stderr, "[sgfhe io] batch %zu stage_in %d stage_out %d: copy-in %.2f ms, enqueue %.2f, wait %.2f, copy-out %.2f\n",
+                    batch, (int)stage_in, (int)stage_out, t1 - t0, t2 - t1, t3 - t2, t4 - t3);
     } while (0);
     if (e != hipSuccess && rc == SGFHE_OK) rc = fail(c, SGFHE_ERR_HIP, hipGetErrorString(e));
     if (d_acc) (void)hipFree(d_acc);   // debug hooks only

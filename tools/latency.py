@@ -23,9 +23,13 @@ for B in [int(x) for x in sys.argv[1:]] or [1, 8, 64, 256, 512]:
     # the drop-in signature (src/fhe.jl:608-610): host pointers in and out (sgfhe_bootstrap_batch)
     ha1, ha2 = a1.cpu().numpy().view(np.uint64), a2.cpu().numpy().view(np.uint64)
     hb1, hb2 = b1.cpu().numpy().view(np.uint64), b2.cpu().numpy().view(np.uint64)
+    # a caller in a loop keeps its result array (SGFHE_LATENCY_FRESH_OUT=1: a fresh one per call, whose
+    # release -- an munmap of pages the GPU driver has seen -- can stall the next call's kernels by
+    # 25-40 ms: profiles/r03_exp_host_pinned.txt)
+    hout = None
     for rep in range(3):
         t0 = time.perf_counter()
-        hout = eng.bootstrap_batch(ha1, hb1, ha2, hb2)
+        hout = eng.bootstrap_batch(ha1, hb1, ha2, hb2, out=None if os.environ.get("SGFHE_LATENCY_FRESH_OUT") else hout)
         hdt = time.perf_counter() - t0
     assert np.array_equal(hout.view(np.int64), out.cpu().numpy())
     print("batch %4d: %8.2f ms per call (device buffers), %8.2f ms (host buffers), %8.1f bootstraps/s"

@@ -53,6 +53,22 @@ KERNEL(k_add3, A_ADD3)
 #define A_SUBCND(i) "v_sub_co_u32 %" #i ", vcc, %" #i ", %8\nv_cndmask_b32 %" #i ", %" #i ", %8, vcc\n"
 #define A_SUBMIN(i) "v_sub_u32 %" #i ", %" #i ", %8\nv_min_u32 %" #i ", %" #i ", %8\n"
 #define A_MULLOHI(i) "v_mul_lo_u32 %" #i ", %" #i ", %8\nv_mul_hi_u32 %" #i ", %" #i ", %8\n"
+#define A_ASHR(i) "v_ashrrev_i32 %" #i ", 1, %" #i "\n"
+#define A_LSHL(i) "v_lshlrev_b32 %" #i ", 1, %" #i "\n"
+#define A_AND(i) "v_and_b32 %" #i ", %" #i ", %8\n"
+#define A_OR(i) "v_or_b32 %" #i ", %" #i ", %8\n"
+#define A_XAD(i) "v_xad_u32 %" #i ", %" #i ", %8, %8\n"
+#define A_ALIGNBIT(i) "v_alignbit_b32 %" #i ", %" #i ", %" #i ", 7\n"
+#define A_BFE(i) "v_bfe_u32 %" #i ", %" #i ", 1, 8\n"
+#define A_MOV(i) "v_mov_b32 %" #i ", %8\n"
+KERNEL(k_ashr, A_ASHR)
+KERNEL(k_lshl, A_LSHL)
+KERNEL(k_and, A_AND)
+KERNEL(k_or, A_OR)
+KERNEL(k_xad, A_XAD)
+KERNEL(k_alignbit, A_ALIGNBIT)
+KERNEL(k_bfe, A_BFE)
+KERNEL(k_mov, A_MOV)
 KERNEL(k_cndmask, A_CNDMASK)
 KERNEL(k_subco, A_SUBCO)
 KERNEL(k_cmp_add, A_CMP)
@@ -125,11 +141,12 @@ int main() {
     int blocks = cus * 8;  // 8 x 256 threads per CU = 8 waves per SIMD
     uint32_t *d; hipMalloc(&d, (size_t)blocks * 256 * 4);
     double lane_ops = (double)blocks * 256 * ITER * 8;
-    struct { const char *name; double ms; } res[40]; int n = 0;
+    struct { const char *name; double ms; } res[64]; int n = 0;
 #define RUN(K) res[n].name = #K; res[n].ms = run(K, d, blocks); n++;
     RUN(k_add) RUN(k_sub) RUN(k_min) RUN(k_xor) RUN(k_lshladd) RUN(k_add3) RUN(k_mullo) RUN(k_mulhi)
     RUN(k_mul24) RUN(k_mulhi24) RUN(k_mad24) RUN(k_mad64) RUN(k_fma32) RUN(k_fma64)
     RUN(k_cndmask) RUN(k_subco) RUN(k_cmp_add) RUN(k_max) RUN(k_mini) RUN(k_lshr) RUN(k_andor) RUN(k_addco) RUN(k_subco_cnd) RUN(k_sub_min) RUN(k_mullo_hi)
+    RUN(k_ashr) RUN(k_lshl) RUN(k_and) RUN(k_or) RUN(k_xad) RUN(k_alignbit) RUN(k_bfe) RUN(k_mov)
     for (int i = 0; i < n; i++) {
         double rate = lane_ops / (res[i].ms * 1e-3);                 // lane-ops / s
         double per_cu_clk = rate / cus / (prop.clockRate * 1e3);    // at nominal clock
