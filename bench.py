@@ -117,9 +117,12 @@ def _counters(config, chunk, build_id):
     return None, "no committed counters for chunk %d" % chunk
 
 
-# Issue rates measured on the MI355X by tools/ubench_int.hip (profiles/r01_ubench_valu.txt), in
-# 10^12 lane-operations per second.
-VALU_RATE = {"mad64": 32.39, "mul": 34.38, "simple": 56.08}
+# Issue rates measured on the MI355X by tools/ubench_int.hip (profiles/r01_ubench_valu.txt,
+# r03_ubench_valu.txt), in 10^12 lane-operations per second: 64-bit multiply-adds, 32-bit multiplies,
+# the full-rate simple instructions (add, sub, two-operand logic, right shifts, moves) and the
+# other simple ones (left shifts, min / max, three-operand and carry forms, v_alignbit: 36-38).
+VALU_RATE = {"mad64": 32.39, "mul": 34.38, "fast": 56.08, "slow": 36.0,
+             "simple": 56.08}   # "simple": profiles before r03_v10 did not split fast / slow
 
 
 def valu_roofline(c, ext_s):
@@ -131,7 +134,7 @@ def valu_roofline(c, ext_s):
         return None
     mix = c["valu_mix"]
     insts = c["k_extprod"]["SQ_INSTS_VALU"]
-    peak = 1.0 / sum(mix[k] / VALU_RATE[k] for k in VALU_RATE)
+    peak = 1.0 / sum(mix[k] / VALU_RATE[k] for k in VALU_RATE if k in mix)
     ach = insts * 64 / ext_s / 1e12
     return {"bound": "valu-int32", "achieved": ach, "peak": peak, "unit": "Tlane-op/s",
             "frac": ach / peak, "valu_insts_per_launch": insts, "mix": mix, "source": c["source"]}
