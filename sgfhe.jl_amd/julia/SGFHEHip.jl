@@ -63,6 +63,9 @@ end
 mutable struct HipBootstrapKey
     params::Params
     ctx::Ptr{Cvoid}
+    # result words of the last batched call, kept and regrown on demand: releasing a
+    # multi-megabyte array between calls can stall the next call's kernels (include/sgfhe_hip.h)
+    scratch::Vector{UInt64}
 
     # random_flatten = true sizes the engine's RNS basis for `rng::AbstractRNG` calls
     # (SGFHE_CTX_RANDOM_FLATTEN: a sixth prime at Params(1024), nothing elsewhere).
@@ -83,13 +86,13 @@ mutable struct HipBootstrapKey
         rc = ccall((:sgfhe_bkey_upload, libsgfhe_hip), Int32,
                    (Ptr{Cvoid}, Ptr{UInt64}, Csize_t), ctx[], canon, length(canon))
         check(ctx[], rc)
-        key = new(p, ctx[])
+        key = new(p, ctx[], UInt64[])
         finalizer(k -> ccall((:sgfhe_ctx_destroy, libsgfhe_hip), Int32, (Ptr{Cvoid},), k.ctx), key)
         key
     end
 
     # raw constructor used by the generate-on-device method below
-    HipBootstrapKey(params::Params, ctx::Ptr{Cvoid}, ::Nothing) = new(params, ctx)
+    HipBootstrapKey(params::Params, ctx::Ptr{Cvoid}, ::Nothing) = new(params, ctx, UInt64[])
 end
 
 # Vector{ModUInt{UInt64, r}} is an isbits array: reinterpret is a zero-copy n x UInt64 view
@@ -121,7 +124,8 @@ function SGFHE.bootstrap(hkey::HipBootstrapKey, rng::Union{AbstractRNG,Nothing},
     @assert length(bits2) == batch
     a1, b1 = lwe_words(bits1, n)
     a2, b2 = lwe_words(bits2, n)
-    out = Vector{UInt64}(undef, batch * 3 * (n + 1))
+    length(hkey.scratch) < batch * 3 * (n + 1) && resize!(hkey.scratch, batch * 3 * (n + 1))
+    out = hkey.scratch
     rc = ccall((:sgfhe_bootstrap_batch, libsgfhe_hip), Int32,
                (Ptr{Cvoid}, Ptr{UInt64}, Ptr{UInt64}, Ptr{UInt64}, Ptr{UInt64}, Csize_t,
                 Ptr{UInt64}, UInt32),
