@@ -66,6 +66,7 @@ mutable struct HipBootstrapKey
     # result words of the last batched call, kept and regrown on demand: releasing a
     # multi-megabyte array between calls can stall the next call's kernels (include/sgfhe_hip.h)
     scratch::Vector{UInt64}
+    lock::ReentrantLock          # tasks sharing a key take turns from the ccall to the last read of `scratch`
 
     # random_flatten = true sizes the engine's RNS basis for `rng::AbstractRNG` calls
     # (SGFHE_CTX_RANDOM_FLATTEN: a sixth prime at Params(1024), nothing elsewhere).
@@ -86,13 +87,13 @@ mutable struct HipBootstrapKey
         rc = ccall((:sgfhe_bkey_upload, libsgfhe_hip), Int32,
                    (Ptr{Cvoid}, Ptr{UInt64}, Csize_t), ctx[], canon, length(canon))
         check(ctx[], rc)
-        key = new(p, ctx[], UInt64[])
+        key = new(p, ctx[], UInt64[], ReentrantLock())
         finalizer(k -> ccall((:sgfhe_ctx_destroy, libsgfhe_hip), Int32, (Ptr{Cvoid},), k.ctx), key)
         key
     end
 
     # raw constructor used by the generate-on-device method below
-    HipBootstrapKey(params::Params, ctx::Ptr{Cvoid}, ::Nothing) = new(params, ctx, UInt64[])
+    HipBootstrapKey(params::Params, ctx::Ptr{Cvoid}, ::Nothing) = new(params, ctx, UInt64[], ReentrantLock())
 end
 
 # Vector{ModUInt{UInt64, r}} is an isbits array: reinterpret is a zero-copy n x UInt64 view
@@ -117,28 +118,30 @@ Batched gate bootstrap on the GPU; returns a vector of (AND, OR, XOR) triples.
 """
 function SGFHE.bootstrap(hkey::HipBootstrapKey, rng::Union{AbstractRNG,Nothing},
                          bits1::AbstractVector{EncryptedBit}, bits2::AbstractVector{EncryptedBit})
-    set_flatten_mode(hkey, rng)
     p = hkey.params
     n = p.n
     batch = length(bits1)
     @assert length(bits2) == batch
     a1, b1 = lwe_words(bits1, n)
     a2, b2 = lwe_words(bits2, n)
-    length(hkey.scratch) < batch * 3 * (n + 1) && resize!(hkey.scratch, batch * 3 * (n + 1))
-    out = hkey.scratch
-    rc = ccall((:sgfhe_bootstrap_batch, libsgfhe_hip), Int32,
-               (Ptr{Cvoid}, Ptr{UInt64}, Ptr{UInt64}, Ptr{UInt64}, Ptr{UInt64}, Csize_t,
-                Ptr{UInt64}, UInt32),
-               hkey.ctx, a1, b1, a2, b2, batch, out, 0)
-    check(hkey.ctx, rc)
     tp = ModUInt{UInt64, UInt64(p.r)}
     mk(x) = tp(x, _verbatim)                       # as at src/utils.jl:116
     res = Vector{NTuple{3,EncryptedBit}}(undef, batch)
-    for t in 1:batch
-        base = (t - 1) * 3 * (n + 1)
-        res[t] = ntuple(3) do g
-            o = base + (g - 1) * (n + 1)
-            EncryptedBit(LWE(mk.(out[o+1:o+n]), mk(out[o+n+1])))
+    lock(hkey.lock) do
+        set_flatten_mode(hkey, rng)               # mode and call stay together under the lock
+        length(hkey.scratch) < batch * 3 * (n + 1) && resize!(hkey.scratch, batch * 3 * (n + 1))
+        out = hkey.scratch
+        rc = ccall((:sgfhe_bootstrap_batch, libsgfhe_hip), Int32,
+                   (Ptr{Cvoid}, Ptr{UInt64}, Ptr{UInt64}, Ptr{UInt64}, Ptr{UInt64}, Csize_t,
+                    Ptr{UInt64}, UInt32),
+                   hkey.ctx, a1, b1, a2, b2, batch, out, 0)
+        check(hkey.ctx, rc)
+        for t in 1:batch
+            base = (t - 1) * 3 * (n + 1)
+            res[t] = ntuple(3) do g
+                o = base + (g - 1) * (n + 1)
+                EncryptedBit(LWE(mk.(out[o+1:o+n]), mk(out[o+n+1])))
+            end
         end
     end
     res
