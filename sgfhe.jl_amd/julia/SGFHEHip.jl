@@ -174,16 +174,18 @@ mode exactly as for `bootstrap`.
 """
 function SGFHE.pack_encrypted_bits(hkey::HipBootstrapKey, rng::Union{AbstractRNG,Nothing},
                                    enc_bits::AbstractVector{EncryptedBit})
-    set_flatten_mode(hkey, rng)
     p = hkey.params
     @assert length(enc_bits) == p.n
     a, b = lwe_words(enc_bits, p.n)
     w = Vector{UInt64}(undef, p.m)
     v = Vector{UInt64}(undef, p.m)
-    rc = ccall((:sgfhe_pack_encrypted_bits, libsgfhe_hip), Int32,
-               (Ptr{Cvoid}, Ptr{UInt64}, Ptr{UInt64}, Csize_t, Ptr{UInt64}, Ptr{UInt64}),
-               hkey.ctx, a, b, 1, w, v)
-    check(hkey.ctx, rc)
+    lock(hkey.lock) do
+        set_flatten_mode(hkey, rng)
+        rc = ccall((:sgfhe_pack_encrypted_bits, libsgfhe_hip), Int32,
+                   (Ptr{Cvoid}, Ptr{UInt64}, Ptr{UInt64}, Csize_t, Ptr{UInt64}, Ptr{UInt64}),
+                   hkey.ctx, a, b, 1, w, v)
+        check(hkey.ctx, rc)
+    end
     tp = ModUInt{UInt64, UInt64(p.r)}
     mk(x) = tp(x, _verbatim)
     SGFHE.Ciphertext(p, SGFHE.RLWE(Polynomial(mk.(w), negacyclic_modulus),
