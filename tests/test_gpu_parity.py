@@ -1,6 +1,8 @@
 """GPU parity tests: the HIP engine (through the C ABI) against the oracle, bit for bit.
 Run on the GPU box with `pytest -m gpu`."""
 
+import os
+
 import numpy as np
 import pytest
 
@@ -133,7 +135,27 @@ def test_params64_bootstrap_truth_table(S, oc):
     for g, fn in enumerate((np.bitwise_and, np.bitwise_or, np.bitwise_xor)):
         dec = o.lwe_decrypt_bits(sk, out[:, g, :params.n], out[:, g, params.n])
         assert np.array_equal(dec, fn(y1, y2))
+    # the host-pointer entry point with the caller's own result array (the form a loop uses), through
+    # the pinned staging buffers and through direct copies; a wrong array is refused
+    mine = np.full(out.shape, 0xDEADBEEF, dtype=np.uint64)
+    assert eng.bootstrap_batch(a1, b1, a2, b2, out=mine) is mine and np.array_equal(mine, ref)
+    raw = eng.bootstrap_batch(a1, b1, a2, b2, raw=True)
+    mine_raw = np.zeros(raw.shape, dtype=np.uint64)
+    eng.bootstrap_batch(a1, b1, a2, b2, raw=True, out=mine_raw)
+    assert np.array_equal(mine_raw, raw)
+    for bad in (np.zeros(out.shape, dtype=np.int64), np.zeros(out.shape[:2], dtype=np.uint64),
+                np.zeros((batch, 3, 2 * (params.n + 1)), dtype=np.uint64)[:, :, ::2]):
+        with pytest.raises(ValueError):
+            eng.bootstrap_batch(a1, b1, a2, b2, out=bad)
     eng.close()
+    os.environ["SGFHE_HOST_PIN"] = "0"
+    try:
+        direct = S.Engine(params)
+        direct.upload_key(bkey)
+        assert np.array_equal(direct.bootstrap_batch(a1, b1, a2, b2), ref)
+        direct.close()
+    finally:
+        del os.environ["SGFHE_HOST_PIN"]
 
 
 # ---- BASELINE.json configurations at full ring size --------------------------------------------
