@@ -133,7 +133,7 @@ class Engine:
                 raise ValueError("random-flatten key: 32 bytes")
             key = bytes(seed)
         else:
-            key = int(seed).to_bytes(32, "little")
+            key = (int(seed) % (1 << 256)).to_bytes(32, "little")
         self._chk(self._L.sgfhe_set_random_flatten_key(self._h, int(bool(enable)), key))
 
     def _lwe_args(self, a1, b1, a2, b2):
