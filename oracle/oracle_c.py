@@ -62,6 +62,13 @@ def lib():
         L.sgo_bootstrap_batch_opt.argtypes = L.sgo_bootstrap_batch.argtypes
         L.sgo_pack_encrypted_bits.argtypes = [ctypes.c_void_p, _u64p, _u64p, _u64p, _u64p, _u64p,
                                               ctypes.c_int]
+        L.sgo_flatten_random.argtypes = [ctypes.c_void_p, _u64p, ctypes.c_int64, ctypes.c_int64, _u64p]
+        L.sgo_flatten_draws.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_uint, ctypes.c_uint32,
+                                        ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(ctypes.c_int64)]
+        L.sgo_bootstrap_batch_rnd.argtypes = [ctypes.c_void_p, ctypes.c_int, _u64p, _u64p, _u64p, _u64p,
+                                              _u64p, ctypes.c_size_t, _u64p, ctypes.c_int,
+                                              ctypes.c_uint64, _u64p, ctypes.c_int, ctypes.c_char_p,
+                                              ctypes.c_uint32, ctypes.c_uint32]
         _lib = L
     return _lib
 
@@ -161,6 +168,20 @@ class Oracle:
         lib().sgo_flatten(self._ctx, _p(ain), _p(out))
         return [int(out[0]) | (int(out[1]) << 64), int(out[2]) | (int(out[3]) << 64)]
 
+    def flatten_random(self, a, x0, x1):
+        """flatten(rng, a, Val(B), Val(2)) (utils.jl:198-241) with the two draws given."""
+        ain = np.array(to_words(a), dtype=np.uint64)
+        out = np.zeros(4, dtype=np.uint64)
+        lib().sgo_flatten_random(self._ctx, _p(ain), int(x0), int(x1), _p(out))
+        return [int(out[0]) | (int(out[1]) << 64), int(out[2]) | (int(out[3]) << 64)]
+
+    def flatten_draws(self, seed, c, y, boot=0, call=0):
+        """[m][2] int64: the draws of accumulator c in the flatten tagged y (engine's ChaCha8 stream)."""
+        d = np.zeros((self.m, 2), dtype=np.int64)
+        lib().sgo_flatten_draws(self._ctx, seed_bytes(seed), c, y, boot, call,
+                                d.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)))
+        return d
+
     def poly_mul(self, a, b, schoolbook=False):
         a = np.ascontiguousarray(a, dtype=np.uint64)
         b = np.ascontiguousarray(b, dtype=np.uint64)
@@ -221,11 +242,14 @@ class Oracle:
         return khat
 
     def bootstrap_batch(self, bkey, a1, b1, a2, b2, raw=False, n_iters=None, want_acc=False,
-                        threads=None, opt=False):
+                        threads=None, opt=False, rnd=None):
         """fhe.jl:559-621 over a batch.  Returns out ([batch][3][n+1] uint64, or [..][2] if raw)
         and, if want_acc, the accumulators [batch][2][m][2] after `n_iters` iterations.
         opt=True: `bkey` is the NTT-domain key of key_transform and the k-loop runs in the GPU
-        path's algebra (4 + 2 NTTs per iteration, BASELINE.md `cpu_opt`); same outputs."""
+        path's algebra (4 + 2 NTTs per iteration, BASELINE.md `cpu_opt`); same outputs.
+        rnd=(seed, call[, boot0]): bootstrap(bkey, rng, ...) -- the randomised flatten
+        (utils.jl:198-241) on the engine's ChaCha8 stream keyed with `seed` (32 bytes or an int);
+        row t of the batch draws as bootstrap boot0 + t of call `call`."""
         bkey = np.ascontiguousarray(bkey, dtype=np.uint64)
         a1 = np.ascontiguousarray(a1, dtype=np.uint64).reshape(-1, self.n)
         a2 = np.ascontiguousarray(a2, dtype=np.uint64).reshape(-1, self.n)
@@ -235,12 +259,19 @@ class Oracle:
         shape = (batch, 3, self.n + 1, 2) if raw else (batch, 3, self.n + 1)
         out = np.zeros(shape, dtype=np.uint64)
         acc = np.zeros((batch, 2, self.m, 2), dtype=np.uint64) if want_acc else None
-        fn = lib().sgo_bootstrap_batch_opt if opt else lib().sgo_bootstrap_batch
-        rc = fn(self._ctx, _p(bkey), _p(a1), _p(b1), _p(a2), _p(b2), batch,
-                                       _p(out), 1 if raw else 0,
-                                       self.n if n_iters is None else n_iters,
-                                       _p(acc) if want_acc else None,
-                                       threads or min(batch, os.cpu_count() or 1))
+        nthreads = threads or min(batch, os.cpu_count() or 1)
+        niter = self.n if n_iters is None else n_iters
+        if rnd is not None:
+            seed, call = rnd[0], rnd[1]
+            boot0 = rnd[2] if len(rnd) > 2 else 0
+            rc = lib().sgo_bootstrap_batch_rnd(self._ctx, 1 if opt else 0, _p(bkey), _p(a1), _p(b1), _p(a2),
+                                               _p(b2), batch, _p(out), 1 if raw else 0, niter,
+                                               _p(acc) if want_acc else None, nthreads, seed_bytes(seed),
+                                               call, boot0)
+        else:
+            fn = lib().sgo_bootstrap_batch_opt if opt else lib().sgo_bootstrap_batch
+            rc = fn(self._ctx, _p(bkey), _p(a1), _p(b1), _p(a2), _p(b2), batch, _p(out), 1 if raw else 0,
+                    niter, _p(acc) if want_acc else None, nthreads)
         if rc:
             raise RuntimeError("sgo_bootstrap_batch failed: %d" % rc)
         return (out, acc) if want_acc else out

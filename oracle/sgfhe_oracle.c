@@ -394,6 +394,97 @@ void sgo_flatten(const sgo_ctx *c, const uint64_t *a, uint64_t *out) {
     st128(out, d0); st128(out + 2, d1);
 }
 
+/* ---- randomised flatten: flatten(rng::AbstractRNG, a, Val(B), Val(l)), utils.jl:198-241, ell = 2 ----
+ * x_i = rand(rng, -xmax:xmax) (:229-231); rand_a = a - sum x_i B^(i-1) (:233-234);
+ * y = flatten(nothing, rand_a) (:236); result x_i + y_i (:237-239), all in Z_Q.
+ * The reference draws from the caller's Julia rng, whose stream cannot be reproduced outside Julia
+ * (SURVEY.md F6).  The draws here are the HIP engine's: a ChaCha8 counter stream keyed with 32
+ * bytes (sgfhe.jl_amd/csrc/kernels.h rnd128 / random_digits; oracle/bigint_oracle.py ChaChaFlatten
+ * restates the same stream).  The 128 bits of coefficient x = (c << log2 m) + j (accumulator c:
+ * 0 = a, 1 = b) in the flatten tagged y are words 4 (x mod 4) .. + 3 of the block whose state
+ * words 12 .. 15 are (x div 4, y, index of the bootstrap within the call, number of the call);
+ * r_0 = (lo64 span) >> 64, r_1 = (hi64 span) >> 64 with span = 2 xmax + 1; x_i = r_i - xmax. */
+static void chacha_block(const uint32_t key[8], uint32_t w12, uint32_t w13, uint32_t w14, uint32_t w15,
+                         int rounds, uint32_t out[16]);
+#define SGO_RND_ROUNDS 8
+
+typedef struct {
+    uint32_t key[8];
+    uint32_t call, boot;
+} rnd_t;
+
+/* utils.jl:210-214 */
+static inline u128 flatten_xmax(const sgo_ctx *c) {
+    return (c->B & 1) ? (c->B - 1) / 2 * 3 : c->B / 2 * 3;
+}
+
+/* convert(T, x) of a signed draw (utils.jl:230): x mod Q */
+static inline u128 signed_to_mod(int64_t x, u128 Q) {
+    return x >= 0 ? (u128)(uint64_t)x % Q : (Q - (u128)(uint64_t)(-x) % Q) % Q;
+}
+
+static inline void flatten2_rnd(const sgo_ctx *c, u128 a, int64_t x0, int64_t x1, u128 *d0, u128 *d1) {
+    mont_t mt = ctx_mont(c);
+    u128 Q = c->Q;
+    u128 X0 = signed_to_mod(x0, Q), X1 = signed_to_mod(x1, Q);
+    u128 rand_a = submod(a, X0, Q);                                      /* utils.jl:233-234, i = 1 */
+    rand_a = submod(rand_a, mulmod_plain(&mt, X1, c->B % Q), Q);         /* i = 2: x[2] * B */
+    u128 y0, y1;
+    flatten2(c, rand_a, &y0, &y1);                                       /* utils.jl:236 */
+    *d0 = addmod(X0, y0, Q);                                             /* utils.jl:237-239 */
+    *d1 = addmod(X1, y1, Q);
+}
+
+/* the two draws of the coefficient with stream index x, out of its block */
+static inline void draws_of(const sgo_ctx *c, const uint32_t blk[16], uint32_t x, int64_t *x0, int64_t *x1) {
+    const uint32_t *w = blk + 4 * (x & 3);
+    const u128 xmax = flatten_xmax(c), span = 2 * xmax + 1;
+    const uint64_t lo = ((uint64_t)w[1] << 32) | w[0], hi = ((uint64_t)w[3] << 32) | w[2];
+    *x0 = (int64_t)(uint64_t)(((u128)lo * span) >> 64) - (int64_t)(uint64_t)xmax;
+    *x1 = (int64_t)(uint64_t)(((u128)hi * span) >> 64) - (int64_t)(uint64_t)xmax;
+}
+
+/* flatten_poly(rng, a, ...) (utils.jl:253-264): coefficient j draws its ell values in order */
+static void flatten_poly2(const sgo_ctx *c, const rnd_t *g, unsigned cc, uint32_t y, const u128 *a,
+                          u128 *d0, u128 *d1) {
+    size_t m = c->m;
+    if (!g) {
+        for (size_t j = 0; j < m; j++) flatten2(c, a[j], &d0[j], &d1[j]);
+        return;
+    }
+    uint32_t blk[16];
+    for (size_t j = 0; j < m; j++) {
+        const uint32_t x = ((uint32_t)cc << c->logm) + (uint32_t)j;
+        if ((x & 3) == 0 || j == 0) chacha_block(g->key, x >> 2, y, g->boot, g->call, SGO_RND_ROUNDS, blk);
+        int64_t x0, x1;
+        draws_of(c, blk, x, &x0, &x1);
+        flatten2_rnd(c, a[j], x0, x1, &d0[j], &d1[j]);
+    }
+}
+
+void sgo_flatten_random(const sgo_ctx *c, const uint64_t *a, int64_t x0, int64_t x1, uint64_t *out) {
+    u128 d0, d1;
+    flatten2_rnd(c, ld128(a), x0, x1, &d0, &d1);
+    st128(out, d0); st128(out + 2, d1);
+}
+
+/* draws[m][2] of one polynomial: accumulator cc (0 = a, 1 = b), flatten tag y, bootstrap `boot` of
+ * call `call` of the stream keyed with key32 */
+void sgo_flatten_draws(const sgo_ctx *c, const uint8_t *key32, unsigned cc, uint32_t y, uint32_t boot,
+                       uint32_t call, int64_t *draws) {
+    rnd_t g;
+    for (int i = 0; i < 8; i++)
+        g.key[i] = (uint32_t)key32[4 * i] | ((uint32_t)key32[4 * i + 1] << 8) |
+                   ((uint32_t)key32[4 * i + 2] << 16) | ((uint32_t)key32[4 * i + 3] << 24);
+    g.call = call; g.boot = boot;
+    uint32_t blk[16];
+    for (size_t j = 0; j < c->m; j++) {
+        const uint32_t x = ((uint32_t)cc << c->logm) + (uint32_t)j;
+        if ((x & 3) == 0 || j == 0) chacha_block(g.key, x >> 2, y, boot, call, SGO_RND_ROUNDS, blk);
+        draws_of(c, blk, x, &draws[2 * j], &draws[2 * j + 1]);
+    }
+}
+
 void sgo_poly_mul(const sgo_ctx *c, const uint64_t *a, const uint64_t *b, uint64_t *out) {
     poly_mul(c, (const u128 *)a, (const u128 *)b, (u128 *)out);
 }
@@ -403,18 +494,17 @@ void sgo_poly_mul_schoolbook(const sgo_ctx *c, const uint64_t *a, const uint64_t
     poly_mul_schoolbook(c, (const u128 *)a, (const u128 *)b, (u128 *)out);
 }
 
-/* fhe.jl:519-530.  A is [4][2][m]; scratch holds 6 m residues. */
+/* fhe.jl:519-530.  A is [4][2][m]; scratch holds 6 m residues.  g = NULL: rng = nothing; else the
+ * flatten of a draws first (fhe.jl:524), then the flatten of b (fhe.jl:525), tagged y. */
 static void external_product(const sgo_ctx *c, const u128 *a, const u128 *b, const u128 *A,
-                             u128 *a_res, u128 *b_res, u128 *scratch) {
+                             u128 *a_res, u128 *b_res, u128 *scratch, const rnd_t *g, uint32_t y) {
     size_t m = c->m;
     u128 Q = c->Q;
     u128 *u = scratch;            /* 4 polys: a_lo, a_hi, b_lo, b_hi  (fhe.jl:524-526) */
     u128 *prod = scratch + 4 * m;
     u128 *ra = scratch + 5 * m;   /* a_res / b_res may alias a / b */
-    for (size_t i = 0; i < m; i++) {                         /* utils.jl:253-264 */
-        flatten2(c, a[i], &u[i], &u[m + i]);
-        flatten2(c, b[i], &u[2 * m + i], &u[3 * m + i]);
-    }
+    flatten_poly2(c, g, 0, y, a, u, u + m);                  /* utils.jl:253-264 */
+    flatten_poly2(c, g, 1, y, b, u + 2 * m, u + 3 * m);
     memset(ra, 0, m * sizeof(u128));
     for (int i = 0; i < 4; i++) {                            /* fhe.jl:527 */
         poly_mul(c, u + i * m, A + (size_t)(i * 2 + 0) * m, prod);
@@ -436,7 +526,7 @@ void sgo_external_product(const sgo_ctx *c, const uint64_t *a, const uint64_t *b
     u128 *ta = (u128 *)malloc(2 * m * sizeof(u128));
     memcpy(ta, a, m * sizeof(u128));
     memcpy(ta + m, b, m * sizeof(u128));
-    external_product(c, ta, ta + m, (const u128 *)A, (u128 *)a_res, (u128 *)b_res, scratch);
+    external_product(c, ta, ta + m, (const u128 *)A, (u128 *)a_res, (u128 *)b_res, scratch, NULL, 0);
     free(ta);
     free(scratch);
 }
@@ -463,25 +553,30 @@ void sgo_private_key(const sgo_ctx *c, uint64_t seed, uint64_t *sk) {
     for (uint64_t i = 0; i < c->n; i++) sk[i] = sm_next(&g) & 1;
 }
 
-/* ChaCha20 block function (RFC 8439, section 2.3): key 8 words, block counter, nonce 3 words. */
-static void chacha20_block(const uint32_t key[8], uint32_t counter, const uint32_t nonce[3],
-                           uint32_t out[16]) {
+/* ChaCha block function (RFC 8439, section 2.3) with `rounds` rounds: key 8 words, state words
+ * 12 .. 15 = w12 .. w15 (block counter and nonce for ChaCha20). */
+static void chacha_block(const uint32_t key[8], uint32_t w12, uint32_t w13, uint32_t w14, uint32_t w15,
+                         int rounds, uint32_t out[16]) {
     uint32_t s[16] = {0x61707865u, 0x3320646eu, 0x79622d32u, 0x6b206574u,
                       key[0], key[1], key[2], key[3], key[4], key[5], key[6], key[7],
-                      counter, nonce[0], nonce[1], nonce[2]};
+                      w12, w13, w14, w15};
     uint32_t x[16];
     memcpy(x, s, sizeof x);
 #define ROTL(v, n) (((v) << (n)) | ((v) >> (32 - (n))))
 #define QR(a, b, c, d)                                                                        \
     x[a] += x[b]; x[d] ^= x[a]; x[d] = ROTL(x[d], 16); x[c] += x[d]; x[b] ^= x[c]; x[b] = ROTL(x[b], 12); \
     x[a] += x[b]; x[d] ^= x[a]; x[d] = ROTL(x[d], 8);  x[c] += x[d]; x[b] ^= x[c]; x[b] = ROTL(x[b], 7);
-    for (int i = 0; i < 10; i++) {
+    for (int i = 0; i < rounds / 2; i++) {
         QR(0, 4, 8, 12) QR(1, 5, 9, 13) QR(2, 6, 10, 14) QR(3, 7, 11, 15)
         QR(0, 5, 10, 15) QR(1, 6, 11, 12) QR(2, 7, 8, 13) QR(3, 4, 9, 14)
     }
 #undef QR
 #undef ROTL
     for (int i = 0; i < 16; i++) out[i] = x[i] + s[i];
+}
+static void chacha20_block(const uint32_t key[8], uint32_t counter, const uint32_t nonce[3],
+                           uint32_t out[16]) {
+    chacha_block(key, counter, nonce[0], nonce[1], nonce[2], 20, out);
 }
 
 /* fhe.jl:181-201.  Randomness: ChaCha20 keyed with the 32-byte seed, one stream per
@@ -572,16 +667,14 @@ static inline u128 extract_at(const u128 *a, size_t i0, size_t k) { return a[i0 
  * so the key is held in the NTT domain (khat) and an iteration is 4 forward + 2 inverse NTTs
  * instead of 24.  Exact arithmetic mod Q: bit-identical to the reference-shaped path. */
 static void iteration_opt(const sgo_ctx *c, const u128 *khat_k, uint64_t j, u128 *a, u128 *b,
-                          u128 *work /* 6 m */) {
+                          u128 *work /* 6 m */, const rnd_t *g, uint32_t y) {
     size_t m = c->m;
     u128 Q = c->Q;
     mont_t mt = ctx_mont(c);
     u128 *u[4] = {work, work + m, work + 2 * m, work + 3 * m};
     u128 *P = work + 4 * m, *rot = work + 5 * m;
-    for (size_t i = 0; i < m; i++) {                                    /* fhe.jl:524-526 */
-        flatten2(c, a[i], &u[0][i], &u[1][i]);
-        flatten2(c, b[i], &u[2][i], &u[3][i]);
-    }
+    flatten_poly2(c, g, 0, y, a, u[0], u[1]);                           /* fhe.jl:524-526 */
+    flatten_poly2(c, g, 1, y, b, u[2], u[3]);
     for (int row = 0; row < 4; row++) ntt_fwd(c, u[row]);
     for (int col = 0; col < 2; col++) {
         for (size_t i = 0; i < m; i++) {
@@ -600,7 +693,7 @@ static void iteration_opt(const sgo_ctx *c, const u128 *khat_k, uint64_t j, u128
 
 static int bootstrap_one(const sgo_ctx *c, const u128 *bkey, const u128 *khat, const uint64_t *a1,
                          uint64_t b1, const uint64_t *a2, uint64_t b2, uint64_t n_iters,
-                         u128 *out_raw, u128 *acc_out) {
+                         u128 *out_raw, u128 *acc_out, const rnd_t *g) {
     size_t m = c->m, n = c->n;
     u128 Q = c->Q;
     mont_t mt = ctx_mont(c);
@@ -625,7 +718,7 @@ static int bootstrap_one(const sgo_ctx *c, const u128 *bkey, const u128 *khat, c
     for (uint64_t k = 0; k < n_iters && k < n; k++) {                   /* fhe.jl:579-582 */
         uint64_t j = (a1[k] + a2[k]) % c->r;                            /* fhe.jl:566 */
         if (khat) {
-            iteration_opt(c, khat + (size_t)k * 8 * m, j, a, b, A);
+            iteration_opt(c, khat + (size_t)k * 8 * m, j, a, b, A, g, (uint32_t)k);
             continue;
         }
         for (int row = 0; row < 4; row++) {
@@ -637,7 +730,7 @@ static int bootstrap_one(const sgo_ctx *c, const u128 *bkey, const u128 *khat, c
                 Ap[0] = addmod(Ap[0], G[row][col], Q);                  /* `.+ G`: constant term */
             }
         }
-        external_product(c, a, b, A, a, b, scratch);                    /* fhe.jl:581 */
+        external_product(c, a, b, A, a, b, scratch, g, (uint32_t)k);    /* fhe.jl:581 */
     }
     if (acc_out) {
         memcpy(acc_out, a, m * sizeof(u128));
@@ -661,17 +754,20 @@ static int bootstrap_one(const sgo_ctx *c, const u128 *bkey, const u128 *khat, c
 
 static int bootstrap_batch(const sgo_ctx *c, int opt, const uint64_t *bkey, const uint64_t *a1,
                            const uint64_t *b1, const uint64_t *a2, const uint64_t *b2, size_t batch,
-                           uint64_t *out, int raw, uint64_t n_iters, uint64_t *acc_out, int threads) {
+                           uint64_t *out, int raw, uint64_t n_iters, uint64_t *acc_out, int threads,
+                           const rnd_t *g0) {
     size_t n = c->n, m = c->m;
     int rc = 0;
     if (opt && !c->use_ntt) return -2;
 #pragma omp parallel for num_threads(threads > 0 ? threads : 1) schedule(dynamic)
     for (long t = 0; t < (long)batch; t++) {
         u128 *rawbuf = (u128 *)malloc(3 * (n + 1) * sizeof(u128));
+        rnd_t g;
+        if (g0) { g = *g0; g.boot = g0->boot + (uint32_t)t; }           /* bootstrap t of the call */
         int r1 = bootstrap_one(c, opt ? NULL : (const u128 *)bkey, opt ? (const u128 *)bkey : NULL,
                                a1 + (size_t)t * n, b1[t], a2 + (size_t)t * n, b2[t], n_iters,
                                out ? rawbuf : NULL,
-                               acc_out ? (u128 *)acc_out + (size_t)t * 2 * m : NULL);
+                               acc_out ? (u128 *)acc_out + (size_t)t * 2 * m : NULL, g0 ? &g : NULL);
         if (r1) {
 #pragma omp atomic write
             rc = r1;
@@ -692,7 +788,7 @@ static int bootstrap_batch(const sgo_ctx *c, int opt, const uint64_t *bkey, cons
 int sgo_bootstrap_batch(const sgo_ctx *c, const uint64_t *bkey, const uint64_t *a1,
                         const uint64_t *b1, const uint64_t *a2, const uint64_t *b2, size_t batch,
                         uint64_t *out, int raw, uint64_t n_iters, uint64_t *acc_out, int threads) {
-    return bootstrap_batch(c, 0, bkey, a1, b1, a2, b2, batch, out, raw, n_iters, acc_out, threads);
+    return bootstrap_batch(c, 0, bkey, a1, b1, a2, b2, batch, out, raw, n_iters, acc_out, threads, NULL);
 }
 
 /* NTT-domain form of the bootstrap key for sgo_bootstrap_batch_opt: every polynomial through the
@@ -709,7 +805,24 @@ int sgo_key_transform(const sgo_ctx *c, const uint64_t *bkey, uint64_t *khat, in
 int sgo_bootstrap_batch_opt(const sgo_ctx *c, const uint64_t *khat, const uint64_t *a1,
                             const uint64_t *b1, const uint64_t *a2, const uint64_t *b2, size_t batch,
                             uint64_t *out, int raw, uint64_t n_iters, uint64_t *acc_out, int threads) {
-    return bootstrap_batch(c, 1, khat, a1, b1, a2, b2, batch, out, raw, n_iters, acc_out, threads);
+    return bootstrap_batch(c, 1, khat, a1, b1, a2, b2, batch, out, raw, n_iters, acc_out, threads, NULL);
+}
+
+/* bootstrap(bkey, rng, ...) (fhe.jl:608-621 with rng::AbstractRNG): the randomised flatten of
+ * utils.jl:198-241 on the ChaCha8 stream keyed with key32; bootstrap t of the batch is bootstrap
+ * boot0 + t of call `call`.  opt != 0: `key` is the NTT-domain key (sgo_key_transform) and the
+ * k-loop runs in the GPU path's algebra; same outputs. */
+int sgo_bootstrap_batch_rnd(const sgo_ctx *c, int opt, const uint64_t *key, const uint64_t *a1,
+                            const uint64_t *b1, const uint64_t *a2, const uint64_t *b2, size_t batch,
+                            uint64_t *out, int raw, uint64_t n_iters, uint64_t *acc_out, int threads,
+                            const uint8_t *key32, uint32_t call, uint32_t boot0) {
+    rnd_t g;
+    for (int i = 0; i < 8; i++)
+        g.key[i] = (uint32_t)key32[4 * i] | ((uint32_t)key32[4 * i + 1] << 8) |
+                   ((uint32_t)key32[4 * i + 2] << 16) | ((uint32_t)key32[4 * i + 3] << 24);
+    g.call = call;
+    g.boot = boot0;
+    return bootstrap_batch(c, opt, key, a1, b1, a2, b2, batch, out, raw, n_iters, acc_out, threads, &g);
 }
 
 /* ---------------------------------------------------------------- packing */
@@ -747,7 +860,7 @@ int sgo_pack_encrypted_bits(const sgo_ctx *c, const uint64_t *bkey, const uint64
     for (long t = 0; t < (long)n; t++) {
         u128 *out3 = (u128 *)malloc(3 * (n + 1) * sizeof(u128));
         int r1 = bootstrap_one(c, (const u128 *)bkey, NULL, zeros, c->Dr, a + (size_t)t * n, b[t], n,
-                               out3, NULL);
+                               out3, NULL, NULL);
         if (r1) {
 #pragma omp atomic write
             rc = r1;

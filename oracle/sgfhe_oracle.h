@@ -1,7 +1,7 @@
 /*
  * TEST INFRASTRUCTURE -- NOT PRODUCT CODE.
  *
- * C restatement ("port") of the deterministic gate bootstrap of nucypher/SGFHE.jl, in the
+ * C restatement ("port") of the gate bootstrap of nucypher/SGFHE.jl (both flatten modes), in the
  * reference's own shape: 128-bit Montgomery residues (DarkIntegers MgModUInt{UInt128,Q},
  * /root/reference/src/fhe.jl:83-85,104), one full NTT polynomial multiply per
  * `Polynomial * Polynomial` call site (8 per external product, fhe.jl:527-528).
@@ -94,6 +94,25 @@ int sgo_key_transform(const sgo_ctx *ctx, const uint64_t *bkey, uint64_t *khat, 
 int sgo_bootstrap_batch_opt(const sgo_ctx *ctx, const uint64_t *khat, const uint64_t *a1,
                             const uint64_t *b1, const uint64_t *a2, const uint64_t *b2, size_t batch,
                             uint64_t *out, int raw, uint64_t n_iters, uint64_t *acc_out, int threads);
+
+/*
+ * The randomised flatten, flatten(rng::AbstractRNG, ...) of utils.jl:198-241, and bootstrap(bkey,
+ * rng, ...) through it.  The reference draws from the caller's Julia rng (not reproducible outside
+ * Julia); here the draws are the HIP engine's ChaCha8 counter stream (layout in sgfhe_oracle.c),
+ * so the engine's randomised mode can be pinned word for word at full batch.
+ *   sgo_flatten_random: one residue with the two draws x0, x1 in [-xmax, xmax] given: out[2] residues
+ *   sgo_flatten_draws:  the draws [m][2] of one polynomial (accumulator cc, flatten tag y = k for the
+ *                       flatten feeding k-loop iteration k, bootstrap `boot` of call `call`)
+ *   sgo_bootstrap_batch_rnd: as sgo_bootstrap_batch (opt = 0) / sgo_bootstrap_batch_opt (opt = 1);
+ *                       bootstrap t of the batch draws as bootstrap boot0 + t of call `call`.
+ */
+void sgo_flatten_random(const sgo_ctx *ctx, const uint64_t *a, int64_t x0, int64_t x1, uint64_t *out);
+void sgo_flatten_draws(const sgo_ctx *ctx, const uint8_t *key32, unsigned cc, uint32_t y, uint32_t boot,
+                       uint32_t call, int64_t *draws);
+int sgo_bootstrap_batch_rnd(const sgo_ctx *ctx, int opt, const uint64_t *key, const uint64_t *a1,
+                            const uint64_t *b1, const uint64_t *a2, const uint64_t *b2, size_t batch,
+                            uint64_t *out, int raw, uint64_t n_iters, uint64_t *acc_out, int threads,
+                            const uint8_t *key32, uint32_t call, uint32_t boot0);
 
 /* fhe.jl:660-696 pack_encrypted_bits(bkey, nothing, enc_bits): a [n][n], b [n] over Z_r ->
  * RLWE (w, v), [m] words in [0, r) each. */

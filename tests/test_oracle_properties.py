@@ -375,3 +375,94 @@ def test_pack_small_ring_c_equals_bigint(oc):
     pw, pv = BO.pack_encrypted_bits(p, bk, lwes)
     assert [int(x) for x in w] == pw and [int(x) for x in v] == pv
     assert BO.decrypt_ciphertext(p, skl, pw, pv) == [int(x) for x in bits]
+
+
+# ---- the C restatement of the randomised flatten (round 4) against the big-integer one --------------
+
+@pytest.mark.parametrize("B", [4, 5, 6, 7])
+def test_flatten_random_c_matches_python_exhaustive(oc, B):
+    """flatten(rng, a, Val(B), Val(2)) (src/utils.jl:198-241): the C restatement equals the literal
+    big-integer one for every a in Z_q and every pair of draws in [-xmax, xmax]^2, restores a and
+    keeps every digit inside (-2B, 2B] (test/internals.test.jl:48-52,69-112 with use_rng = true)."""
+    q = B * B - 1
+    if q % 2 == 0:
+        q -= 1               # Montgomery-based C restatement: odd modulus
+    o = oc.Oracle(n=8, r=128, m=64, Q=q, B=B, DQ_tilde=q // 8)
+    xmax = BO.flatten_xmax(B)
+    for a in range(q):
+        for x0 in range(-xmax, xmax + 1):
+            for x1 in (-xmax, -1, 0, 2, xmax):
+                d = o.flatten_random(a, x0, x1)
+                assert d == BO.flatten_random(lambda i: (x0, x1)[i], a, B, 2, q)
+                assert (d[0] + d[1] * B) % q == a
+                if q > 4 * B:            # the limits are only distinguishable when they do not wrap
+                    assert all(x <= 2 * B or x >= q - 2 * B for x in d)
+
+
+def test_flatten_draws_c_equal_python_stream(oc):
+    """The C oracle's ChaCha8 draw stream is the big-integer oracle's (and hence the engine's):
+    every draw of several polynomials, both accumulators, several tags / bootstraps / calls, for a
+    64-bit and a 87-bit ring."""
+    for p in (BO.Params.make(64), BO.Params.custom(16, BO.find_modulus(256, 1 << 86), 35 * (1 << 38))):
+        o = oc.Oracle.from_params(p)
+        for seed in (5, bytes(range(7, 39))):
+            for c, y, boot, call in ((0, 0, 0, 0), (1, 3, 2, 1), (1, (1 << 31) | 5, 4097, 70000)):
+                g = BO.ChaChaFlatten(p, seed, boot, call)
+                f = g.draws(c, y)
+                d = o.flatten_draws(seed, c, y, boot, call)
+                assert [[f(j, 0), f(j, 1)] for j in range(p.m)] == d.tolist()
+                assert abs(d).max() <= g.xmax
+
+
+@pytest.mark.parametrize("ring", ["params64", "synthetic", "wide base"])
+def test_c_randomised_bootstrap_equals_bigint(oc, ring):
+    """bootstrap(bkey, rng, ...) through the C restatement (reference-shaped and in the GPU path's
+    algebra) against the literal big-integer restatement on the same stream: accumulators after 1,
+    2 and n iterations, raw and ModRed outputs, rows of a batch drawing as bootstraps boot0 + t."""
+    if ring == "params64":
+        p, noise, its = BO.Params.make(64), None, (1, 2)
+    elif ring == "synthetic":
+        p, noise, its = BO.Params.custom(16, BO.find_modulus(256, 1 << 52), 1 << 27), 2, (1, 2, 16)
+    else:       # B = 3 * 2^45 + 1 (odd, >= 2^46), Q just under B^2: the ring of test_gpu_random's wide case
+        p, noise, its = BO.Params.custom(8, BO.find_modulus(128, 1 << 92), 3 * (1 << 45) + 1), 2, (1, 2, 8)
+    o = oc.Oracle.from_params(p)
+    sk = o.private_key(300)
+    bkey = o.bootstrap_key(sk, 301, noise=noise)
+    khat = o.key_transform(bkey)
+    bits = np.array([1, 1, 0, 1], dtype=np.uint8)
+    a, b = o.lwe_encrypt_bits(sk, bits, 302)
+    lwe = (a[0::2], b[0::2], a[1::2], b[1::2])
+    vals = oc.u128_to_ints(bkey)
+    m, n = p.m, p.n
+    bk = [[[vals[((k * 4 + r) * 2 + c) * m:((k * 4 + r) * 2 + c + 1) * m] for c in range(2)]
+           for r in range(4)] for k in range(n)]
+    seed, call, boot0 = 0x0123456789ABCDEF, 3, 5
+    want_acc = {}
+    want_raw = []
+    for t in range(2):
+        acc = {}
+
+        def trace(k, aa, bb, acc=acc):
+            if k + 1 in its:
+                acc[k + 1] = list(aa) + list(bb)
+        raw = BO.bootstrap_internal(p, bk, ([int(x) for x in lwe[0][t]], int(lwe[1][t])),
+                                    ([int(x) for x in lwe[2][t]], int(lwe[3][t])), trace=trace,
+                                    rng=BO.ChaChaFlatten(p, seed, boot0 + t, call))
+        want_acc[t] = acc
+        want_raw.append([x for g3 in raw for x in g3[0] + [g3[1]]])
+    for opt, key in ((False, bkey), (True, khat)):
+        for it in its:
+            _, acc = o.bootstrap_batch(key, *lwe, n_iters=it, want_acc=True, opt=opt, rnd=(seed, call, boot0))
+            for t in range(2):
+                assert oc.u128_to_ints(acc[t]) == want_acc[t][it], (opt, it, t)
+        raw = o.bootstrap_batch(key, *lwe, raw=True, opt=opt, rnd=(seed, call, boot0))
+        for t in range(2):
+            assert oc.u128_to_ints(raw[t]) == want_raw[t]
+        out = o.bootstrap_batch(key, *lwe, opt=opt, rnd=(seed, call, boot0))
+        for t in range(2):
+            assert [int(v) for v in out[t].reshape(-1)] == [BO.reduce_modulus(p.r, x, p.Q) for x in want_raw[t]]
+        assert not np.array_equal(out, o.bootstrap_batch(key, *lwe, opt=opt))          # not the deterministic result
+        assert not np.array_equal(out, o.bootstrap_batch(key, *lwe, opt=opt, rnd=(seed, call + 1, boot0)))
+    y1, y2 = bits[0::2], bits[1::2]
+    for g3, fn in enumerate((np.bitwise_and, np.bitwise_or, np.bitwise_xor)):
+        assert np.array_equal(o.lwe_decrypt_bits(sk, out[:, g3, :n], out[:, g3, n]), fn(y1, y2))
