@@ -12,7 +12,13 @@
  *   - the caller owns every buffer it passes; the library owns device memory behind the handle
  *   - a ctx is bound to one device; any number of ctxs may share a device.  Every entry point
  *     that takes a ctx locks it for the duration of the call, so a ctx may be shared by host
- *     threads (calls on one ctx are serialised; calls on different ctxs run concurrently)
+ *     threads (calls on one ctx are serialised; calls on different ctxs run concurrently).
+ *     That includes the asynchronous entry point sgfhe_bootstrap_batch_device: the work of
+ *     successive calls on one ctx is ordered on the device in the order the calls were made,
+ *     whatever stream each call names (each call's first kernel waits, on the device, for the
+ *     previous call's last one: the ctx owns the work buffers every call uses), so two threads
+ *     or two streams sharing a ctx get the bytes of the same calls made one after the other
+ *     (the reference call is pure, src/fhe.jl:608-621)
  *   - residues mod Q cross the boundary as canonical representatives in [0, Q), little-endian
  *     `limbs` x uint64 each, limbs = 2 (16 bytes, the reference's UInt128 storage width) unless
  *     stated otherwise; LWE words over Z_r are one uint64 each, exactly the memory of
@@ -70,7 +76,7 @@ const char *sgfhe_version(void);
  * SGFHE_ABI_VERSION it was written for and refuses a stale library (julia/SGFHEHip.jl __init__,
  * sgfhe.jl_amd/_lib.py).  Bumped whenever a signature, a struct layout, a flag value or the
  * meaning of an argument changes. */
-#define SGFHE_ABI_VERSION 5u
+#define SGFHE_ABI_VERSION 6u
 uint32_t sgfhe_abi_version(void);
 /* Identity of the kernel sources the library was compiled from: the first 16 hex digits of the
  * SHA-256 over csrc/{*.h, *.hip} (in file-name order), followed by "+<flags>" when the build used
@@ -179,9 +185,12 @@ int32_t sgfhe_bkey_import_device_form(sgfhe_ctx *ctx, const void *src_device);
  *   out    : [batch][3][n + 1] uint64: a[0..n) then b; gate order AND, OR, XOR
  *            (with SGFHE_FLAG_RAW_MODQ: [batch][3][n + 1][2], residues mod Q)
  * Deterministic flatten (rng = nothing, src/utils.jl:155-189) unless sgfhe_set_random_flatten[_key]
- * selected the other.  Host pointers; synchronous.  Buffers of up to 48 MB travel through
- * page-locked staging buffers the ctx keeps (one memcpy and one DMA per direction); larger ones are
- * copied directly.  A caller in a loop should keep its `out` buffer: releasing a multi-megabyte
+ * selected the other.  Host pointers; synchronous.  The arrays travel chunk by chunk through
+ * page-locked staging buffers the ctx keeps (up to 1 GiB each; sgfhe_release_host_staging frees
+ * them): a chunk's inputs go up while the chunks before it compute and its results come down while
+ * the chunks after it compute, so a large batch runs at the rate of device-resident buffers
+ * (larger arrays, and SGFHE_HOST_PIN=0 in the environment, are copied directly before and after).
+ * A caller in a loop should keep its `out` buffer: releasing a multi-megabyte
  * array between calls (munmap) can stall the next call's kernels by tens of milliseconds.
  * SGFHE_DEBUG_IO=1 in the environment prints the phases of every call to stderr.
  */
@@ -189,12 +198,20 @@ int32_t sgfhe_bootstrap_batch(sgfhe_ctx *ctx, const uint64_t *a1, const uint64_t
                               const uint64_t *a2, const uint64_t *b2, size_t batch, uint64_t *out,
                               uint32_t flags);
 
-/* Same with every buffer resident in device memory; asynchronous on the ctx stream
- * (sgfhe_sync waits).  `stream` = NULL uses the ctx's own stream. */
+/* Same with every buffer resident in device memory; asynchronous.  `stream` (a hipStream_t) is the
+ * stream the call's work is queued on, NULL = the ctx's own: `out` is complete when that stream
+ * reaches the end of the call's work (ordinary stream order for whatever the caller queues next on
+ * it), and the inputs must stay valid until then.  Calls on one ctx do not overlap on the device:
+ * a call's work starts after the work of every earlier call on this ctx, on any stream, has
+ * finished (see the conventions above).  sgfhe_sync waits on the host for all work queued on the
+ * ctx. */
 int32_t sgfhe_bootstrap_batch_device(sgfhe_ctx *ctx, const uint64_t *a1, const uint64_t *b1,
                                      const uint64_t *a2, const uint64_t *b2, size_t batch,
                                      uint64_t *out, uint32_t flags, void *stream);
 int32_t sgfhe_sync(sgfhe_ctx *ctx);
+/* Frees the staging buffers sgfhe_bootstrap_batch keeps on the ctx (device and page-locked host
+ * memory, sized by the largest batch seen); the next call allocates them again. */
+int32_t sgfhe_release_host_staging(sgfhe_ctx *ctx);
 
 /*
  * external_product(nothing, a, b, A, Val(B), Val(2)) (src/fhe.jl:519-530), the operation
@@ -332,6 +349,12 @@ int32_t sgfhe_host_normalize_public(const sgfhe_params *p, const uint8_t *a_bits
  */
 int32_t sgfhe_timing_enable(sgfhe_ctx *ctx, int enable);
 int32_t sgfhe_timing_read(sgfhe_ctx *ctx, double *stats, int reset);
+/* Names of the two k-loop kernels this ctx launches in its present flatten mode, as they appear in
+ * a rocprofv3 kernel trace ("k_extprod<13, 4, false>", "k_crt_lean<5, 3>"; parameter sets outside
+ * k_crt_lean's bounds and SGFHE_CRT_LEAN=0 give k_crt_acc2 / k_crt_acc), NUL-terminated into the
+ * caller's buffers (64 bytes suffice). */
+int32_t sgfhe_kernel_names(const sgfhe_ctx *ctx, char *extprod, size_t extprod_cap, char *crt,
+                           size_t crt_cap);
 
 #ifdef __cplusplus
 }

@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.environ.get("SGFHE_HIP_LIB") or os.path.join(CSRC, "libsgfhe_hip.so")
 
-ABI_VERSION = 5   # SGFHE_ABI_VERSION of include/sgfhe_hip.h this binding was written for
+ABI_VERSION = 6   # SGFHE_ABI_VERSION of include/sgfhe_hip.h this binding was written for
 
 _u64p = ctypes.POINTER(ctypes.c_uint64)
 _u32p = ctypes.POINTER(ctypes.c_uint32)
@@ -28,11 +28,14 @@ class SgfheParams(ctypes.Structure):
 
 
 def source_hash():
-    """Identity of the kernel sources: SHA-256 over csrc/{*.h, *.hip} in file-name order (what the
-    Makefile embeds in the library as sgfhe_build_id())."""
+    """Identity of the sources the library is compiled from: SHA-256 over csrc/{*.h, *.hip} in
+    file-name order, then include/sgfhe_hip.h (what the Makefile embeds in the library as
+    sgfhe_build_id()): a change of the ABI header alone makes the in-tree library stale too."""
     h = hashlib.sha256()
-    for f in sorted(f for f in os.listdir(CSRC) if f.endswith((".h", ".hip"))):
-        with open(os.path.join(CSRC, f), "rb") as fh:
+    files = [os.path.join(CSRC, f) for f in sorted(f for f in os.listdir(CSRC) if f.endswith((".h", ".hip")))]
+    files.append(os.path.join(os.path.dirname(os.path.dirname(CSRC)), "include", "sgfhe_hip.h"))
+    for f in files:
+        with open(f, "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
 
@@ -131,6 +134,8 @@ def lib():
         "sgfhe_host_normalize_public": (i32, [ctypes.POINTER(SgfheParams), vp, vp, vp, vp]),
         "sgfhe_timing_enable": (i32, [vp, ctypes.c_int]),
         "sgfhe_timing_read": (i32, [vp, ctypes.POINTER(ctypes.c_double), ctypes.c_int]),
+        "sgfhe_kernel_names": (i32, [vp, ctypes.c_char_p, sz, ctypes.c_char_p, sz]),
+        "sgfhe_release_host_staging": (i32, [vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)          # AttributeError if the library lacks a declared symbol
@@ -152,4 +157,5 @@ EXPORTED_SYMBOLS = (
     "sgfhe_debug_primes", "sgfhe_host_deterministic_expand", "sgfhe_host_encrypt_private",
     "sgfhe_host_pack_private", "sgfhe_host_normalize_private", "sgfhe_host_split_ciphertext",
     "sgfhe_host_decrypt_lwe", "sgfhe_host_decrypt_rlwe", "sgfhe_host_public_key",
-    "sgfhe_host_encrypt_public", "sgfhe_host_pack_public", "sgfhe_host_normalize_public", "sgfhe_timing_enable", "sgfhe_timing_read")
+    "sgfhe_host_encrypt_public", "sgfhe_host_pack_public", "sgfhe_host_normalize_public", "sgfhe_timing_enable", "sgfhe_timing_read",
+    "sgfhe_kernel_names", "sgfhe_release_host_staging")

@@ -83,6 +83,15 @@ struct sgfhe_ctx {
     hipStream_t stream2 = nullptr;  // second lane: chunk i+1 overlaps its memory-bound k_crt_acc
                                     // with the VALU-bound k_extprod of chunk i
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    // Calls on one ctx are ordered on the device whatever stream each names: every call that queues
+    // work first makes its stream wait for ev_done, the end of the previous call's work, and records
+    // it again when its own work is queued (the lanes' work buffers, the key and the constants are
+    // shared by all calls).  sgfhe_sync and everything that frees or replaces a buffer wait for it on
+    // the host.
+    hipEvent_t ev_done = nullptr;
+    bool pending = false;           // ev_done has been recorded and may not have completed
+    hipStream_t stream_io = nullptr;   // copies of the host-pointer entry point, beside the lanes' kernels
+    std::vector<hipEvent_t> ev_pool;   // events of the pipelined host-pointer path (created once, reused)
     // device constants
     PrimeK *d_primes = nullptr;
     CrtConst *d_crt = nullptr;
@@ -91,6 +100,7 @@ struct sgfhe_ctx {
     CrtConst h_crt;
     CrtLean *d_lean = nullptr;  // constants of k_crt_lean (nl = 0: this parameter set keeps k_crt_acc)
     CrtLean h_lean;
+    bool lean_rnd_ok = false;   // k_crt_lean_rnd's width bounds hold for this parameter set (build_constants)
     uint32_t pack_G = 1, pack_G_rnd = 0;  // key slices per exact-accumulation group of the packing path
                                           // (deterministic / randomised flatten; 0 = not available)
     // key
@@ -147,11 +157,22 @@ struct sgfhe_ctx {
     uint32_t attr_done = 0;
 };
 enum : uint32_t { ATTR_EXTPROD = 1u, ATTR_SMALL = 2u, ATTR_SHORTPROD = 4u };
-static constexpr size_t PIN_MAX_BYTES = (size_t)48 << 20;   // per buffer: above it the CPU memcpy costs more than the pinning
+// Page-locked mirrors of the host-pointer entry point's staging buffers: per buffer at most this much
+// (a batch of 16384 at Params(1024) needs 268 + 403 MB).  Round 3 staged whole buffers and stopped at
+// 48 MB, where one CPU memcpy cost what pinning the caller's pages did; the copies are now pipelined
+// chunk by chunk beside the kernels (HostPipe), so their size no longer matters.
+static constexpr size_t PIN_MAX_BYTES = (size_t)1 << 30;
 
 namespace {
 
 #define SGFHE_LOCK(ctx) std::lock_guard<std::recursive_mutex> lock_((ctx)->mu)
+// A synchronous entry point that touches the key, the constants or the lanes' buffers on the ctx
+// stream first waits (on the host) for the work of earlier asynchronous calls.
+#define SGFHE_QUIESCE(ctx)                                                                        \
+    do {                                                                                          \
+        int32_t rq_ = drain(ctx);                                                                 \
+        if (rq_) return rq_;                                                                      \
+    } while (0)
 
 #define HIPCHK(ctx, call)                                                                         \
     do {                                                                                          \
@@ -168,6 +189,26 @@ namespace {
 int32_t fail(sgfhe_ctx *ctx, int32_t code, const std::string &msg) {
     if (ctx) ctx->err = msg;
     return code;
+}
+
+// Start of a call that queues work on `st`: that work begins after everything earlier calls queued.
+int32_t fence_begin(sgfhe_ctx *c, hipStream_t st) {
+    if (c->pending) HIPCHK(c, hipStreamWaitEvent(st, c->ev_done, 0));
+    return SGFHE_OK;
+}
+// End of such a call: its last work on `st` (the lanes have been joined into it).
+int32_t fence_end(sgfhe_ctx *c, hipStream_t st) {
+    HIPCHK(c, hipEventRecord(c->ev_done, st));
+    c->pending = true;
+    return SGFHE_OK;
+}
+// Host waits for all work queued on the ctx (before buffers are freed or replaced, and in sgfhe_sync).
+int32_t drain(sgfhe_ctx *c) {
+    if (c->pending) {
+        HIPCHK(c, hipEventSynchronize(c->ev_done));
+        c->pending = false;
+    }
+    return SGFHE_OK;
 }
 
 size_t lds_bytes(int logm, int npoly) { return (size_t)npoly * ((size_t)4 << logm); }
@@ -364,7 +405,7 @@ int32_t launch_crt_raw(sgfhe_ctx *c, const uint32_t *yres, uint64_t *dig, uint32
     // (B < 2^12, Q < 2^30), the general one
     const bool lean = mode == 0u && c->h_lean.nl != 0 && c->use_lean;
     // the same for the randomised flatten (the k-loop's modes MODE_RANDOM and MODE_RANDOM | MODE_WIDE)
-    const bool lean_rnd = (mode & ~MODE_WIDE) == MODE_RANDOM && c->h_lean.nl != 0 && c->use_lean;
+    const bool lean_rnd = (mode & ~MODE_WIDE) == MODE_RANDOM && c->lean_rnd_ok && c->use_lean;
     switch (c->npr) {
 #define X(NP)                                                                                     \
     case NP:                                                                                      \
@@ -433,6 +474,8 @@ void free_lanes(sgfhe_ctx *c) {
 
 int32_t ensure_work(sgfhe_ctx *c, uint32_t cpad) {
     if (cpad <= c->cap) return SGFHE_OK;
+    int32_t rcd = drain(c);   // an earlier asynchronous call may still be using the buffers
+    if (rcd) return rcd;
     free_lanes(c);
     for (auto &L : c->lane) {
         HIPCHK(c, hipMalloc(&L.dig, (size_t)cpad * 4 * c->M * sizeof(uint64_t)));
@@ -448,8 +491,10 @@ int32_t ensure_work(sgfhe_ctx *c, uint32_t cpad) {
 // ---- timing events ------------------------------------------------------------------------------
 
 void timing_flush(sgfhe_ctx *c) {
+    // (the samples may sit on a caller's stream: wait for the events, not for the ctx stream)
     for (auto &t : c->ev) {
         float ms = 0;
+        (void)hipEventSynchronize(t.e2);
         if (hipEventElapsedTime(&ms, t.e0, t.e1) == hipSuccess) { c->t_ext += ms; c->n_ext++; }
         if (hipEventElapsedTime(&ms, t.e1, t.e2) == hipSuccess) { c->t_crt += ms; c->n_crt++; }
         (void)hipEventDestroy(t.e0);
@@ -459,6 +504,7 @@ void timing_flush(sgfhe_ctx *c) {
     c->ev.clear();
     for (auto &t : c->ev_call) {
         float ms = 0;
+        (void)hipEventSynchronize(t.e1);
         if (hipEventElapsedTime(&ms, t.e0, t.e1) == hipSuccess) { c->t_call += ms; c->n_call++; c->boots_call += t.batch; }
         (void)hipEventDestroy(t.e0);
         (void)hipEventDestroy(t.e1);
@@ -513,10 +559,24 @@ int32_t run_iterations(sgfhe_ctx *c, ChunkJob *jobs, int njobs, uint64_t n_iters
     return SGFHE_OK;
 }
 
+// Host buffers of sgfhe_bootstrap_batch, moved chunk by chunk beside the lanes' kernels (stream_io):
+// a chunk's inputs go up while the chunks before it compute, its outputs come down while the chunks
+// after it compute, and the CPU copies between the caller's (pageable) arrays and the page-locked
+// mirrors happen while the device is busy.  What stays exposed is the first chunk's input (a few MB)
+// and the last chunks' output.
+struct HostPipe {
+    const uint64_t *a1, *b1, *a2, *b2;   // the caller's arrays
+    uint64_t *out;                        // the caller's result array
+    uint64_t *d_in, *d_out;               // device staging: chunk at row c0 = words [c0 (2 n + 2) ...) laid out
+                                          // [a1 rows | a2 rows | b1 | b2]; result rows as in `out`
+    uint64_t *p_in, *p_out;               // page-locked mirrors of both, same layouts
+    size_t out_row_words;                 // 3 (n + 1), twice that with SGFHE_FLAG_RAW_MODQ
+};
+
 int32_t bootstrap_device(sgfhe_ctx *c, const uint64_t *a1, const uint64_t *b1, const uint64_t *a2,
                          const uint64_t *b2, size_t batch, uint64_t *out, uint32_t flags,
                          uint64_t n_iters, ulonglong2 *acc_out, hipStream_t st,
-                         uint64_t *dig_out = nullptr) {
+                         uint64_t *dig_out = nullptr, const HostPipe *hp = nullptr) {
     if (!c->have_key) return fail(c, SGFHE_ERR_NO_KEY, "no bootstrap key uploaded");
     uint32_t chunk = c->chunk ? c->chunk : default_chunk(c);
     if (!c->chunk && c->lanes == 2 && batch > 2 * (size_t)c->small_max) {
@@ -547,6 +607,10 @@ int32_t bootstrap_device(sgfhe_ctx *c, const uint64_t *a1, const uint64_t *b1, c
         if (rc) return rc;
         c->last_chunk = round_up8(first);
     }
+    {   // after everything earlier calls queued on this ctx, whatever their streams
+        int32_t rc = fence_begin(c, st);
+        if (rc) return rc;
+    }
     hipEvent_t ecall0 = nullptr, ecall1 = nullptr;
     if (c->timing && c->ev_call.size() < 256) {
         HIPCHK(c, hipEventCreate(&ecall0));
@@ -557,10 +621,36 @@ int32_t bootstrap_device(sgfhe_ctx *c, const uint64_t *a1, const uint64_t *b1, c
         HIPCHK(c, hipEventRecord(c->ev_fork, st));
         HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
     }
+    // events of the host pipeline, from the ctx's pool
+    size_t ev_next = 0;
+    auto next_event = [&](hipEvent_t *e) -> hipError_t {
+        if (ev_next == c->ev_pool.size()) {
+            hipEvent_t ne = nullptr;
+            const hipError_t er = hipEventCreateWithFlags(&ne, hipEventDisableTiming);
+            if (er != hipSuccess) return er;
+            c->ev_pool.push_back(ne);
+        }
+        *e = c->ev_pool[ev_next++];
+        return hipSuccess;
+    };
+    struct OutJob { hipEvent_t done; size_t c0; uint32_t cb; };
+    std::vector<OutJob> outq;   // result rows on their way to the page-locked mirror
+    size_t out_drained = 0;
+    auto drain_out = [&](size_t upto) -> hipError_t {   // ... and from there into the caller's array
+        for (; out_drained < upto; out_drained++) {
+            const OutJob &o = outq[out_drained];
+            const hipError_t er = hipEventSynchronize(o.done);
+            if (er != hipSuccess) return er;
+            memcpy(hp->out + o.c0 * hp->out_row_words, hp->p_out + o.c0 * hp->out_row_words,
+                   (size_t)o.cb * hp->out_row_words * 8);
+        }
+        return hipSuccess;
+    };
     const size_t stride = (size_t)chunk * (two_lanes ? 2 : 1);
     for (size_t g0 = 0; g0 < batch; g0 += stride) {
         ChunkJob jobs[2];
         int njobs = 0;
+        const size_t out_before = outq.size();
         for (int li = 0; li < (two_lanes ? 2 : 1); li++) {
             const size_t c0 = g0 + (size_t)li * chunk;
             if (c0 >= batch) break;
@@ -572,10 +662,24 @@ int32_t bootstrap_device(sgfhe_ctx *c, const uint64_t *a1, const uint64_t *b1, c
             J.c0 = c0;
             J.ra = RndArgs{c->rnd_key, call, (uint32_t)c0};
             J.sampled = li == 0 && J.cpad == c->last_chunk;
+            const uint64_t *ja1 = a1 + c0 * n, *jb1 = b1 + c0, *ja2 = a2 + c0 * n, *jb2 = b2 + c0;
+            if (hp) {   // this chunk's inputs: caller's arrays -> page-locked mirror -> device, on stream_io
+                const size_t w0 = c0 * (2 * (size_t)n + 2), cb = J.cb;
+                uint64_t *pi = hp->p_in + w0, *di = hp->d_in + w0;
+                memcpy(pi, hp->a1 + c0 * n, cb * n * 8);
+                memcpy(pi + cb * n, hp->a2 + c0 * n, cb * n * 8);
+                memcpy(pi + 2 * cb * n, hp->b1 + c0, cb * 8);
+                memcpy(pi + 2 * cb * n + cb, hp->b2 + c0, cb * 8);
+                HIPCHK(c, hipMemcpyAsync(di, pi, cb * (2 * (size_t)n + 2) * 8, hipMemcpyHostToDevice, c->stream_io));
+                hipEvent_t ein;
+                HIPCHK(c, next_event(&ein));
+                HIPCHK(c, hipEventRecord(ein, c->stream_io));
+                HIPCHK(c, hipStreamWaitEvent(J.st, ein, 0));
+                ja1 = di; ja2 = di + cb * n; jb1 = di + 2 * cb * n; jb2 = jb1 + cb;
+            }
             const uint32_t tot = J.cpad * M;
-            hipLaunchKernelGGL(k_init, dim3((tot + 255) / 256), dim3(256), 0, J.st, a1 + c0 * n, b1 + c0,
-                               a2 + c0 * n, b2 + c0, J.L->dig, J.L->ua, c->d_crt, J.cb, J.cpad, n,
-                               (uint32_t)c->logm, mode, J.ra);
+            hipLaunchKernelGGL(k_init, dim3((tot + 255) / 256), dim3(256), 0, J.st, ja1, jb1, ja2, jb2,
+                               J.L->dig, J.L->ua, c->d_crt, J.cb, J.cpad, n, (uint32_t)c->logm, mode, J.ra);
             HIPCHK(c, hipGetLastError());
         }
         int32_t rc = run_iterations(c, jobs, njobs, n_iters, mode);
@@ -605,7 +709,21 @@ int32_t bootstrap_device(sgfhe_ctx *c, const uint64_t *a1, const uint64_t *b1, c
                                        (size_t)3 * t3, c->rns2);
                 HIPCHK(c, hipGetLastError());
             }
+            if (hp) {   // this chunk's results: device -> page-locked mirror on stream_io, behind its last kernel
+                hipEvent_t ek, eo;
+                HIPCHK(c, next_event(&ek));
+                HIPCHK(c, next_event(&eo));
+                HIPCHK(c, hipEventRecord(ek, J.st));
+                HIPCHK(c, hipStreamWaitEvent(c->stream_io, ek, 0));
+                const size_t w0 = J.c0 * hp->out_row_words;
+                HIPCHK(c, hipMemcpyAsync(hp->p_out + w0, hp->d_out + w0, (size_t)J.cb * hp->out_row_words * 8,
+                                         hipMemcpyDeviceToHost, c->stream_io));
+                HIPCHK(c, hipEventRecord(eo, c->stream_io));
+                outq.push_back({eo, J.c0, J.cb});
+            }
         }
+        // with this group queued, collect the results of the group before it
+        if (hp) HIPCHK(c, drain_out(out_before));
     }
     if (two_lanes) {  // join
         HIPCHK(c, hipEventRecord(c->ev_join, c->stream2));
@@ -615,6 +733,11 @@ int32_t bootstrap_device(sgfhe_ctx *c, const uint64_t *a1, const uint64_t *b1, c
         HIPCHK(c, hipEventRecord(ecall1, st));
         c->ev_call.push_back({ecall0, ecall1, (uint64_t)batch});
     }
+    {
+        int32_t rc = fence_end(c, st);
+        if (rc) return rc;
+    }
+    if (hp) HIPCHK(c, drain_out(outq.size()));
     return SGFHE_OK;
 }
 
@@ -777,6 +900,13 @@ int32_t build_constants(sgfhe_ctx *c) {
             lim((Q - (xm2 * (1 + B)) % Q) % Q, K.cR);
             K.xm2lo = (uint32_t)xm2;
             K.xm2hi = (uint32_t)(xm2 >> 32);
+            // k_crt_lean_rnd adds the draws to the old stored digits: its hi operand reaches
+            // Q / B + 6 B <= 7 B.  With two limbs (Q < 2^58) the term h1 B1 2^61 of hi B has no limb
+            // sum to go to (crt_lean_one drops it), so the kernel is taken only where that term is
+            // zero; and 6 B^2 has to stay far below the 2^34 Q of the residue sum for the quotient
+            // estimate's width (tests/rns_model.py CrtLean.digits asserts both).  Reference
+            // parameter sets have three limbs and B ~ sqrt(Q); others fall back to k_crt_acc.
+            c->lean_rnd_ok = (NL >= 3 || ((7 * B) >> 32) == 0 || K.B1 == 0) && B * B <= (Q << 27);
         }
         const char *env = getenv("SGFHE_CRT_LEAN");
         c->use_lean = !(env && env[0] == '0');
@@ -1007,7 +1137,9 @@ int32_t sgfhe_ctx_create_ex(const sgfhe_params *p, int device, uint32_t flags, s
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess)
+        hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming) != hipSuccess ||
+        hipStreamCreateWithFlags(&c->stream_io, hipStreamNonBlocking) != hipSuccess)
         return fail(c, SGFHE_ERR_HIP, "hipStreamCreate / hipEventCreate failed");
     return build_constants(c);
 }
@@ -1015,10 +1147,15 @@ int32_t sgfhe_ctx_create_ex(const sgfhe_params *p, int device, uint32_t flags, s
 int32_t sgfhe_ctx_destroy(sgfhe_ctx *c) {
     if (!c) return SGFHE_OK;
     (void)hipSetDevice(c->device);
+    (void)drain(c);   // work of an asynchronous call on a caller's stream
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->stream2) (void)hipStreamSynchronize(c->stream2);
+    if (c->stream_io) (void)hipStreamSynchronize(c->stream_io);
     timing_flush(c);
     free_lanes(c);
+    for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
+    if (c->ev_done) (void)hipEventDestroy(c->ev_done);
+    if (c->stream_io) (void)hipStreamDestroy(c->stream_io);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
@@ -1087,6 +1224,7 @@ int32_t sgfhe_set_small_batch_max(sgfhe_ctx *c, uint32_t max_bootstraps) {
     if (max_bootstraps > 256)
         return fail(c, SGFHE_ERR_INVALID_ARG, "small-batch form: at most 256 bootstraps");
     (void)hipSetDevice(c->device);
+    (void)drain(c);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->stream2) (void)hipStreamSynchronize(c->stream2);
     free_lanes(c);  // the staging buffer is sized from this value
@@ -1105,6 +1243,7 @@ int32_t sgfhe_bkey_upload(sgfhe_ctx *c, const uint64_t *canonical, size_t n_word
     if (!c || !canonical) return SGFHE_ERR_INVALID_ARG;
     SGFHE_LOCK(c);
     (void)hipSetDevice(c->device);
+    SGFHE_QUIESCE(c);
     const size_t expect = (size_t)c->n * 8 * c->M * 2;
     if (n_words != expect) return fail(c, SGFHE_ERR_INVALID_ARG, "bkey_upload: n_words != n*8*m*2");
     int32_t rc = key_alloc(c);
@@ -1137,6 +1276,7 @@ int32_t sgfhe_bkey_generate(sgfhe_ctx *c, const uint64_t *sk, size_t n_sk, const
     if (noise >= (1u << 30) || (u128)noise * 2 >= c->Q)
         return fail(c, SGFHE_ERR_INVALID_ARG, "bkey_generate: noise must be below 2^30 and below Q / 2");
     (void)hipSetDevice(c->device);
+    SGFHE_QUIESCE(c);
     int32_t rc = key_alloc(c);
     if (rc) return rc;
     const uint32_t M = c->M, rows = c->n * 4;
@@ -1215,6 +1355,7 @@ int32_t sgfhe_bkey_upload_rns2(sgfhe_ctx *c, const uint64_t *pairs, size_t n_wor
     if (!c || !pairs) return SGFHE_ERR_INVALID_ARG;
     SGFHE_LOCK(c);
     (void)hipSetDevice(c->device);
+    SGFHE_QUIESCE(c);
     const size_t expect = (size_t)c->n * 8 * c->M * 2;
     if (n_words != expect) return fail(c, SGFHE_ERR_INVALID_ARG, "bkey_upload_rns2: bad n_words");
     int32_t rc = rns2_configure(c, m1, m2);
@@ -1240,6 +1381,7 @@ int32_t sgfhe_rns2_convert(sgfhe_ctx *c, int to_pairs, const uint64_t *in, size_
     SGFHE_LOCK(c);
     if (count == 0) return SGFHE_OK;
     (void)hipSetDevice(c->device);
+    SGFHE_QUIESCE(c);
     int32_t rc = rns2_configure(c, m1, m2);
     if (rc) return rc;
     ulonglong2 *d = nullptr;
@@ -1283,6 +1425,7 @@ int32_t sgfhe_bkey_export_device_form(sgfhe_ctx *c, void *dst) {
     SGFHE_LOCK(c);
     if (!c->have_key) return fail(c, SGFHE_ERR_NO_KEY, "no bootstrap key uploaded");
     (void)hipSetDevice(c->device);
+    SGFHE_QUIESCE(c);
     const KeyBlobHeader h = blob_header(c);
     HIPCHK(c, hipMemcpy(dst, &h, sizeof h, hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpyAsync(static_cast<char *>(dst) + sizeof h, c->d_key, c->key_bytes,
@@ -1295,6 +1438,7 @@ int32_t sgfhe_bkey_import_device_form(sgfhe_ctx *c, const void *src) {
     if (!c || !src) return SGFHE_ERR_INVALID_ARG;
     SGFHE_LOCK(c);
     (void)hipSetDevice(c->device);
+    SGFHE_QUIESCE(c);
     KeyBlobHeader got;
     HIPCHK(c, hipMemcpy(&got, src, sizeof got, hipMemcpyDeviceToHost));
     const KeyBlobHeader want = blob_header(c);
@@ -1321,6 +1465,9 @@ int32_t sgfhe_bootstrap_batch_device(sgfhe_ctx *c, const uint64_t *a1, const uin
     SGFHE_LOCK(c);
     if (batch == 0) return SGFHE_OK;
     (void)hipSetDevice(c->device);
+    // The call's work is queued on the caller's stream (or the ctx's own), behind everything earlier
+    // calls queued on this ctx on any stream (fence_begin): calls on one ctx never overlap on the
+    // device, so two threads or two streams may share it.
     return bootstrap_device(c, a1, b1, a2, b2, batch, out, flags, c->n, nullptr,
                             stream ? (hipStream_t)stream : c->stream);
 }
@@ -1329,6 +1476,9 @@ int32_t sgfhe_sync(sgfhe_ctx *c) {
     if (!c) return SGFHE_ERR_INVALID_ARG;
     SGFHE_LOCK(c);
     (void)hipSetDevice(c->device);
+    // all work queued on the ctx, whichever streams the calls named (every call ends in ev_done)
+    int32_t rc = drain(c);
+    if (rc) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return SGFHE_OK;
 }
@@ -1338,12 +1488,15 @@ static int32_t bootstrap_host(sgfhe_ctx *c, const uint64_t *a1, const uint64_t *
                               uint32_t flags, uint64_t n_iters, uint64_t *acc, uint64_t *digs = nullptr) {
     (void)hipSetDevice(c->device);
     const size_t n = c->n;
-    const size_t out_words = batch * 3 * (n + 1) * ((flags & SGFHE_FLAG_RAW_MODQ) ? 2 : 1);
+    const size_t out_row = 3 * (n + 1) * ((flags & SGFHE_FLAG_RAW_MODQ) ? 2 : 1);
+    const size_t out_words = batch * out_row;
     const size_t acc_words = batch * 2 * (size_t)c->M * 2;
     uint64_t *d_in = nullptr, *d_out = nullptr, *d_dig = nullptr;
     ulonglong2 *d_acc = nullptr;
     const size_t dig_words = batch * 4 * (size_t)c->M;
     const size_t in_words = 2 * batch * (n + 1);
+    int32_t rc = drain(c);   // the staging buffers may be regrown: nothing of an earlier call may be in flight
+    if (rc) return rc;
     if (in_words > c->io_in_words) {
         if (c->io_in) (void)hipFree(c->io_in);
         c->io_in = nullptr;
@@ -1360,50 +1513,55 @@ static int32_t bootstrap_host(sgfhe_ctx *c, const uint64_t *a1, const uint64_t *
     }
     d_in = c->io_in;
     if (out) d_out = c->io_out;
-    // page-locked mirrors, grown on demand; a failed allocation falls back to direct copies
-    const size_t a_bytes = batch * n * 8;
-    bool stage_in = c->use_pin && a_bytes <= PIN_MAX_BYTES;
-    bool stage_out = c->use_pin && out && out_words * 8 <= PIN_MAX_BYTES;
-    if (stage_in && in_words > c->pin_in_words) {
+    const bool dbg = getenv("SGFHE_DEBUG_IO") != nullptr;
+    // The production call (results only): page-locked mirrors of both staging buffers, grown on demand
+    // and kept, and the copies pipelined chunk by chunk beside the kernels (HostPipe).  A failed
+    // allocation, a buffer above PIN_MAX_BYTES, SGFHE_HOST_PIN=0 and the debug hooks take direct copies
+    // of the caller's arrays.
+    bool pipe = c->use_pin && out && !acc && !digs && in_words * 8 <= PIN_MAX_BYTES &&
+                out_words * 8 <= PIN_MAX_BYTES;
+    if (pipe && in_words > c->pin_in_words) {
         if (c->pin_in) (void)hipHostFree(c->pin_in);
         c->pin_in = nullptr;
         c->pin_in_words = 0;
         const hipError_t pe = hipHostMalloc(&c->pin_in, in_words * 8, hipHostMallocDefault);
         if (pe == hipSuccess) c->pin_in_words = in_words;
-        else { (void)hipGetLastError(); c->pin_in = nullptr; stage_in = false; }
-        if (getenv("SGFHE_DEBUG_IO")) fprintf(stderr, "[sgfhe io] pin_in %zu bytes: %s\n", in_words * 8, hipGetErrorString(pe));
+        else { (void)hipGetLastError(); c->pin_in = nullptr; pipe = false; }
+        if (dbg) fprintf(stderr, "[sgfhe io] pin_in %zu bytes: %s\n", in_words * 8, hipGetErrorString(pe));
     }
-    if (stage_out && out_words > c->pin_out_words) {
+    if (pipe && out_words > c->pin_out_words) {
         if (c->pin_out) (void)hipHostFree(c->pin_out);
         c->pin_out = nullptr;
         c->pin_out_words = 0;
         const hipError_t pe = hipHostMalloc(&c->pin_out, out_words * 8, hipHostMallocDefault);
         if (pe == hipSuccess) c->pin_out_words = out_words;
-        else { (void)hipGetLastError(); c->pin_out = nullptr; stage_out = false; }
-        if (getenv("SGFHE_DEBUG_IO")) fprintf(stderr, "[sgfhe io] pin_out %zu bytes: %s\n", out_words * 8, hipGetErrorString(pe));
+        else { (void)hipGetLastError(); c->pin_out = nullptr; pipe = false; }
+        if (dbg) fprintf(stderr, "[sgfhe io] pin_out %zu bytes: %s\n", out_words * 8, hipGetErrorString(pe));
     }
-    int32_t rc = SGFHE_OK;
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t0 = now();
+    if (pipe) {
+        const HostPipe hp = {a1, b1, a2, b2, out, d_in, d_out, c->pin_in, c->pin_out, out_row};
+        rc = bootstrap_device(c, nullptr, nullptr, nullptr, nullptr, batch, d_out, flags, n_iters, nullptr,
+                              c->stream, nullptr, &hp);
+        const hipError_t e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess && rc == SGFHE_OK) rc = fail(c, SGFHE_ERR_HIP, hipGetErrorString(e));
+        if (rc == SGFHE_OK) c->pending = false;
+        if (dbg) fprintf(stderr, "[sgfhe io] batch %zu pipelined: %.2f ms\n", batch, now() - t0);
+        return rc;
+    }
     hipError_t e = hipSuccess;
     uint64_t *d_a1 = d_in, *d_a2 = d_in + batch * n, *d_b1 = d_in + 2 * batch * n,
              *d_b2 = d_b1 + batch;
-    const bool dbg = getenv("SGFHE_DEBUG_IO") != nullptr;
-    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    double t0 = now(), t1 = 0, t2 = 0, t3 = 0, t4 = 0;
+    const size_t a_bytes = batch * n * 8;
+    double t1 = 0, t2 = 0, t3 = 0;
     do {
         if (acc && (e = hipMalloc(&d_acc, acc_words * 8)) != hipSuccess) break;
         if (digs && (e = hipMalloc(&d_dig, dig_words * 8)) != hipSuccess) break;
-        if (stage_in) {   // same layout as the device buffer: one DMA
-            memcpy(c->pin_in, a1, a_bytes);
-            memcpy(c->pin_in + batch * n, a2, a_bytes);
-            memcpy(c->pin_in + 2 * batch * n, b1, batch * 8);
-            memcpy(c->pin_in + 2 * batch * n + batch, b2, batch * 8);
-            if ((e = hipMemcpyAsync(d_in, c->pin_in, in_words * 8, hipMemcpyHostToDevice, c->stream))) break;
-        } else {
-            if ((e = hipMemcpyAsync(d_a1, a1, a_bytes, hipMemcpyHostToDevice, c->stream))) break;
-            if ((e = hipMemcpyAsync(d_a2, a2, a_bytes, hipMemcpyHostToDevice, c->stream))) break;
-            if ((e = hipMemcpyAsync(d_b1, b1, batch * 8, hipMemcpyHostToDevice, c->stream))) break;
-            if ((e = hipMemcpyAsync(d_b2, b2, batch * 8, hipMemcpyHostToDevice, c->stream))) break;
-        }
+        if ((e = hipMemcpyAsync(d_a1, a1, a_bytes, hipMemcpyHostToDevice, c->stream))) break;
+        if ((e = hipMemcpyAsync(d_a2, a2, a_bytes, hipMemcpyHostToDevice, c->stream))) break;
+        if ((e = hipMemcpyAsync(d_b1, b1, batch * 8, hipMemcpyHostToDevice, c->stream))) break;
+        if ((e = hipMemcpyAsync(d_b2, b2, batch * 8, hipMemcpyHostToDevice, c->stream))) break;
         t1 = now();
         rc = bootstrap_device(c, d_a1, d_b1, d_a2, d_b2, batch, d_out, flags, n_iters, d_acc,
                               c->stream, d_dig);
@@ -1411,18 +1569,16 @@ static int32_t bootstrap_host(sgfhe_ctx *c, const uint64_t *a1, const uint64_t *
         t2 = now();
         if (digs && (e = hipMemcpyAsync(digs, d_dig, dig_words * 8, hipMemcpyDeviceToHost, c->stream)))
             break;
-        if (out && (e = hipMemcpyAsync(stage_out ? c->pin_out : out, d_out, out_words * 8,
-                                       hipMemcpyDeviceToHost, c->stream)))
+        if (out && (e = hipMemcpyAsync(out, d_out, out_words * 8, hipMemcpyDeviceToHost, c->stream)))
             break;
         if (acc && (e = hipMemcpyAsync(acc, d_acc, acc_words * 8, hipMemcpyDeviceToHost, c->stream)))
             break;
         e = hipStreamSynchronize(c->stream);
+        if (e == hipSuccess) c->pending = false;
         t3 = now();
-        if (e == hipSuccess && stage_out) memcpy(out, c->pin_out, out_words * 8);
-        t4 = now();
         if (dbg)
-            fprintf(stderr, "[sgfhe io] batch %zu stage_in %d stage_out %d: copy-in %.2f ms, enqueue %.2f, wait %.2f, copy-out %.2f\n",
-                    batch, (int)stage_in, (int)stage_out, t1 - t0, t2 - t1, t3 - t2, t4 - t3);
+            fprintf(stderr, "[sgfhe io] batch %zu direct copies: copy-in %.2f ms, enqueue %.2f, wait + copy-out %.2f\n",
+                    batch, t1 - t0, t2 - t1, t3 - t2);
     } while (0);
     if (e != hipSuccess && rc == SGFHE_OK) rc = fail(c, SGFHE_ERR_HIP, hipGetErrorString(e));
     if (d_acc) (void)hipFree(d_acc);   // debug hooks only
@@ -1462,6 +1618,7 @@ int32_t sgfhe_debug_flatten(sgfhe_ctx *c, const uint64_t *values, uint64_t *digi
     if (!c || !values || !digits) return SGFHE_ERR_INVALID_ARG;
     SGFHE_LOCK(c);
     (void)hipSetDevice(c->device);
+    SGFHE_QUIESCE(c);
     const uint32_t M = c->M;
     int32_t rc = ensure_work(c, 8);
     if (rc) return rc;
@@ -1495,6 +1652,7 @@ int32_t sgfhe_external_product(sgfhe_ctx *c, const uint64_t *a, const uint64_t *
     if (!c || !a || !b || !A || !a_res || !b_res) return SGFHE_ERR_INVALID_ARG;
     SGFHE_LOCK(c);
     (void)hipSetDevice(c->device);
+    SGFHE_QUIESCE(c);
     const uint32_t M = c->M;
     const uint32_t cpad = 8;
     int32_t rc = ensure_work(c, cpad);
@@ -1534,6 +1692,7 @@ int32_t sgfhe_debug_cmux(sgfhe_ctx *c, const uint64_t *a, const uint64_t *b, con
     SGFHE_LOCK(c);
     if (j >= 2 * (uint64_t)c->M) return fail(c, SGFHE_ERR_INVALID_ARG, "debug_cmux: j must be in [0, 2 m)");
     (void)hipSetDevice(c->device);
+    SGFHE_QUIESCE(c);
     const uint32_t M = c->M;
     const uint32_t cpad = 8;
     int32_t rc = ensure_work(c, cpad);
@@ -1579,6 +1738,7 @@ int32_t sgfhe_pack_encrypted_bits(sgfhe_ctx *c, const uint64_t *a, const uint64_
     if (count == 0) return SGFHE_OK;
     if (!c->have_key) return fail(c, SGFHE_ERR_NO_KEY, "no bootstrap key uploaded");
     (void)hipSetDevice(c->device);
+    SGFHE_QUIESCE(c);
     const size_t n = c->n, M = c->M;
     const size_t nb = count * n;  // bootstraps
     // rng != nothing: the n bootstraps and the flatten of every as_i (all m coefficients of the
@@ -1646,6 +1806,7 @@ int32_t sgfhe_debug_ntt(sgfhe_ctx *c, uint32_t prime_index, int inverse, const u
     if (!c || !in || !out || prime_index >= c->npr) return SGFHE_ERR_INVALID_ARG;
     SGFHE_LOCK(c);
     (void)hipSetDevice(c->device);
+    SGFHE_QUIESCE(c);
     uint32_t *d = nullptr;
     HIPCHK(c, hipMalloc(&d, (size_t)2 * c->M * 4));
     int32_t rc = SGFHE_OK;
@@ -1859,6 +2020,39 @@ int32_t sgfhe_host_normalize_public(const sgfhe_params *p, const uint8_t *a_bits
     return SGFHE_OK;
 }
 
+int32_t sgfhe_kernel_names(const sgfhe_ctx *c, char *extprod, size_t extprod_cap, char *crt, size_t crt_cap) {
+    if (!c || !extprod || !crt || !extprod_cap || !crt_cap) return SGFHE_ERR_INVALID_ARG;
+    SGFHE_LOCK(c);
+    const bool wide = c->rnd && (c->B >> 46);
+    const int le = c->logm <= SGFHE_EXT_LE3_MAX ? 3 : LOGE;
+    snprintf(extprod, extprod_cap, "k_extprod<%d, %d, %s>", c->logm, le, wide ? "true" : "false");
+    // the selection of launch_crt_raw for the k-loop's mode
+    if (!c->rnd && c->h_lean.nl && c->use_lean)
+        snprintf(crt, crt_cap, "k_crt_lean<%u, %u>", c->npr, c->h_lean.nl);
+    else if (c->rnd && c->lean_rnd_ok && c->use_lean)
+        snprintf(crt, crt_cap, "k_crt_lean_rnd<%u, %u, %s>", c->npr, c->h_lean.nl, wide ? "true" : "false");
+    else if (!c->rnd)
+        snprintf(crt, crt_cap, "k_crt_acc2<%u>", c->npr);
+    else
+        snprintf(crt, crt_cap, "k_crt_acc<%u>", c->npr);
+    return SGFHE_OK;
+}
+
+int32_t sgfhe_release_host_staging(sgfhe_ctx *c) {
+    if (!c) return SGFHE_ERR_INVALID_ARG;
+    SGFHE_LOCK(c);
+    (void)hipSetDevice(c->device);
+    SGFHE_QUIESCE(c);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->io_in) (void)hipFree(c->io_in);
+    if (c->io_out) (void)hipFree(c->io_out);
+    if (c->pin_in) (void)hipHostFree(c->pin_in);
+    if (c->pin_out) (void)hipHostFree(c->pin_out);
+    c->io_in = c->io_out = c->pin_in = c->pin_out = nullptr;
+    c->io_in_words = c->io_out_words = c->pin_in_words = c->pin_out_words = 0;
+    return SGFHE_OK;
+}
+
 int32_t sgfhe_timing_enable(sgfhe_ctx *c, int enable) {
     if (!c) return SGFHE_ERR_INVALID_ARG;
     SGFHE_LOCK(c);
@@ -1870,6 +2064,8 @@ int32_t sgfhe_timing_read(sgfhe_ctx *c, double *stats, int reset) {
     if (!c || !stats) return SGFHE_ERR_INVALID_ARG;
     SGFHE_LOCK(c);
     (void)hipSetDevice(c->device);
+    int32_t rcd = drain(c);
+    if (rcd) return rcd;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     timing_flush(c);
     stats[0] = c->n_ext ? c->t_ext / (double)c->n_ext : 0.0;

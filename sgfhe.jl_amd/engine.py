@@ -6,6 +6,7 @@ is only plumbing for device memory and torch.distributed (RCCL), never the compu
 """
 
 import ctypes
+import threading
 
 import numpy as np
 
@@ -39,6 +40,11 @@ class Engine:
         bootstrap / pack_encrypted_bits): one more prime at Params(1024), nothing elsewhere."""
         self.params = params
         self.device = device
+        # Held around every C call together with the read of its error string, and by the scheme
+        # layer from the choice of the flatten mode to the end of the call that uses it, so that
+        # threads sharing an Engine cannot interleave between the two (the C library serialises the
+        # individual calls; the pairs are this binding's to keep together).
+        self.lock = threading.RLock()
         self._L = _lib.lib()
         sp = _lib.SgfheParams(params.n, params.r, params.m, params.ell, _words(params.Q),
                               _words(params.B), _words(params.DQ_tilde))
@@ -64,9 +70,11 @@ class Engine:
         except Exception:
             pass
 
-    def _chk(self, rc):
-        if rc != 0:
-            raise SgfheError(rc, self._L.sgfhe_last_error_string(self._h).decode())
+    def _call(self, name, *args):
+        with self.lock:
+            rc = getattr(self._L, name)(self._h, *args)
+            if rc != 0:
+                raise SgfheError(rc, self._L.sgfhe_last_error_string(self._h).decode())
 
     # ---- key ------------------------------------------------------------------------------
     def upload_key(self, canonical):
@@ -75,20 +83,20 @@ class Engine:
         a, ptr = _c(canonical)
         if a.size != p.n * 8 * p.m * 2:
             raise ValueError("bootstrap key must hold n*4*2*m residues of 2 words")
-        self._chk(self._L.sgfhe_bkey_upload(self._h, ptr, a.size))
+        self._call("sgfhe_bkey_upload", ptr, a.size)
 
     def upload_key_rns2(self, pairs, m1, m2):
         """pairs: [n][4][2][m][2] uint64 (v1, v2) RNS2Number limbs (src/rns.jl:8-24)."""
         a, ptr = _c(pairs)
-        self._chk(self._L.sgfhe_bkey_upload_rns2(self._h, ptr, a.size, m1, m2))
+        self._call("sgfhe_bkey_upload_rns2", ptr, a.size, m1, m2)
 
     def rns2_convert(self, values, m1, m2, to_pairs):
         """src/rns.jl on the device: [..., 2] uint64 canonical {lo, hi} -> (x mod m1, x mod m2)
         (to_pairs=True, rns.jl:16-18) or limb pairs -> canonical (to_pairs=False, rns.jl:32-40)."""
         a, ptr = _c(values)
         out = np.zeros_like(a)
-        self._chk(self._L.sgfhe_rns2_convert(self._h, int(bool(to_pairs)), ptr, a.size // 2, m1, m2,
-                                             out.ctypes.data_as(ctypes.c_void_p)))
+        self._call("sgfhe_rns2_convert", int(bool(to_pairs)), ptr, a.size // 2, m1, m2,
+                                             out.ctypes.data_as(ctypes.c_void_p))
         return out
 
     def generate_key(self, sk_bits, seed, noise=None):
@@ -99,30 +107,30 @@ class Engine:
             seed = int(seed).to_bytes(32, "little")
         if len(seed) != 32:
             raise ValueError("key seed must be 32 bytes")
-        self._chk(self._L.sgfhe_bkey_generate(self._h, ptr, a.size, bytes(seed),
-                                              self.params.n if noise is None else noise))
+        self._call("sgfhe_bkey_generate", ptr, a.size, bytes(seed),
+                                              self.params.n if noise is None else noise)
 
     def key_device_form_bytes(self):
         n = ctypes.c_size_t()
-        self._chk(self._L.sgfhe_bkey_device_form_bytes(self._h, ctypes.byref(n)))
+        self._call("sgfhe_bkey_device_form_bytes", ctypes.byref(n))
         return n.value
 
     def export_key_device_form(self, dst_device_ptr):
-        self._chk(self._L.sgfhe_bkey_export_device_form(self._h, ctypes.c_void_p(dst_device_ptr)))
+        self._call("sgfhe_bkey_export_device_form", ctypes.c_void_p(dst_device_ptr))
 
     def import_key_device_form(self, src_device_ptr):
-        self._chk(self._L.sgfhe_bkey_import_device_form(self._h, ctypes.c_void_p(src_device_ptr)))
+        self._call("sgfhe_bkey_import_device_form", ctypes.c_void_p(src_device_ptr))
 
     # ---- bootstrap ----------------------------------------------------------------------------
     def set_chunk(self, chunk):
-        self._chk(self._L.sgfhe_set_chunk(self._h, chunk))
+        self._call("sgfhe_set_chunk", chunk)
 
     def set_lanes(self, lanes):
-        self._chk(self._L.sgfhe_set_lanes(self._h, lanes))
+        self._call("sgfhe_set_lanes", lanes)
 
     def set_small_batch_max(self, max_bootstraps):
         """Chunks of at most this many bootstraps use the small-batch form of the k-loop (0: never)."""
-        self._chk(self._L.sgfhe_set_small_batch_max(self._h, max_bootstraps))
+        self._call("sgfhe_set_small_batch_max", max_bootstraps)
 
     def set_random_flatten(self, enable, seed=0):
         """rng != nothing branch of flatten (utils.jl:198-241): the draws come from a ChaCha8 counter
@@ -134,7 +142,7 @@ class Engine:
             key = bytes(seed)
         else:
             key = (int(seed) % (1 << 256)).to_bytes(32, "little")
-        self._chk(self._L.sgfhe_set_random_flatten_key(self._h, int(bool(enable)), key))
+        self._call("sgfhe_set_random_flatten_key", int(bool(enable)), key)
 
     def _lwe_args(self, a1, b1, a2, b2):
         n = self.params.n
@@ -166,21 +174,19 @@ class Engine:
         elif out.shape != shape or out.dtype != np.uint64 or not out.flags["C_CONTIGUOUS"]:
             raise ValueError("bootstrap_batch: out must be a C-contiguous uint64 array of shape %r" % (shape,))
         if batch:
-            self._chk(self._L.sgfhe_bootstrap_batch(
-                self._h, p1, q1, p2, q2, batch, out.ctypes.data_as(ctypes.c_void_p),
-                (FLAG_RAW_MODQ if raw else 0) | (FLAG_RAW_RNS2 if rns2 else 0)))
+            self._call("sgfhe_bootstrap_batch", p1, q1, p2, q2, batch, out.ctypes.data_as(ctypes.c_void_p),
+                (FLAG_RAW_MODQ if raw else 0) | (FLAG_RAW_RNS2 if rns2 else 0))
         return out
 
     def bootstrap_batch_device(self, a1_ptr, b1_ptr, a2_ptr, b2_ptr, batch, out_ptr, raw=False,
                                stream=None):
         """Asynchronous, all buffers device-resident (raw pointers)."""
-        self._chk(self._L.sgfhe_bootstrap_batch_device(
-            self._h, ctypes.c_void_p(a1_ptr), ctypes.c_void_p(b1_ptr), ctypes.c_void_p(a2_ptr),
+        self._call("sgfhe_bootstrap_batch_device", ctypes.c_void_p(a1_ptr), ctypes.c_void_p(b1_ptr), ctypes.c_void_p(a2_ptr),
             ctypes.c_void_p(b2_ptr), batch, ctypes.c_void_p(out_ptr),
-            FLAG_RAW_MODQ if raw else 0, ctypes.c_void_p(stream or 0)))
+            FLAG_RAW_MODQ if raw else 0, ctypes.c_void_p(stream or 0))
 
     def sync(self):
-        self._chk(self._L.sgfhe_sync(self._h))
+        self._call("sgfhe_sync")
 
     def pack_encrypted_bits(self, a, b):
         """pack_encrypted_bits (fhe.jl:660-696) for `count` groups of n LWEs: a [count][n][n],
@@ -193,9 +199,9 @@ class Engine:
         count = a.size // (p.n * p.n)
         w = np.zeros((count, p.m), dtype=np.uint64)
         v = np.zeros((count, p.m), dtype=np.uint64)
-        self._chk(self._L.sgfhe_pack_encrypted_bits(self._h, pa, pb, count,
+        self._call("sgfhe_pack_encrypted_bits", pa, pb, count,
                                                     w.ctypes.data_as(ctypes.c_void_p),
-                                                    v.ctypes.data_as(ctypes.c_void_p)))
+                                                    v.ctypes.data_as(ctypes.c_void_p))
         return w, v
 
     # ---- parity / debug hooks ---------------------------------------------------------------
@@ -209,9 +215,9 @@ class Engine:
             raise ValueError("external_product: a, b are [m][2]; A is [4][2][m][2]")
         ra = np.zeros((m, 2), dtype=np.uint64)
         rb = np.zeros((m, 2), dtype=np.uint64)
-        self._chk(self._L.sgfhe_external_product(self._h, pa, pb, pA,
+        self._call("sgfhe_external_product", pa, pb, pA,
                                                  ra.ctypes.data_as(ctypes.c_void_p),
-                                                 rb.ctypes.data_as(ctypes.c_void_p)))
+                                                 rb.ctypes.data_as(ctypes.c_void_p))
         return ra, rb
 
     def debug_cmux(self, a, b, C, j):
@@ -225,16 +231,16 @@ class Engine:
             raise ValueError("debug_cmux: a, b are [m][2]; C is [4][2][m][2]")
         ra = np.zeros((m, 2), dtype=np.uint64)
         rb = np.zeros((m, 2), dtype=np.uint64)
-        self._chk(self._L.sgfhe_debug_cmux(self._h, pa, pb, pC, int(j), ra.ctypes.data_as(ctypes.c_void_p),
-                                           rb.ctypes.data_as(ctypes.c_void_p)))
+        self._call("sgfhe_debug_cmux", pa, pb, pC, int(j), ra.ctypes.data_as(ctypes.c_void_p),
+                                           rb.ctypes.data_as(ctypes.c_void_p))
         return ra, rb
 
     def debug_accumulators(self, a1, b1, a2, b2, n_iters):
         batch, (p1, q1, p2, q2), _keep = self._lwe_args(a1, b1, a2, b2)
         acc = np.zeros((batch, 2, self.params.m, 2), dtype=np.uint64)
         if batch:
-            self._chk(self._L.sgfhe_debug_accumulators(self._h, p1, q1, p2, q2, batch, n_iters,
-                                                       acc.ctypes.data_as(ctypes.c_void_p)))
+            self._call("sgfhe_debug_accumulators", p1, q1, p2, q2, batch, n_iters,
+                                                       acc.ctypes.data_as(ctypes.c_void_p))
         return acc
 
     def debug_digits(self, a1, b1, a2, b2, n_iters):
@@ -242,8 +248,8 @@ class Engine:
         batch, (p1, q1, p2, q2), _keep = self._lwe_args(a1, b1, a2, b2)
         dig = np.zeros((batch, 2, 2, self.params.m), dtype=np.uint64)
         if batch:
-            self._chk(self._L.sgfhe_debug_digits(self._h, p1, q1, p2, q2, batch, n_iters,
-                                                 dig.ctypes.data_as(ctypes.c_void_p)))
+            self._call("sgfhe_debug_digits", p1, q1, p2, q2, batch, n_iters,
+                                                 dig.ctypes.data_as(ctypes.c_void_p))
         return dig
 
     def debug_flatten(self, values):
@@ -254,34 +260,45 @@ class Engine:
         if a.size != 4 * m:
             raise ValueError("debug_flatten: values is [2][m][2]")
         dig = np.zeros((2, 2, m), dtype=np.uint64)
-        self._chk(self._L.sgfhe_debug_flatten(self._h, ptr, dig.ctypes.data_as(ctypes.c_void_p)))
+        self._call("sgfhe_debug_flatten", ptr, dig.ctypes.data_as(ctypes.c_void_p))
         return dig
 
     def debug_ntt(self, prime_index, poly, inverse=False):
         x, px = _c(poly, np.uint32)
         out = np.zeros(self.params.m, dtype=np.uint32)
-        self._chk(self._L.sgfhe_debug_ntt(self._h, prime_index, int(inverse), px,
-                                          out.ctypes.data_as(ctypes.c_void_p)))
+        self._call("sgfhe_debug_ntt", prime_index, int(inverse), px,
+                                          out.ctypes.data_as(ctypes.c_void_p))
         return out
 
     def primes(self):
         cnt = ctypes.c_uint32()
         arr = (ctypes.c_uint32 * 8)()
-        self._chk(self._L.sgfhe_debug_primes(self._h, ctypes.byref(cnt), arr))
+        self._call("sgfhe_debug_primes", ctypes.byref(cnt), arr)
         return [int(arr[i]) for i in range(cnt.value)]
 
     # ---- measurement ----------------------------------------------------------------------------
     def timing_enable(self, on=True):
-        self._chk(self._L.sgfhe_timing_enable(self._h, int(on)))
+        self._call("sgfhe_timing_enable", int(on))
 
     def build_id(self):
         """sgfhe_build_id() of the loaded library: hash of the kernel sources it was compiled from
         (+ ablation flags)."""
         return self._L.sgfhe_build_id().decode()
 
+    def kernel_names(self):
+        """(external-product kernel, CRT kernel) of the k-loop in the present flatten mode, as a
+        rocprofv3 kernel trace names them (sgfhe_kernel_names)."""
+        a, b = ctypes.create_string_buffer(64), ctypes.create_string_buffer(64)
+        self._call("sgfhe_kernel_names", a, 64, b, 64)
+        return a.value.decode(), b.value.decode()
+
+    def release_host_staging(self):
+        """Free the device and page-locked staging buffers bootstrap_batch keeps on the ctx."""
+        self._call("sgfhe_release_host_staging")
+
     def timing_read(self, reset=True):
         st = (ctypes.c_double * 8)()
-        self._chk(self._L.sgfhe_timing_read(self._h, st, int(reset)))
+        self._call("sgfhe_timing_read", st, int(reset))
         return dict(extprod_ms=st[0], extprod_samples=int(st[1]), crt_ms=st[2],
                     crt_samples=int(st[3]), chunk=int(st[4]), call_ms=st[5], calls=int(st[6]),
                     call_batch=st[7])

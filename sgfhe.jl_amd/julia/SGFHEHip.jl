@@ -21,7 +21,7 @@ const libsgfhe_hip = get(ENV, "SGFHE_HIP_LIB", "libsgfhe_hip.so")
 
 # Revision of include/sgfhe_hip.h these ccalls were written for (SGFHE_ABI_VERSION): a library
 # built from another revision is refused when the module loads.
-const ABI_VERSION = UInt32(5)
+const ABI_VERSION = UInt32(6)
 
 function __init__()
     got = ccall((:sgfhe_abi_version, libsgfhe_hip), UInt32, ())

@@ -352,13 +352,14 @@ def pack_encrypted_bits(bkey, rng, enc_bits):
     """pack_encrypted_bits(bkey, rng, enc_bits) (src/fhe.jl:660-696): n EncryptedBits -> one
     RLWE Ciphertext, on the HIP engine.  rng = None: deterministic flatten (bit-exact); a numpy
     Generator: randomised flatten of the n bootstraps and of the shortened external products."""
-    _set_flatten_mode(bkey, rng)
     p = bkey.params
     if len(enc_bits) != p.n:
         raise AssertionError("exactly n encrypted bits are required (src/fhe.jl:667)")
     a = np.stack([e.lwe.a for e in enc_bits])[None, :, :]
     b = np.array([e.lwe.b for e in enc_bits], dtype=np.uint64)[None, :]
-    w, v = bkey.engine.pack_encrypted_bits(a, b)
+    with bkey.engine.lock:                       # mode and call stay together (threads sharing a key)
+        _set_flatten_mode(bkey, rng)
+        w, v = bkey.engine.pack_encrypted_bits(a, b)
     return Ciphertext(p, RLWE(w[0], v[0]))
 
 
@@ -393,16 +394,16 @@ def _set_flatten_mode(bkey, rng):
 def bootstrap(bkey, rng, enc_bit1, enc_bit2):
     """bootstrap(bkey, rng, enc_bit1, enc_bit2) (src/fhe.jl:608-621): returns EncryptedBits of
     AND, OR, XOR.  A batch of 1 through the HIP engine."""
-    _set_flatten_mode(bkey, rng)
-    out = bkey.engine.bootstrap_batch(enc_bit1.lwe.a[None, :], [enc_bit1.lwe.b],
-                                      enc_bit2.lwe.a[None, :], [enc_bit2.lwe.b])
+    with bkey.engine.lock:                       # mode and call stay together (threads sharing a key)
+        _set_flatten_mode(bkey, rng)
+        out = bkey.engine.bootstrap_batch(enc_bit1.lwe.a[None, :], [enc_bit1.lwe.b],
+                                          enc_bit2.lwe.a[None, :], [enc_bit2.lwe.b])
     n = bkey.params.n
     return tuple(EncryptedBit(LWE(out[0, g, :n], out[0, g, n])) for g in range(3))
 
 
 def bootstrap_batch(bkey, rng, enc_bits1, enc_bits2):
     """Batched form: two equally long lists of EncryptedBit -> list of (AND, OR, XOR) triples."""
-    _set_flatten_mode(bkey, rng)
     if len(enc_bits1) != len(enc_bits2):
         raise ValueError("ragged batch")
     n = bkey.params.n
@@ -412,6 +413,8 @@ def bootstrap_batch(bkey, rng, enc_bits1, enc_bits2):
     a2 = np.stack([e.lwe.a for e in enc_bits2])
     b1 = np.array([e.lwe.b for e in enc_bits1], dtype=np.uint64)
     b2 = np.array([e.lwe.b for e in enc_bits2], dtype=np.uint64)
-    out = bkey.engine.bootstrap_batch(a1, b1, a2, b2)
+    with bkey.engine.lock:
+        _set_flatten_mode(bkey, rng)
+        out = bkey.engine.bootstrap_batch(a1, b1, a2, b2)
     return [tuple(EncryptedBit(LWE(out[t, g, :n], out[t, g, n])) for g in range(3))
             for t in range(out.shape[0])]

@@ -115,23 +115,48 @@ def test_extract_matches_reference_semantics(S):
 
 
 def test_pack_selects_flatten_mode_and_checks_length(S):
-    """pack_encrypted_bits(bkey, rng, enc_bits): rng picks the flatten mode on the engine (as for
-    bootstrap) before anything else; a wrong number of bits is the reference's assertion
-    (src/fhe.jl:667)."""
+    """pack_encrypted_bits(bkey, rng, enc_bits): a wrong number of bits is the reference's assertion
+    (src/fhe.jl:667), raised before the engine is touched; otherwise rng picks the flatten mode on
+    the engine (as for bootstrap) and the call follows it under the engine's lock, so that threads
+    sharing a key cannot interleave between the two."""
+    import threading
     calls = []
+    p = S.Params(64)
 
     class FakeEngine:
+        lock = threading.RLock()
+
         def set_random_flatten(self, enable, seed=0):
-            calls.append((bool(enable), seed))
+            assert self.lock._is_owned()
+            calls.append(("mode", bool(enable), seed))
+
+        def pack_encrypted_bits(self, a, b):
+            assert self.lock._is_owned()
+            calls.append(("pack", a.shape, b.shape))
+            return np.zeros((1, p.m), dtype=np.uint64), np.zeros((1, p.m), dtype=np.uint64)
+
+        def bootstrap_batch(self, a1, b1, a2, b2):
+            assert self.lock._is_owned()
+            calls.append(("bootstrap", np.asarray(a1).shape))
+            return np.zeros((np.asarray(a1).shape[0], 3, p.n + 1), dtype=np.uint64)
 
     class Dummy:
-        params = S.Params(64)
+        params = p
         engine = FakeEngine()
     with pytest.raises(AssertionError):
         S.pack_encrypted_bits(Dummy(), np.random.default_rng(0), [])
     with pytest.raises(AssertionError):
         S.pack_encrypted_bits(Dummy(), None, [])
-    assert calls[0][0] is True and calls[1] == (False, 0)
+    assert calls == []
+    bit = S.EncryptedBit(S.LWE(np.zeros(p.n, dtype=np.uint64), np.uint64(0)))
+    S.pack_encrypted_bits(Dummy(), np.random.default_rng(0), [bit] * p.n)
+    S.pack_encrypted_bits(Dummy(), None, [bit] * p.n)
+    S.bootstrap(Dummy(), None, bit, bit)
+    S.bootstrap_batch(Dummy(), np.random.default_rng(1), [bit, bit], [bit, bit])
+    kinds = [c[0] for c in calls]
+    assert kinds == ["mode", "pack", "mode", "pack", "mode", "bootstrap", "mode", "bootstrap"]
+    assert calls[0][1] is True and len(calls[0][2]) == 32 and calls[2][1:] == (False, 0)
+    assert calls[4][1] is False and calls[6][1] is True
 
 
 def test_library_exports_every_declared_symbol(S):
