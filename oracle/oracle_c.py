@@ -68,7 +68,8 @@ def lib():
         L.sgo_bootstrap_batch_rnd.argtypes = [ctypes.c_void_p, ctypes.c_int, _u64p, _u64p, _u64p, _u64p,
                                               _u64p, ctypes.c_size_t, _u64p, ctypes.c_int,
                                               ctypes.c_uint64, _u64p, ctypes.c_int, ctypes.c_char_p,
-                                              ctypes.c_uint32, ctypes.c_uint32]
+                                              ctypes.c_uint32, ctypes.c_uint32,
+                                              ctypes.POINTER(ctypes.c_uint32)]
         _lib = L
     return _lib
 
@@ -249,7 +250,8 @@ class Oracle:
         path's algebra (4 + 2 NTTs per iteration, BASELINE.md `cpu_opt`); same outputs.
         rnd=(seed, call[, boot0]): bootstrap(bkey, rng, ...) -- the randomised flatten
         (utils.jl:198-241) on the engine's ChaCha8 stream keyed with `seed` (32 bytes or an int);
-        row t of the batch draws as bootstrap boot0 + t of call `call`."""
+        row t of the batch draws as bootstrap boot0 + t of call `call`; boot0 may be an array of
+        one index per row (rows picked out of a larger call)."""
         bkey = np.ascontiguousarray(bkey, dtype=np.uint64)
         a1 = np.ascontiguousarray(a1, dtype=np.uint64).reshape(-1, self.n)
         a2 = np.ascontiguousarray(a2, dtype=np.uint64).reshape(-1, self.n)
@@ -264,10 +266,17 @@ class Oracle:
         if rnd is not None:
             seed, call = rnd[0], rnd[1]
             boot0 = rnd[2] if len(rnd) > 2 else 0
+            boots = None
+            if not np.isscalar(boot0):
+                boots = np.ascontiguousarray(boot0, dtype=np.uint32)
+                assert boots.shape == (batch,)
+                boot0 = 0
             rc = lib().sgo_bootstrap_batch_rnd(self._ctx, 1 if opt else 0, _p(bkey), _p(a1), _p(b1), _p(a2),
                                                _p(b2), batch, _p(out), 1 if raw else 0, niter,
                                                _p(acc) if want_acc else None, nthreads, seed_bytes(seed),
-                                               call, boot0)
+                                               call, int(boot0),
+                                               boots.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32))
+                                               if boots is not None else None)
         else:
             fn = lib().sgo_bootstrap_batch_opt if opt else lib().sgo_bootstrap_batch
             rc = fn(self._ctx, _p(bkey), _p(a1), _p(b1), _p(a2), _p(b2), batch, _p(out), 1 if raw else 0,

@@ -755,7 +755,7 @@ static int bootstrap_one(const sgo_ctx *c, const u128 *bkey, const u128 *khat, c
 static int bootstrap_batch(const sgo_ctx *c, int opt, const uint64_t *bkey, const uint64_t *a1,
                            const uint64_t *b1, const uint64_t *a2, const uint64_t *b2, size_t batch,
                            uint64_t *out, int raw, uint64_t n_iters, uint64_t *acc_out, int threads,
-                           const rnd_t *g0) {
+                           const rnd_t *g0, const uint32_t *boots) {
     size_t n = c->n, m = c->m;
     int rc = 0;
     if (opt && !c->use_ntt) return -2;
@@ -763,7 +763,7 @@ static int bootstrap_batch(const sgo_ctx *c, int opt, const uint64_t *bkey, cons
     for (long t = 0; t < (long)batch; t++) {
         u128 *rawbuf = (u128 *)malloc(3 * (n + 1) * sizeof(u128));
         rnd_t g;
-        if (g0) { g = *g0; g.boot = g0->boot + (uint32_t)t; }           /* bootstrap t of the call */
+        if (g0) { g = *g0; g.boot = boots ? boots[t] : g0->boot + (uint32_t)t; }   /* its index in the call */
         int r1 = bootstrap_one(c, opt ? NULL : (const u128 *)bkey, opt ? (const u128 *)bkey : NULL,
                                a1 + (size_t)t * n, b1[t], a2 + (size_t)t * n, b2[t], n_iters,
                                out ? rawbuf : NULL,
@@ -788,7 +788,7 @@ static int bootstrap_batch(const sgo_ctx *c, int opt, const uint64_t *bkey, cons
 int sgo_bootstrap_batch(const sgo_ctx *c, const uint64_t *bkey, const uint64_t *a1,
                         const uint64_t *b1, const uint64_t *a2, const uint64_t *b2, size_t batch,
                         uint64_t *out, int raw, uint64_t n_iters, uint64_t *acc_out, int threads) {
-    return bootstrap_batch(c, 0, bkey, a1, b1, a2, b2, batch, out, raw, n_iters, acc_out, threads, NULL);
+    return bootstrap_batch(c, 0, bkey, a1, b1, a2, b2, batch, out, raw, n_iters, acc_out, threads, NULL, NULL);
 }
 
 /* NTT-domain form of the bootstrap key for sgo_bootstrap_batch_opt: every polynomial through the
@@ -805,24 +805,25 @@ int sgo_key_transform(const sgo_ctx *c, const uint64_t *bkey, uint64_t *khat, in
 int sgo_bootstrap_batch_opt(const sgo_ctx *c, const uint64_t *khat, const uint64_t *a1,
                             const uint64_t *b1, const uint64_t *a2, const uint64_t *b2, size_t batch,
                             uint64_t *out, int raw, uint64_t n_iters, uint64_t *acc_out, int threads) {
-    return bootstrap_batch(c, 1, khat, a1, b1, a2, b2, batch, out, raw, n_iters, acc_out, threads, NULL);
+    return bootstrap_batch(c, 1, khat, a1, b1, a2, b2, batch, out, raw, n_iters, acc_out, threads, NULL, NULL);
 }
 
 /* bootstrap(bkey, rng, ...) (fhe.jl:608-621 with rng::AbstractRNG): the randomised flatten of
  * utils.jl:198-241 on the ChaCha8 stream keyed with key32; bootstrap t of the batch is bootstrap
- * boot0 + t of call `call`.  opt != 0: `key` is the NTT-domain key (sgo_key_transform) and the
- * k-loop runs in the GPU path's algebra; same outputs. */
+ * boot0 + t of call `call`, or bootstrap boots[t] when `boots` is given (rows picked out of a larger
+ * call).  opt != 0: `key` is the NTT-domain key (sgo_key_transform) and the k-loop runs in the GPU
+ * path's algebra; same outputs. */
 int sgo_bootstrap_batch_rnd(const sgo_ctx *c, int opt, const uint64_t *key, const uint64_t *a1,
                             const uint64_t *b1, const uint64_t *a2, const uint64_t *b2, size_t batch,
                             uint64_t *out, int raw, uint64_t n_iters, uint64_t *acc_out, int threads,
-                            const uint8_t *key32, uint32_t call, uint32_t boot0) {
+                            const uint8_t *key32, uint32_t call, uint32_t boot0, const uint32_t *boots) {
     rnd_t g;
     for (int i = 0; i < 8; i++)
         g.key[i] = (uint32_t)key32[4 * i] | ((uint32_t)key32[4 * i + 1] << 8) |
                    ((uint32_t)key32[4 * i + 2] << 16) | ((uint32_t)key32[4 * i + 3] << 24);
     g.call = call;
     g.boot = boot0;
-    return bootstrap_batch(c, opt, key, a1, b1, a2, b2, batch, out, raw, n_iters, acc_out, threads, &g);
+    return bootstrap_batch(c, opt, key, a1, b1, a2, b2, batch, out, raw, n_iters, acc_out, threads, &g, boots);
 }
 
 /* ---------------------------------------------------------------- packing */

@@ -104,7 +104,8 @@ int sgo_bootstrap_batch_opt(const sgo_ctx *ctx, const uint64_t *khat, const uint
  *   sgo_flatten_draws:  the draws [m][2] of one polynomial (accumulator cc, flatten tag y = k for the
  *                       flatten feeding k-loop iteration k, bootstrap `boot` of call `call`)
  *   sgo_bootstrap_batch_rnd: as sgo_bootstrap_batch (opt = 0) / sgo_bootstrap_batch_opt (opt = 1);
- *                       bootstrap t of the batch draws as bootstrap boot0 + t of call `call`.
+ *                       bootstrap t of the batch draws as bootstrap boot0 + t of call `call`, or as
+ *                       bootstrap boots[t] when `boots` is not NULL (rows picked out of a larger call).
  */
 void sgo_flatten_random(const sgo_ctx *ctx, const uint64_t *a, int64_t x0, int64_t x1, uint64_t *out);
 void sgo_flatten_draws(const sgo_ctx *ctx, const uint8_t *key32, unsigned cc, uint32_t y, uint32_t boot,
@@ -112,7 +113,7 @@ void sgo_flatten_draws(const sgo_ctx *ctx, const uint8_t *key32, unsigned cc, ui
 int sgo_bootstrap_batch_rnd(const sgo_ctx *ctx, int opt, const uint64_t *key, const uint64_t *a1,
                             const uint64_t *b1, const uint64_t *a2, const uint64_t *b2, size_t batch,
                             uint64_t *out, int raw, uint64_t n_iters, uint64_t *acc_out, int threads,
-                            const uint8_t *key32, uint32_t call, uint32_t boot0);
+                            const uint8_t *key32, uint32_t call, uint32_t boot0, const uint32_t *boots);
 
 /* fhe.jl:660-696 pack_encrypted_bits(bkey, nothing, enc_bits): a [n][n], b [n] over Z_r ->
  * RLWE (w, v), [m] words in [0, r) each. */

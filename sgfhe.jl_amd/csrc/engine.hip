@@ -11,6 +11,7 @@
 #include <chrono>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "kernels.h"
@@ -90,7 +91,10 @@ struct sgfhe_ctx {
     // the host.
     hipEvent_t ev_done = nullptr;
     bool pending = false;           // ev_done has been recorded and may not have completed
-    hipStream_t stream_io = nullptr;   // copies of the host-pointer entry point, beside the lanes' kernels
+    // copies of the host-pointer entry point, beside the lanes' kernels: uploads and downloads on
+    // streams of their own (on one stream the upload of the next chunks would queue behind the
+    // download of the present ones, which waits for their last kernel)
+    hipStream_t stream_io = nullptr, stream_io2 = nullptr;
     std::vector<hipEvent_t> ev_pool;   // events of the pipelined host-pointer path (created once, reused)
     // device constants
     PrimeK *d_primes = nullptr;
@@ -559,6 +563,25 @@ int32_t run_iterations(sgfhe_ctx *c, ChunkJob *jobs, int njobs, uint64_t n_iters
     return SGFHE_OK;
 }
 
+// memcpy between the caller's pageable arrays and the page-locked mirrors.  The copies of the first
+// chunk's inputs and of the last chunks' results are the part of a host-pointer call that no kernel
+// hides: above 2 MB they are cut across up to four threads (one thread moves 5-8 GB/s).
+void host_copy(void *dst, const void *src, size_t bytes) {
+    const size_t parts = bytes >= ((size_t)2 << 20) ? (bytes >= ((size_t)8 << 20) ? 4 : 2) : 1;
+    if (parts == 1) { memcpy(dst, src, bytes); return; }
+    const size_t step = ((bytes / parts) + 4095) & ~(size_t)4095;
+    std::thread th[3];
+    size_t nth = 0, off = step;
+    for (; nth < parts - 1 && off < bytes; nth++, off += step) {
+        const size_t len = bytes - off < step ? bytes - off : step;
+        char *d = static_cast<char *>(dst) + off;
+        const char *sr = static_cast<const char *>(src) + off;
+        th[nth] = std::thread([d, sr, len] { memcpy(d, sr, len); });
+    }
+    memcpy(dst, src, step < bytes ? step : bytes);
+    for (size_t i = 0; i < nth; i++) th[i].join();
+}
+
 // Host buffers of sgfhe_bootstrap_batch, moved chunk by chunk beside the lanes' kernels (stream_io):
 // a chunk's inputs go up while the chunks before it compute, its outputs come down while the chunks
 // after it compute, and the CPU copies between the caller's (pageable) arrays and the page-locked
@@ -641,8 +664,8 @@ int32_t bootstrap_device(sgfhe_ctx *c, const uint64_t *a1, const uint64_t *b1, c
             const OutJob &o = outq[out_drained];
             const hipError_t er = hipEventSynchronize(o.done);
             if (er != hipSuccess) return er;
-            memcpy(hp->out + o.c0 * hp->out_row_words, hp->p_out + o.c0 * hp->out_row_words,
-                   (size_t)o.cb * hp->out_row_words * 8);
+            host_copy(hp->out + o.c0 * hp->out_row_words, hp->p_out + o.c0 * hp->out_row_words,
+                      (size_t)o.cb * hp->out_row_words * 8);
         }
         return hipSuccess;
     };
@@ -666,8 +689,8 @@ int32_t bootstrap_device(sgfhe_ctx *c, const uint64_t *a1, const uint64_t *b1, c
             if (hp) {   // this chunk's inputs: caller's arrays -> page-locked mirror -> device, on stream_io
                 const size_t w0 = c0 * (2 * (size_t)n + 2), cb = J.cb;
                 uint64_t *pi = hp->p_in + w0, *di = hp->d_in + w0;
-                memcpy(pi, hp->a1 + c0 * n, cb * n * 8);
-                memcpy(pi + cb * n, hp->a2 + c0 * n, cb * n * 8);
+                host_copy(pi, hp->a1 + c0 * n, cb * n * 8);
+                host_copy(pi + cb * n, hp->a2 + c0 * n, cb * n * 8);
                 memcpy(pi + 2 * cb * n, hp->b1 + c0, cb * 8);
                 memcpy(pi + 2 * cb * n + cb, hp->b2 + c0, cb * 8);
                 HIPCHK(c, hipMemcpyAsync(di, pi, cb * (2 * (size_t)n + 2) * 8, hipMemcpyHostToDevice, c->stream_io));
@@ -709,16 +732,16 @@ int32_t bootstrap_device(sgfhe_ctx *c, const uint64_t *a1, const uint64_t *b1, c
                                        (size_t)3 * t3, c->rns2);
                 HIPCHK(c, hipGetLastError());
             }
-            if (hp) {   // this chunk's results: device -> page-locked mirror on stream_io, behind its last kernel
+            if (hp) {   // this chunk's results: device -> page-locked mirror on stream_io2, behind its last kernel
                 hipEvent_t ek, eo;
                 HIPCHK(c, next_event(&ek));
                 HIPCHK(c, next_event(&eo));
                 HIPCHK(c, hipEventRecord(ek, J.st));
-                HIPCHK(c, hipStreamWaitEvent(c->stream_io, ek, 0));
+                HIPCHK(c, hipStreamWaitEvent(c->stream_io2, ek, 0));
                 const size_t w0 = J.c0 * hp->out_row_words;
                 HIPCHK(c, hipMemcpyAsync(hp->p_out + w0, hp->d_out + w0, (size_t)J.cb * hp->out_row_words * 8,
-                                         hipMemcpyDeviceToHost, c->stream_io));
-                HIPCHK(c, hipEventRecord(eo, c->stream_io));
+                                         hipMemcpyDeviceToHost, c->stream_io2));
+                HIPCHK(c, hipEventRecord(eo, c->stream_io2));
                 outq.push_back({eo, J.c0, J.cb});
             }
         }
@@ -1139,7 +1162,8 @@ int32_t sgfhe_ctx_create_ex(const sgfhe_params *p, int device, uint32_t flags, s
         hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming) != hipSuccess ||
-        hipStreamCreateWithFlags(&c->stream_io, hipStreamNonBlocking) != hipSuccess)
+        hipStreamCreateWithFlags(&c->stream_io, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&c->stream_io2, hipStreamNonBlocking) != hipSuccess)
         return fail(c, SGFHE_ERR_HIP, "hipStreamCreate / hipEventCreate failed");
     return build_constants(c);
 }
@@ -1151,11 +1175,13 @@ int32_t sgfhe_ctx_destroy(sgfhe_ctx *c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->stream2) (void)hipStreamSynchronize(c->stream2);
     if (c->stream_io) (void)hipStreamSynchronize(c->stream_io);
+    if (c->stream_io2) (void)hipStreamSynchronize(c->stream_io2);
     timing_flush(c);
     free_lanes(c);
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
     if (c->ev_done) (void)hipEventDestroy(c->ev_done);
     if (c->stream_io) (void)hipStreamDestroy(c->stream_io);
+    if (c->stream_io2) (void)hipStreamDestroy(c->stream_io2);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);

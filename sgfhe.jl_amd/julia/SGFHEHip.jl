@@ -124,8 +124,10 @@ function SGFHE.bootstrap(hkey::HipBootstrapKey, rng::Union{AbstractRNG,Nothing},
     @assert length(bits2) == batch
     a1, b1 = lwe_words(bits1, n)
     a2, b2 = lwe_words(bits2, n)
-    tp = ModUInt{UInt64, UInt64(p.r)}
-    mk(x) = tp(x, _verbatim)                       # as at src/utils.jl:116
+    # the reference's own constructor form: reduce_modulus ends in
+    # `new_repr(convert.(new_base_type, x_rs), new_modulus, DarkIntegers._verbatim)` with
+    # new_repr = ModUInt, new_base_type = UInt64, new_modulus = params.r (src/utils.jl:116, src/fhe.jl:616-618)
+    mk(x::UInt64) = ModUInt(x, p.r, _verbatim)
     res = Vector{NTuple{3,EncryptedBit}}(undef, batch)
     lock(hkey.lock) do
         set_flatten_mode(hkey, rng)               # mode and call stay together under the lock
@@ -186,8 +188,7 @@ function SGFHE.pack_encrypted_bits(hkey::HipBootstrapKey, rng::Union{AbstractRNG
                    hkey.ctx, a, b, 1, w, v)
         check(hkey.ctx, rc)
     end
-    tp = ModUInt{UInt64, UInt64(p.r)}
-    mk(x) = tp(x, _verbatim)
+    mk(x::UInt64) = ModUInt(x, p.r, _verbatim)     # as at src/utils.jl:116 (reduce_modulus of src/fhe.jl:692-693)
     SGFHE.Ciphertext(p, SGFHE.RLWE(Polynomial(mk.(w), negacyclic_modulus),
                                    Polynomial(mk.(v), negacyclic_modulus)))
 end

@@ -10,7 +10,7 @@ src/rns.jl:51-60) -- the big-integer oracle would need hours for the 1 GiB key -
 the big-integer oracle where that is affordable: every key polynomial product of slices 0 and 1
 and the accumulators after the first two iterations are recomputed with Kronecker products.
 
-Usage: python tests/golden/make_golden.py [p64] [p64rnd] [extprod] [tables] [p512] [p1024] [pack64] [cfg4]
+Usage: python tests/golden/make_golden.py [p64] [p64rnd] [extprod] [tables] [p512] [p1024] [p1024rnd] [pack64] [cfg4]
 """
 
 import hashlib
@@ -113,6 +113,44 @@ def random_flatten_case():
             "sk_seed": 1, "key_seed": 2, "in_seed": 3, "key_sha256": key_hash(bk),
             "flatten_key_hex": fkey.hex(), "stream": "ChaCha8, oracle/bigint_oracle.py ChaChaFlatten",
             "call": 0, "cases": cases}
+
+
+def random_flatten_case_1024():
+    """Params(1024) with the randomised flatten (src/utils.jl:198-241) -- the reference's documented
+    call bootstrap(bkey, rng, ...) (README.md:24, docs/src/manual.md:144) at its own parameter set --
+    on the engine's ChaCha8 draw stream: key and input pair of p1024.json's case, as bootstrap 0 and
+    (the same inputs again) bootstrap 5 of call 2 of the stream, so that the counter words for the
+    bootstrap index and the call are pinned at this ring too.  Literal big-integer restatement."""
+    p = O.Params.make(1024)
+    sk = O.private_key(p, 21)
+    t0 = time.time()
+    bk = O.bootstrap_key(p, sk, 22)
+    print("  key", time.time() - t0, "s", flush=True)
+    g = O.SplitMix64(23)
+    l1 = O.lwe_encrypt_bit(p, sk, 1, g)
+    l2 = O.lwe_encrypt_bit(p, sk, 1, g)
+    fkey = bytes(range(11, 43))
+    cases = []
+    for boot, call in ((0, 0), (5, 2)):
+        cps = {}
+
+        def trace(k, a, b):
+            if (k + 1) in (1, 2, 512, 1024):
+                cps[str(k + 1)] = [h_ints(a), h_ints(b)]
+        t0 = time.time()
+        raw = O.bootstrap_internal(p, bk, l1, l2, trace=trace, rng=O.ChaChaFlatten(p, fkey, boot=boot, call=call))
+        out = [([O.reduce_modulus(p.r, x, p.Q) for x in a], O.reduce_modulus(p.r, b, p.Q)) for a, b in raw]
+        print("  bootstrap", boot, call, time.time() - t0, "s", flush=True)
+        assert [O.lwe_decrypt_bit(p, sk, o) for o in out] == [1, 1, 0]
+        cases.append({"bits": [1, 1], "boot": boot, "call": call,
+                      "lwe1": {"a": l1[0], "b": l1[1]}, "lwe2": {"a": l2[0], "b": l2[1]},
+                      "acc_sha256_after": cps, "raw_sha256": [h_ints(a + [b]) for a, b in raw],
+                      "out_sha256": [h_ints(a + [b], 8) for a, b in out],
+                      "out_head": [(a + [b])[:8] + [b] for a, b in out]})
+    return {"params": {"n": p.n, "r": p.r, "m": p.m, "Q": str(p.Q), "B": str(p.B)},
+            "sk_seed": 21, "key_seed": 22, "in_seed": 23, "key_sha256": key_hash(bk),
+            "flatten_key_hex": fkey.hex(), "stream": "ChaCha8, oracle/bigint_oracle.py ChaChaFlatten",
+            "cases": cases}
 
 
 def extprod_case():
@@ -242,7 +280,7 @@ def cfg4_case():
 
 
 def main():
-    what = sys.argv[1:] or ["p64", "p64rnd", "extprod", "tables", "p512", "p1024", "pack64", "cfg4"]
+    what = sys.argv[1:] or ["p64", "p64rnd", "extprod", "tables", "p512", "p1024", "p1024rnd", "pack64", "cfg4"]
     pairs4 = [(0, 0), (0, 1), (1, 0), (1, 1)]
     for w in what:
         print(w, flush=True)
@@ -256,6 +294,8 @@ def main():
             d = extprod_case()
         elif w == "p64rnd":
             d = random_flatten_case()
+        elif w == "p1024rnd":
+            d = random_flatten_case_1024()
         elif w == "tables":
             d = tables()
         elif w == "pack64":

@@ -105,6 +105,29 @@ def test_params64_random_flatten_golden():
         assert out == case["out"]
 
 
+def test_params1024_random_flatten_golden(oc):
+    """golden/p1024rnd.json (literal big-integer restatement of bootstrap(bkey, rng, ...) at the
+    reference's Params(1024) on the engine's ChaCha8 stream): the C restatement of utils.jl:198-241
+    reproduces the accumulator hashes after the first two iterations here, as bootstrap 0 of call 0
+    and as bootstrap 5 of call 2; the full bootstrap is compared on the GPU box
+    (tests/test_gpu_round4.py::test_sixprime_ctx_matches_big_integer_golden)."""
+    d = load("p1024rnd")
+    o = oc.Oracle.make(1024)
+    assert str(o.Q) == d["params"]["Q"]
+    sk = o.private_key(d["sk_seed"])
+    bkey = o.bootstrap_key(sk, d["key_seed"])              # the key of p1024.json (same seeds)
+    assert hashlib.sha256(np.ascontiguousarray(bkey).tobytes()).hexdigest() == load("p1024")["key_sha256"]
+    fkey = bytes.fromhex(d["flatten_key_hex"])
+    for case in d["cases"]:
+        a1, b1 = np.array([case["lwe1"]["a"]], dtype=np.uint64), [case["lwe1"]["b"]]
+        a2, b2 = np.array([case["lwe2"]["a"]], dtype=np.uint64), [case["lwe2"]["b"]]
+        for k in ("1", "2"):
+            _, acc = o.bootstrap_batch(bkey, a1, b1, a2, b2, n_iters=int(k), want_acc=True,
+                                       rnd=(fkey, case["call"], case["boot"]))
+            assert [h_ints(oc.u128_to_ints(acc[0, 0])), h_ints(oc.u128_to_ints(acc[0, 1]))] == \
+                case["acc_sha256_after"][k], (case["boot"], case["call"], k)
+
+
 def test_params512_golden(oc):
     _check_bootstrap_golden(oc, "p512", full=True)
 
@@ -172,3 +195,61 @@ def test_pack_encrypted_bits_golden(oc):
     assert BO.decrypt_ciphertext(p, skl, d["w"], d["v"]) == d["bits"]
     lwes = BO.split_ciphertext(p, d["w"], d["v"])
     assert [BO.lwe_decrypt_bit(p, skl, l) for l in lwes] == d["bits"]
+
+
+# ---- fixtures of the Julia reference itself (sgfhe.jl_amd/julia/make_fixtures.jl), when present ------
+
+def _raw_ints(oc, raw):
+    return [[oc.u128_to_ints(raw[i, g]) for g in range(3)] for i in range(raw.shape[0])]
+
+
+def _julia_case(oc, d, key):
+    import julia_fixture as JF
+    p = d["params"]
+    o = oc.Oracle(p["n"], p["r"], p["m"], int(p["Q"]), int(p["B"]), int(p["DQ_tilde"]))
+    a1, b1, a2, b2 = JF.inputs(d)
+    out = o.bootstrap_batch(key, a1, b1, a2, b2)
+    raw = o.bootstrap_batch(key, a1, b1, a2, b2, raw=True)
+    sk = np.array(d["sk"], dtype=np.uint64)
+    JF.check(d, out, _raw_ints(oc, raw),
+             lambda i, g: int(o.lwe_decrypt_bits(sk, out[i, g, :p["n"]], out[i, g, p["n"]])[0]))
+    return o
+
+
+@pytest.mark.parametrize("n", [64, 512])
+def test_julia_reference_fixture(oc, n):
+    """tests/golden/julia_p<n>.json + its key file, written by sgfhe.jl_amd/julia/make_fixtures.jl under
+    Julia with the reference installed: bootstrap(bkey, nothing, ...) and _bootstrap_internal outputs of
+    the reference itself for its own key.  With them present the C restatement (reference-shaped loop)
+    is pinned to the Julia build's bytes and DESIGN.md's "parity unpinned" can be struck.  They cannot
+    be made in the build container (no julia), so this test skips until a maintainer drops them in."""
+    import julia_fixture as JF
+    fx = JF.load(G, n)
+    if fx is None:
+        pytest.skip("golden/julia_p%d.json not present (run julia/make_fixtures.jl under Julia)" % n)
+    d, key = fx
+    assert "Julia" in d["generated_by"] or "julia" in d["generated_by"]
+    o = _julia_case(oc, d, key)
+    assert (o.n, o.Q) == (n, oc.Oracle.make(n).Q)           # the reference's Params(n)
+
+
+def test_julia_fixture_reader_on_a_self_made_file(oc, tmp_path):
+    """The reading / checking path of test_julia_reference_fixture, exercised on a file of the same
+    layout written from the oracle's own results (so a maintainer's file meets working code), and
+    shown to fail on a single flipped word."""
+    import julia_fixture as JF
+    o = oc.Oracle.make(64)
+    sk = o.private_key(9)
+    bkey = o.bootstrap_key(sk, 10)
+    bits = np.array([0, 1, 1, 1], dtype=np.uint8)
+    a, b = o.lwe_encrypt_bits(sk, bits, 11)
+    out = o.bootstrap_batch(bkey, a[0::2], b[0::2], a[1::2], b[1::2])
+    raw = o.bootstrap_batch(bkey, a[0::2], b[0::2], a[1::2], b[1::2], raw=True)
+    JF.write_like_julia(str(tmp_path), o, 64, sk, bkey, bits, a, b, out, _raw_ints(oc, raw))
+    d, key = JF.load(str(tmp_path), 64)
+    assert np.array_equal(key, bkey)
+    _julia_case(oc, d, key)
+    d["cases"][1]["out"][2][5] ^= 1
+    with pytest.raises(AssertionError):
+        _julia_case(oc, d, key)
+    assert JF.load(str(tmp_path), 512) is None

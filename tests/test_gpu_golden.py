@@ -577,3 +577,52 @@ def test_chained_gates_soak(S):
         y1, y2 = y1 & y2, y1 ^ y2
         worst = max(worst, max(abs(lwe_error(e, y)) for e, y in zip(e1 + e2, list(y1) + list(y2))))
     assert worst < params.Dr // 2
+
+
+# ---- fixtures of the Julia reference itself (sgfhe.jl_amd/julia/make_fixtures.jl), when present ------
+
+def _engine_julia_case(S, oc, d, key):
+    import julia_fixture as JF
+    p = d["params"]
+    params = S.Params.custom(p["n"], int(p["Q"]), int(p["B"]), DQ_tilde=int(p["DQ_tilde"]))
+    assert (params.r, params.m) == (p["r"], p["m"])
+    eng = S.Engine(params)
+    try:
+        eng.upload_key(key)                                     # the reference's own key, as it is
+        a1, b1, a2, b2 = JF.inputs(d)
+        out = eng.bootstrap_batch(a1, b1, a2, b2)               # the drop-in call, rng = nothing
+        raw = eng.bootstrap_batch(a1, b1, a2, b2, raw=True)
+        o = oc.Oracle.from_params(params)
+        sk = np.array(d["sk"], dtype=np.uint64)
+        JF.check(d, out, [[_u128_ints(raw[i, g]) for g in range(3)] for i in range(raw.shape[0])],
+                 lambda i, g: int(o.lwe_decrypt_bits(sk, out[i, g, :p["n"]], out[i, g, p["n"]])[0]))
+    finally:
+        eng.close()
+
+
+@pytest.mark.parametrize("n", [64, 512])
+def test_engine_matches_julia_reference_fixture(S, oc, n):
+    """The HIP engine against bootstrap(bkey, nothing, ...) / _bootstrap_internal of the Julia
+    reference itself, on the reference's own key (tests/golden/julia_p<n>.json, written by
+    julia/make_fixtures.jl under Julia).  Skips until a maintainer provides the files: Julia is not
+    available in this pipeline."""
+    import julia_fixture as JF
+    fx = JF.load(G, n)
+    if fx is None:
+        pytest.skip("golden/julia_p%d.json not present (run julia/make_fixtures.jl under Julia)" % n)
+    _engine_julia_case(S, oc, *fx)
+
+
+def test_engine_julia_fixture_path_on_a_self_made_file(S, oc, tmp_path):
+    """The same consuming code on a file of that layout written from the oracle's results."""
+    import julia_fixture as JF
+    o = oc.Oracle.make(64)
+    sk = o.private_key(9)
+    bkey = o.bootstrap_key(sk, 10)
+    bits = np.array([0, 1, 1, 1], dtype=np.uint8)
+    a, b = o.lwe_encrypt_bits(sk, bits, 11)
+    out = o.bootstrap_batch(bkey, a[0::2], b[0::2], a[1::2], b[1::2])
+    raw = o.bootstrap_batch(bkey, a[0::2], b[0::2], a[1::2], b[1::2], raw=True)
+    JF.write_like_julia(str(tmp_path), o, 64, sk, bkey, bits, a, b, out,
+                        [[oc.u128_to_ints(raw[i, g]) for g in range(3)] for i in range(2)])
+    _engine_julia_case(S, oc, *JF.load(str(tmp_path), 64))

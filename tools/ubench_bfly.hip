@@ -8,6 +8,11 @@
 //         every second stage (inverse)
 //   f64   double precision, p < 2^49: h = y w, l = fma(y, w, -h), q = rint(y w/p),
 //         t = fma(-q, p, h) + l; X + t, X - t with no reductions at all
+//   u31   (round 4) unsigned, 2^30 < p < 2^31, values in [0, 2p) -- the only lazy
+//         window a 32-bit word leaves such a prime: every sum and every difference needs its own
+//         conditional correction (10 instructions per butterfly)
+//   s30   (round 4) signed Montgomery on a 30-bit prime: the int32 window is (-2p, 2p), so the X
+//         input of every butterfly is pulled back to [0, p] in every stage (8 instructions)
 // Prints nanoseconds per butterfly per lane-slot at 4 and 8 waves per SIMD.
 // build: hipcc --offload-arch=gfx950 -O3 -o tools/ubench_bfly tools/ubench_bfly.hip
 #include <hip/hip_runtime.h>
@@ -176,6 +181,75 @@ __global__ void __launch_bounds__(256) k_s29_inv(uint32_t *out, uint32_t seed) {
     out[blockIdx.x * 256 + threadIdx.x] = r;
 }
 
+// ---- unsigned 31-bit: values in [0, 2p), p < 2^31 ----------------------------------------------------
+// t = y w R^-1 mod p in [0, 2p) for any 32-bit y and w < p (T + mq p < 2^64)
+__device__ __forceinline__ void bfly31_fwd(uint32_t &X, uint32_t &Y, uint32_t wM, const Mod &md) {
+    const uint32_t t = mont_lazy(Y, wM, md);
+    // X + t - 2p when that is not negative, else X + t:   d = X - (2p - t)
+    uint32_t d, e;
+    const bool b0 = __builtin_usub_overflow(X, md.p2 - t, &d);
+    const bool b1 = __builtin_usub_overflow(X, t, &e);
+    X = b0 ? d + md.p2 : d;
+    Y = b1 ? e + md.p2 : e;
+}
+template <int B>
+__device__ __forceinline__ void u31_fwd_stage(uint32_t (&x)[16], const uint32_t (&t)[15], const Mod &md) {
+    constexpr int NG = 1 << (3 - B);
+#pragma unroll
+    for (int g = 0; g < NG; g++)
+#pragma unroll
+        for (int l = 0; l < (1 << B); l++) {
+            const int e0 = (g << (B + 1)) | l;
+            bfly31_fwd(x[e0], x[e0 | (1 << B)], t[NG - 1 + g], md);
+        }
+}
+__global__ void __launch_bounds__(256) k_u31_fwd(uint32_t *out, uint32_t seed) {
+    const uint32_t p = 2147352577u;  // 2^31 - 2^17 + 1 (shape only)
+    uint32_t inv = p;
+    for (int i = 0; i < 5; i++) inv *= 2u - p * inv;
+    const Mod md = {p, 0u - inv, 2 * p};
+    uint32_t x[16], t[15];
+    for (int e = 0; e < 16; e++) x[e] = (threadIdx.x * 2654435761u + e * 40503u + seed) % p;
+    for (int e = 0; e < 15; e++) t[e] = (threadIdx.x * 97u + e * 7919u + seed * 3u) % p;
+    for (int it = 0; it < ITER; it++) {
+        u31_fwd_stage<3>(x, t, md); u31_fwd_stage<2>(x, t, md); u31_fwd_stage<1>(x, t, md); u31_fwd_stage<0>(x, t, md);
+    }
+    uint32_t r = 0;
+    for (int e = 0; e < 16; e++) r ^= x[e];
+    out[blockIdx.x * 256 + threadIdx.x] = r;
+}
+
+// ---- signed 30-bit: window (-2p, 2p), X reduced in every stage ----------------------------------------
+template <int B>
+__device__ __forceinline__ void s30_fwd_stage(int32_t (&x)[16], const int32_t (&t)[15], const SMod &md) {
+    constexpr int NG = 1 << (3 - B);
+#pragma unroll
+    for (int g = 0; g < NG; g++)
+#pragma unroll
+        for (int l = 0; l < (1 << B); l++) {
+            const int e0 = (g << (B + 1)) | l, e1 = e0 | (1 << B);
+            const int32_t tt = smont(x[e1], t[NG - 1 + g], md);      // |tt| < |y| / 8 + p / 2 < 0.75 p
+            const int32_t X = x[e0] - (x[e0] >> 30) * md.p;          // floor form: [0, p] up to a few delta
+            x[e0] = X + tt;
+            x[e1] = X - tt;
+        }
+}
+__global__ void __launch_bounds__(256) k_s30_fwd(uint32_t *out, uint32_t seed) {
+    const int32_t p = 1073479681;  // just below 2^30
+    uint32_t inv = (uint32_t)p;
+    for (int i = 0; i < 5; i++) inv *= 2u - (uint32_t)p * inv;
+    const SMod md = {p, -p, inv};
+    int32_t x[16], t[15];
+    for (int e = 0; e < 16; e++) x[e] = (int32_t)((threadIdx.x * 2654435761u + e * 40503u + seed) % (uint32_t)p) - p / 2;
+    for (int e = 0; e < 15; e++) t[e] = (int32_t)((threadIdx.x * 97u + e * 7919u + seed * 3u) % (uint32_t)p) - p / 2;
+    for (int it = 0; it < ITER; it++) {
+        s30_fwd_stage<3>(x, t, md); s30_fwd_stage<2>(x, t, md); s30_fwd_stage<1>(x, t, md); s30_fwd_stage<0>(x, t, md);
+    }
+    uint32_t r = 0;
+    for (int e = 0; e < 16; e++) r ^= (uint32_t)x[e];
+    out[blockIdx.x * 256 + threadIdx.x] = r;
+}
+
 // ---- fp64, 49-bit primes -------------------------------------------------------------------------
 template <int B>
 __device__ __forceinline__ void f_fwd_stage(double (&x)[16], const double (&w)[15], const double (&wp)[15],
@@ -243,13 +317,14 @@ int main() {
     for (int wps : {4, 8}) {
         const int blocks = cus * wps;  // wps x 256 threads per CU = wps waves per SIMD
         const double bflies = (double)blocks * 256 * ITER * 32;
-        struct { const char *name; double ms; } res[8];
+        struct { const char *name; double ms; } res[10];
         int n = 0;
 #define RUN(K) res[n].name = #K; res[n].ms = run(K, d, blocks); n++;
-        RUN(k_u30_fwd) RUN(k_s29_fwd) RUN(k_f64_fwd) RUN(k_u30_inv) RUN(k_s29_inv)
+        RUN(k_u30_fwd) RUN(k_s29_fwd) RUN(k_f64_fwd) RUN(k_u30_inv) RUN(k_s29_inv) RUN(k_u31_fwd) RUN(k_s30_fwd)
         for (int i = 0; i < n; i++)
-            printf("%d waves/SIMD  %-10s %8.3f ms  %7.3f T butterflies/s  rel-to-u30_fwd %.3f\n", wps,
-                   res[i].name, res[i].ms, bflies / (res[i].ms * 1e-3) * 1e-12, res[i].ms / res[0].ms);
+            printf("%d waves/SIMD  %-10s %8.3f ms  %7.3f T butterflies/s  rel-to-u30_fwd %.3f  rel-to-s29_fwd %.3f\n", wps,
+                   res[i].name, res[i].ms, bflies / (res[i].ms * 1e-3) * 1e-12, res[i].ms / res[0].ms,
+                   res[i].ms / res[1].ms);
     }
     return 0;
 }
