@@ -396,7 +396,10 @@ def main():
     # Same number of steps as the headline, after a warm-up of its own (the first call through host
     # pointers also allocates the engine's staging buffers and touches the pages of the result array),
     # bracketed by the same barriers, MAX over ranks.  sgfhe_bootstrap_batch moves the arrays chunk by
-    # chunk beside the kernels, so this leg is expected within a fraction of a percent of the headline.
+    # chunk beside the kernels.  The clock of this pool's boxes drifts by up to 1 % over the first
+    # minutes of a run (power limit and temperature), so the ratio to the device-resident rate comes
+    # from steps that ALTERNATE between the two entry points -- one synchronous device-resident step,
+    # one host-pointer step, `steps` times -- not from this leg against the headline timed earlier.
     host_io = None
     if not args.no_host_io:
         ha1, ha2 = a1.cpu().numpy().view(np.uint64), a2.cpu().numpy().view(np.uint64)
@@ -409,26 +412,35 @@ def main():
         if dist:
             dist.barrier()
         torch.cuda.synchronize()
-        t1 = time.perf_counter()
+        hdt = ddt = 0.0
         for _ in range(args.steps):
+            t1 = time.perf_counter()
+            step()
+            eng.sync()
+            t2 = time.perf_counter()
             eng.bootstrap_batch(ha1, hb1, ha2, hb2, out=hout)   # synchronous: returns with `hout` complete
+            t3 = time.perf_counter()
+            ddt += t2 - t1
+            hdt += t3 - t2
         torch.cuda.synchronize()
         if dist:
             dist.barrier()
-        hdt = time.perf_counter() - t1
         same = None if rnd else bool(np.array_equal(hout.view(np.int64), out.cpu().numpy()))
         if dist:
-            tmax = torch.tensor([hdt], dtype=torch.float64, device="cuda")
+            tmax = torch.tensor([hdt, ddt], dtype=torch.float64, device="cuda")
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-            hdt = float(tmax.item())
+            hdt, ddt = float(tmax[0].item()), float(tmax[1].item())
         host_io = {"value": world * args.steps * B / hdt, "unit": "bootstraps/sec",
                    "ms_per_step": hdt / args.steps * 1e3, "steps": args.steps,
                    "warmup": max(1, args.warmup), "first_call_ms": hdt_first * 1e3,
-                   "vs_device_resident": (world * args.steps * B / hdt) / (world * args.steps * B / dt),
+                   "device_resident_ms_per_step_alternating": ddt / args.steps * 1e3,
+                   "vs_device_resident": ddt / hdt,
                    "equals_device_resident_output": same,
                    "note": "inputs and outputs in host memory (sgfhe_bootstrap_batch, the drop-in "
                            "signature): includes H2D of 2 (n + 1) and D2H of 3 (n + 1) words per "
-                           "bootstrap, pipelined chunk by chunk beside the kernels"}
+                           "bootstrap, pipelined chunk by chunk beside the kernels; vs_device_resident "
+                           "= time of the device-resident steps / time of the host-pointer steps of one "
+                           "alternating sequence (one synchronous call each per step)"}
 
     if rank == 0:
         total = world * args.steps * B

@@ -275,14 +275,18 @@ int32_t launch_small_t(sgfhe_ctx *c, const sgfhe_ctx::Lane &L, const int32_t *ke
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         c->attr_done |= ATTR_SMALL;
     }
+    // (Round 4 measured the per-prime records passed by value in the kernel arguments instead of
+    // through this pointer -- one dependent load less at the head of each launch: 24.75 against
+    // 24.74 ms per call, no change, profiles/r04_exp_small_args.txt.)
+    PrimeSet ps = c->d_primes;
     if (mode & MODE_WIDE)
         hipLaunchKernelGGL((k_fwd_phase<LOGM, LE, true>), dim3(cpad * c->npr * 4), dim3(TH), lds, st, L.dig,
-                           keyk, L.zpart, c->d_primes, mode);
+                           keyk, L.zpart, ps, mode);
     else
         hipLaunchKernelGGL((k_fwd_phase<LOGM, LE>), dim3(cpad * c->npr * 4), dim3(TH), lds, st, L.dig,
-                           keyk, L.zpart, c->d_primes, mode);
+                           keyk, L.zpart, ps, mode);
     hipLaunchKernelGGL((k_inv_column<LOGM, LE>), dim3(cpad * c->npr * 2), dim3(TH), lds, st, L.zpart,
-                       L.yres, L.ua, c->d_primes, k, c->n);
+                       L.yres, L.ua, ps, k, c->n);
     HIPCHK(c, hipGetLastError());
     return SGFHE_OK;
 }
@@ -640,6 +644,19 @@ int32_t bootstrap_device(sgfhe_ctx *c, const uint64_t *a1, const uint64_t *b1, c
         HIPCHK(c, hipEventCreate(&ecall1));
         HIPCHK(c, hipEventRecord(ecall0, st));
     }
+    // A host-pointer call that is one group of chunks (a handful of gates up to two chunks' worth) has
+    // nothing to overlap its copies with: they go on `st` itself, in order with the kernels -- one upload
+    // before the first kernel, one download behind the last -- without the copy streams' events.
+    const size_t stride = (size_t)chunk * (two_lanes ? 2 : 1);
+    const bool hp_single = hp && batch <= stride;
+    if (hp_single) {
+        const size_t nn = n;
+        host_copy(hp->p_in, hp->a1, batch * nn * 8);
+        host_copy(hp->p_in + batch * nn, hp->a2, batch * nn * 8);
+        memcpy(hp->p_in + 2 * batch * nn, hp->b1, batch * 8);
+        memcpy(hp->p_in + 2 * batch * nn + batch, hp->b2, batch * 8);
+        HIPCHK(c, hipMemcpyAsync(hp->d_in, hp->p_in, batch * (2 * nn + 2) * 8, hipMemcpyHostToDevice, st));
+    }
     if (two_lanes) {  // fork: the second lane starts after everything already queued on st
         HIPCHK(c, hipEventRecord(c->ev_fork, st));
         HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
@@ -669,7 +686,29 @@ int32_t bootstrap_device(sgfhe_ctx *c, const uint64_t *a1, const uint64_t *b1, c
         }
         return hipSuccess;
     };
-    const size_t stride = (size_t)chunk * (two_lanes ? 2 : 1);
+    // SGFHE_DEBUG_IO=1: wall-clock phases of a pipelined host-pointer call
+    const bool dbg_io = hp && getenv("SGFHE_DEBUG_IO") != nullptr;
+    // SGFHE_IO_EXP: experiments of round 4 (tools/io_variants.py, profiles/r04_exp_io_variants.txt):
+    // 1 = results collected only at the end, 2 = all results after the last kernel, 4 = all inputs
+    // before the first kernel.  The default (0) measured best: 1.003 x the device-resident call.
+    const int io_exp = hp && getenv("SGFHE_IO_EXP") ? atoi(getenv("SGFHE_IO_EXP")) : 0;
+    auto wall = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double tw0 = dbg_io ? wall() : 0.0;
+    double tw_first = 0.0, tw_wait = 0.0;
+    hipEvent_t e_allin = nullptr;
+    if ((io_exp & 4) && !hp_single) {   // experiment: every chunk's inputs up front, one event
+        for (size_t c0 = 0; c0 < batch; c0 += chunk) {
+            const size_t cb = batch - c0 < chunk ? batch - c0 : chunk, w0 = c0 * (2 * (size_t)n + 2);
+            uint64_t *pi = hp->p_in + w0;
+            host_copy(pi, hp->a1 + c0 * n, cb * n * 8);
+            host_copy(pi + cb * n, hp->a2 + c0 * n, cb * n * 8);
+            memcpy(pi + 2 * cb * n, hp->b1 + c0, cb * 8);
+            memcpy(pi + 2 * cb * n + cb, hp->b2 + c0, cb * 8);
+        }
+        HIPCHK(c, hipMemcpyAsync(hp->d_in, hp->p_in, batch * (2 * (size_t)n + 2) * 8, hipMemcpyHostToDevice, c->stream_io));
+        HIPCHK(c, next_event(&e_allin));
+        HIPCHK(c, hipEventRecord(e_allin, c->stream_io));
+    }
     for (size_t g0 = 0; g0 < batch; g0 += stride) {
         ChunkJob jobs[2];
         int njobs = 0;
@@ -686,7 +725,15 @@ int32_t bootstrap_device(sgfhe_ctx *c, const uint64_t *a1, const uint64_t *b1, c
             J.ra = RndArgs{c->rnd_key, call, (uint32_t)c0};
             J.sampled = li == 0 && J.cpad == c->last_chunk;
             const uint64_t *ja1 = a1 + c0 * n, *jb1 = b1 + c0, *ja2 = a2 + c0 * n, *jb2 = b2 + c0;
-            if (hp) {   // this chunk's inputs: caller's arrays -> page-locked mirror -> device, on stream_io
+            if (hp_single) {   // whole-call layout [a1 | a2 | b1 | b2], uploaded above
+                ja1 = hp->d_in + c0 * n; ja2 = hp->d_in + (batch + c0) * n;
+                jb1 = hp->d_in + 2 * batch * n + c0; jb2 = jb1 + batch;
+            } else if (hp && e_allin) {
+                const size_t w0 = c0 * (2 * (size_t)n + 2), cb = J.cb;
+                uint64_t *di = hp->d_in + w0;
+                if (g0 == 0) HIPCHK(c, hipStreamWaitEvent(J.st, e_allin, 0));
+                ja1 = di; ja2 = di + cb * n; jb1 = di + 2 * cb * n; jb2 = jb1 + cb;
+            } else if (hp) {   // this chunk's inputs: caller's arrays -> page-locked mirror -> device, on stream_io
                 const size_t w0 = c0 * (2 * (size_t)n + 2), cb = J.cb;
                 uint64_t *pi = hp->p_in + w0, *di = hp->d_in + w0;
                 host_copy(pi, hp->a1 + c0 * n, cb * n * 8);
@@ -705,6 +752,7 @@ int32_t bootstrap_device(sgfhe_ctx *c, const uint64_t *a1, const uint64_t *b1, c
                                J.L->dig, J.L->ua, c->d_crt, J.cb, J.cpad, n, (uint32_t)c->logm, mode, J.ra);
             HIPCHK(c, hipGetLastError());
         }
+        if (dbg_io && g0 == 0) tw_first = wall();
         int32_t rc = run_iterations(c, jobs, njobs, n_iters, mode);
         if (rc) return rc;
         for (int j = 0; j < njobs; j++) {
@@ -732,7 +780,11 @@ int32_t bootstrap_device(sgfhe_ctx *c, const uint64_t *a1, const uint64_t *b1, c
                                        (size_t)3 * t3, c->rns2);
                 HIPCHK(c, hipGetLastError());
             }
-            if (hp) {   // this chunk's results: device -> page-locked mirror on stream_io2, behind its last kernel
+            if (hp_single) {
+                // one download behind the join, below
+            } else if (hp && (io_exp & 2)) {
+                outq.push_back({nullptr, J.c0, J.cb});
+            } else if (hp) {   // this chunk's results: device -> page-locked mirror on stream_io2, behind its last kernel
                 hipEvent_t ek, eo;
                 HIPCHK(c, next_event(&ek));
                 HIPCHK(c, next_event(&eo));
@@ -746,7 +798,11 @@ int32_t bootstrap_device(sgfhe_ctx *c, const uint64_t *a1, const uint64_t *b1, c
             }
         }
         // with this group queued, collect the results of the group before it
-        if (hp) HIPCHK(c, drain_out(out_before));
+        if (hp && !(io_exp & 3)) {
+            const double t = dbg_io ? wall() : 0.0;
+            HIPCHK(c, drain_out(out_before));
+            if (dbg_io) tw_wait += wall() - t;
+        }
     }
     if (two_lanes) {  // join
         HIPCHK(c, hipEventRecord(c->ev_join, c->stream2));
@@ -760,7 +816,33 @@ int32_t bootstrap_device(sgfhe_ctx *c, const uint64_t *a1, const uint64_t *b1, c
         int32_t rc = fence_end(c, st);
         if (rc) return rc;
     }
-    if (hp) HIPCHK(c, drain_out(outq.size()));
+    if (hp_single) {
+        HIPCHK(c, hipMemcpyAsync(hp->p_out, hp->d_out, batch * hp->out_row_words * 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipStreamSynchronize(st));
+        c->pending = false;
+        host_copy(hp->out, hp->p_out, batch * hp->out_row_words * 8);
+        return SGFHE_OK;
+    }
+    if (hp && (io_exp & 2)) {   // experiment: all results after the last kernel
+        HIPCHK(c, hipMemcpyAsync(hp->p_out, hp->d_out, batch * hp->out_row_words * 8, hipMemcpyDeviceToHost, st));
+        hipEvent_t eo;
+        HIPCHK(c, next_event(&eo));
+        HIPCHK(c, hipEventRecord(eo, st));
+        for (auto &o : outq) o.done = eo;
+    }
+    if (hp) {
+        const double t1 = dbg_io ? wall() : 0.0;
+        double t2 = 0.0;
+        if (dbg_io && !outq.empty()) {   // the last chunks' kernels are done when their download may start
+            (void)hipEventSynchronize(c->ev_done);
+            t2 = wall();
+        }
+        HIPCHK(c, drain_out(outq.size()));
+        if (dbg_io)
+            fprintf(stderr, "[sgfhe io] pipelined call of %zu: first chunks staged and queued after %.2f ms, all queued after "
+                    "%.2f ms (of which %.2f waiting for earlier results), last kernel done at %.2f, results in the "
+                    "caller's array at %.2f\n", batch, tw_first - tw0, t1 - tw0, tw_wait, t2 - tw0, wall() - tw0);
+    }
     return SGFHE_OK;
 }
 

@@ -490,21 +490,30 @@ k_extprod(const uint64_t *__restrict__ dig, const int32_t *__restrict__ keyk,
     }
     const uint32_t j = ua[(size_t)b * n + k];
     const uint32_t yoff = 3u * (uint32_t)P.p + P.hoff;
-    lds_store<LOGM, 2, LE, G::STOP>(z, lds, tid);
+#ifdef SGFHE_EPI_PLAIN   // (A/B build, round 4: not adopted -- see below)
+    // Both product polynomials go to LDS in the plain layout (word i of polynomial c at c m + i): lane
+    // t writes word t + T e and reads word (t - j + T e) mod m, consecutive lanes consecutive words
+    // either way, so neither access has a bank conflict whatever j is.  (Round 3 kept the transform's
+    // swizzled layout here; its j-shifted reads then collide where the run of 64 source indices
+    // crosses a swizzle boundary: 2.6 % of the kernel's LDS cycles, profiles/r03_v10_counters.json.)
+    // The buffer is the one the transform's last loads came from: every wave has to be done with them.
     SGFHE_SYNC();
-    // Source index of output coefficient i = tid + T e is s_e = (i - j) mod 2m = s_0 + T e:
-    // the swizzled low part is computed once per thread.
     {
-        constexpr uint32_t LOWMASK = (1u << G::STOP) - 1u;
+        int32_t *const ldsi = reinterpret_cast<int32_t *>(lds);
+#pragma unroll
+        for (int c = 0; c < 2; c++)
+#pragma unroll
+            for (int e = 0; e < E; e++) ldsi[c * M + T * e + tid] = z[c][e];
+    }
+    SGFHE_SYNC();
+    {
         const uint32_t s0 = ((uint32_t)tid - j) & (2 * M - 1);
-        const uint32_t lowswz = swz<LE>(s0 & LOWMASK);
+        const uint32_t low = s0 & ((1u << G::STOP) - 1u);
         const uint32_t h0 = s0 >> G::STOP;
 #pragma unroll
         for (int e = 0; e < E; e++) {
             const uint32_t he = h0 + e;
-            const uint32_t hipart = (he & (E - 1)) << G::STOP;
-            // swz is XOR-linear; for m = 8192 the e bits lie above every bit it reads
-            const uint32_t addr = hipart ^ lowswz ^ (G::STOP >= 9 ? 0u : swz_bits<LE>(hipart));
+            const uint32_t addr = ((he & (E - 1)) << G::STOP) | low;
             // x^m = -1: the source is negated when bit LE of he is set.  -v = (v ^ -1) + 1, so
             // with smask = 0 / -1 the output is (v ^ smask) + (yoff - smask - z): one subtract and
             // one xor-add per residue, the per-e constants shared by both columns.
@@ -522,6 +531,40 @@ k_extprod(const uint64_t *__restrict__ dig, const int32_t *__restrict__ keyk,
             }
         }
     }
+#else
+    // The transform's swizzled layout is kept for this exchange.  Its j-shifted reads collide where
+    // the run of 64 source indices crosses a swizzle boundary (2.6 % of the kernel's LDS cycles,
+    // profiles/r03_v10_counters.json); the plain layout above has no conflict for any j but needs
+    // one more workgroup barrier, and measured the same at m = 8192 (2108 against 2110 bootstraps/s,
+    // same call) and 2.3-2.4 % slower at m = 4096 and 16384 (profiles/r04_exp_epilogue.txt): LDS
+    // bandwidth is not what this kernel waits for.
+    lds_store<LOGM, 2, LE, G::STOP>(z, lds, tid);
+    SGFHE_SYNC();
+    // Source index of output coefficient i = tid + T e is s_e = (i - j) mod 2m = s_0 + T e:
+    // the swizzled low part is computed once per thread.
+    {
+        constexpr uint32_t LOWMASK = (1u << G::STOP) - 1u;
+        const uint32_t s0 = ((uint32_t)tid - j) & (2 * M - 1);
+        const uint32_t lowswz = swz<LE>(s0 & LOWMASK);
+        const uint32_t h0 = s0 >> G::STOP;
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+            const uint32_t he = h0 + e;
+            const uint32_t hipart = (he & (E - 1)) << G::STOP;
+            // swz is XOR-linear; for m = 8192 the e bits lie above every bit it reads
+            const uint32_t addr = hipart ^ lowswz ^ (G::STOP >= 9 ? 0u : swz_bits<LE>(hipart));
+            const uint32_t smask = 0u - ((he >> LE) & 1u);
+            const uint32_t yoe = yoff - smask;
+#pragma unroll
+            for (int c = 0; c < 2; c++) {
+                const uint32_t v = lds[c * M + addr];
+                const uint32_t y = (v ^ smask) + (yoe - (uint32_t)z[c][e]);
+                buf_st_u32(ryres, vout + ((uint32_t)(4 * T * e) & 4095u),
+                              (c ? sy1 : sy0) + ((uint32_t)(4 * T * e) & ~4095u), y);
+            }
+        }
+    }
+#endif
 }
 
 // ---- k_crt_acc --------------------------------------------------------------------------------

@@ -68,26 +68,24 @@ def test_bench_line_contract():
     assert h["value"] > 0 and h["equals_device_resident_output"] is True
     assert h["steps"] == d["steps"] and h["warmup"] >= 1
     assert abs(h["value"] - 256 / (h["ms_per_step"] * 1e-3)) < 1e-6 * h["value"]
-    assert abs(h["vs_device_resident"] - h["value"] / d["value"]) < 1e-9
+    assert abs(h["vs_device_resident"] - h["device_resident_ms_per_step_alternating"] / h["ms_per_step"]) < 1e-9
 
 
 def test_host_buffers_run_at_the_device_resident_rate():
-    """with the copies pipelined chunk by chunk beside the kernels, a batch of
-    4096 through host pointers (sgfhe_bootstrap_batch, H2D and D2H inside the timed region) runs
-    within one percent of the device-resident headline at Params(512), four steps each, same
-    process, same box.  What stays exposed is the first chunks' input and the last chunks' output,
-    a few milliseconds per call whatever the ring: 0.45 s per step here, 1.9 s at Params(1024), where
-    the committed bench lines (profiles/r04_bench_params1024.json, host_io.vs_device_resident) show
-    the two rates within 0.2 %."""
+    """with the copies pipelined chunk by chunk beside the kernels, the headline
+    workload (Params(1024), batch 4096) through host pointers -- sgfhe_bootstrap_batch, H2D and D2H
+    inside the timed region -- runs within 0.7 % of the device-resident entry point, steps of the two
+    alternating in one process so that clock drift falls on both (measured 0.2-0.4 % on three boxes,
+    profiles/r04_exp_io_variants.txt: the first chunks' upload and the last chunks' download and copy,
+    2-3 ms of a 1.9 s call, stay exposed).  Round 3 copied whole buffers around the k-loop: 1.0 %."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "params512",
-                        "--batch", "4096", "--steps", "4", "--warmup", "1", "--no-cpu-baseline",
-                        "--no-isolated"], env=env, capture_output=True, text=True, timeout=900)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1",
+                        "--no-cpu-baseline", "--no-isolated"], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     h = d["host_io"]
-    assert h["equals_device_resident_output"] is True and h["steps"] == 4
-    assert h["vs_device_resident"] > 0.99, (h["value"], d["value"])
+    assert h["equals_device_resident_output"] is True and h["steps"] == 3
+    assert h["vs_device_resident"] > 0.993, (h["ms_per_step"], h["device_resident_ms_per_step_alternating"])
 
 
 def test_bench_flags():
