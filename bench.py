@@ -284,8 +284,8 @@ def main():
                     help="cap on the cpu_baseline threads (0 = every core this process may use; "
                          "the leg on an eighth of them is reported beside it)")
     ap.add_argument("--flatten", choices=["deterministic", "random"], default="deterministic",
-                    help="random: the rng::AbstractRNG branch (src/utils.jl:198-241) on a ctx created "
-                         "with SGFHE_CTX_RANDOM_FLATTEN (six primes at Params(1024)); not the headline")
+                    help="random: the rng::AbstractRNG branch (src/utils.jl:198-241; at Params(1024) "
+                         "the ctx's six-prime basis); not the headline")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher rehearsal without a GPU: the ranks rendezvous over gloo, take the "
                          "MAX of a dummy timing and rank 0 prints a stub line (tests/)")
@@ -325,7 +325,10 @@ def main():
     W = W_BYTES[args.config]
     B = args.batch or (8192 if world == 8 else 4096)
     rnd = args.flatten == "random"
-    eng = S.Engine(p, device=local_rank, random_flatten=rnd)
+    # the headline (deterministic flatten) on a ctx with the one basis it needs: the key blob that the
+    # ranks exchange is then the five-prime form (1.34 GB at Params(1024)); `--flatten random` takes a
+    # default ctx (a basis per mode where the randomised one needs a prime more)
+    eng = S.Engine(p, device=local_rank, deterministic_only=not rnd)
     if rnd:
         eng.set_random_flatten(True, 0x5EED + rank)
     if args.lanes:

@@ -88,13 +88,21 @@ const char *sgfhe_build_id(void);
  * Replaces: the type-level set-up Julia does when `Params(n)` fixes MgModUInt{LargeType, Q}
  * (src/fhe.jl:71-85,102-104) -- here: RNS primes, twiddle tables, CRT and flatten constants. */
 int32_t sgfhe_ctx_create(const sgfhe_params *p, int device, sgfhe_ctx **out);
-/* The same with creation flags.  SGFHE_CTX_RANDOM_FLATTEN sizes the RNS basis for the randomised
- * flatten (`rng::AbstractRNG` of bootstrap / pack_encrypted_bits, src/utils.jl:198-241), whose
- * digits are four times larger: Params(1024) then runs on six 29-bit primes instead of five
- * (about 20 % more work per bootstrap); the other Params(n) have the head-room anyway.  Without
- * the flag sgfhe_set_random_flatten(enable = 1) fails with SGFHE_ERR_UNSUPPORTED on a ctx whose
- * primes do not cover it. */
+/* The same with creation flags.
+ * Both flatten modes of the reference (`rng = nothing` and `rng::AbstractRNG` of bootstrap /
+ * pack_encrypted_bits, src/utils.jl:155-189 and :198-241) are available on every ctx.  The digits
+ * of the randomised one are four times larger, and at Params(1024) that takes a sixth 29-bit RNS
+ * prime: such a ctx keeps a basis per mode (ABI revision 6) -- the key in both forms (1.34 + 1.61 GB
+ * at Params(1024); the five-prime form is derived from the six-prime one on the device), constants
+ * for both -- so the deterministic mode runs on five primes whatever the ctx may be asked later, and
+ * sgfhe_set_random_flatten switches.  The other Params(n) need one basis for both.
+ *   SGFHE_CTX_DETERMINISTIC_ONLY  the smaller basis only (no second key form): on such a ctx
+ *       sgfhe_set_random_flatten(enable = 1) fails with SGFHE_ERR_UNSUPPORTED where the randomised
+ *       mode would need the extra prime.  Its key blob is the smaller basis's.
+ *   SGFHE_CTX_RANDOM_FLATTEN      accepted and without effect (up to ABI revision 5 it asked for the
+ *       larger basis, which then also served the deterministic mode, about 20 % slower). */
 #define SGFHE_CTX_RANDOM_FLATTEN 1u
+#define SGFHE_CTX_DETERMINISTIC_ONLY 2u
 int32_t sgfhe_ctx_create_ex(const sgfhe_params *p, int device, uint32_t flags, sgfhe_ctx **out);
 int32_t sgfhe_ctx_destroy(sgfhe_ctx *ctx);
 const char *sgfhe_last_error_string(const sgfhe_ctx *ctx);
@@ -127,8 +135,9 @@ int32_t sgfhe_set_lanes(sgfhe_ctx *ctx, uint32_t lanes);
  * and oracle/bigint_oracle.py reproduces them bit for bit.  They decrypt like the reference's
  * but are not bit-comparable with it (the stream of the caller's Julia rng cannot be reproduced:
  * a host draws the 32 key bytes from that rng instead, julia/SGFHEHip.jl).  Applies to later
- * bootstrap / pack calls; needs a ctx whose RNS primes cover it (SGFHE_CTX_RANDOM_FLATTEN), else
- * SGFHE_ERR_UNSUPPORTED.  Every Params(n) the reference can build is covered, n = 64 ... 2048
+ * bootstrap / pack calls, on every ctx not created with SGFHE_CTX_DETERMINISTIC_ONLY (see
+ * sgfhe_ctx_create_ex; a ctx with a basis per mode switches to the other one, queued work is not
+ * affected).  Every Params(n) the reference can build is covered, n = 64 ... 2048
  * (B up to 2^47: above 2^46 the stored digits take a third plane of the digit record).
  * sgfhe_set_random_flatten_key takes the full 32-byte key (the reference draws every v_i from the
  * caller's rng, src/utils.jl:229: with a key from a cryptographic source the perturbations are

@@ -7,7 +7,7 @@ libsgfhe_hip.so (hand-written HIP for gfx950; include/sgfhe_hip.h).  Import as
 """
 
 from ._lib import build, lib, LIB_PATH, EXPORTED_SYMBOLS, ABI_VERSION, source_hash, embedded_build_id
-from .engine import Engine, SgfheError, FLAG_RAW_MODQ, CTX_RANDOM_FLATTEN
+from .engine import Engine, SgfheError, FLAG_RAW_MODQ, CTX_RANDOM_FLATTEN, CTX_DETERMINISTIC_ONLY
 from .params import Params, find_modulus, isprime
 from . import distributed
 from . import host
@@ -17,7 +17,7 @@ from .scheme import (PrivateKey, PublicKey, PublicEncryptedCiphertext, Bootstrap
                      PrivateEncryptedCiphertext, packbits, unpackbits, prng_expand)
 
 __all__ = ["distributed", "host", "build", "lib", "LIB_PATH", "EXPORTED_SYMBOLS", "ABI_VERSION", "source_hash", "embedded_build_id", "Engine", "SgfheError",
-           "FLAG_RAW_MODQ", "CTX_RANDOM_FLATTEN", "Params", "find_modulus", "isprime", "PrivateKey", "BootstrapKey",
+           "FLAG_RAW_MODQ", "CTX_RANDOM_FLATTEN", "CTX_DETERMINISTIC_ONLY", "Params", "find_modulus", "isprime", "PrivateKey", "BootstrapKey",
            "PublicKey", "PublicEncryptedCiphertext",
            "LWE", "RLWE", "EncryptedBit", "PackedCiphertext", "encrypt", "extract",
            "split_ciphertext", "decrypt", "bootstrap", "bootstrap_batch", "Ciphertext",

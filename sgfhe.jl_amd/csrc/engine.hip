@@ -74,6 +74,31 @@ struct sgfhe_ctx {
     int logm = 0;
     uint32_t M = 0, n = 0;
     u128 Q = 0, B = 0;
+    // ---- RNS bases ------------------------------------------------------------------------------
+    // A ctx has one basis of word-size primes, or two: the deterministic flatten needs 5 m B Q below
+    // the product of the primes, the randomised one 20 m B Q, and where that takes one prime more
+    // (Params(1024): five against six) the ctx keeps a basis for each mode -- the key in both forms
+    // (the form of the smaller basis is the larger one's times a constant per prime, derived on the
+    // device), constants for both -- so that `bootstrap(bkey, rng, ...)` works on every ctx and the
+    // deterministic mode never pays for the extra prime.  The fields below (npr ... pack_G_rnd,
+    // d_key) are the ACTIVE basis: a copy of basis[active], switched by sgfhe_set_random_flatten
+    // (activate()); everything that launches kernels reads them.
+    struct Basis {
+        uint32_t npr = 0;
+        uint32_t primes[NPR_MAX] = {};
+        PrimeK *d_primes = nullptr;
+        CrtConst *d_crt = nullptr;
+        CrtConst h_crt;
+        CrtLean *d_lean = nullptr;
+        CrtLean h_lean;
+        bool lean_rnd_ok = false;
+        uint32_t pack_G = 1, pack_G_rnd = 0;
+        int32_t *d_key = nullptr;
+        size_t key_bytes = 0;
+    } basis[2];
+    int nb = 1, active = 0;       // bases in use (basis[0]: deterministic mode, basis[nb - 1]: randomised), active one
+    uint32_t npr_max = 0;         // primes of the larger basis: work buffers are sized for it
+    uint32_t tw_done = 0;         // primes whose twiddle tables are on the device
     uint32_t primes[NPR_MAX];
     uint32_t npr = 0;  // RNS primes in use: the fewest whose product covers the exactness bound
     std::string err;
@@ -214,6 +239,42 @@ int32_t drain(sgfhe_ctx *c) {
     }
     return SGFHE_OK;
 }
+
+// basis[b] -> the active fields
+void activate(sgfhe_ctx *c, int b) {
+    const sgfhe_ctx::Basis &S = c->basis[b];
+    c->active = b;
+    c->npr = S.npr;
+    memcpy(c->primes, S.primes, sizeof c->primes);
+    c->d_primes = S.d_primes;
+    c->d_crt = S.d_crt;
+    c->h_crt = S.h_crt;
+    c->d_lean = S.d_lean;
+    c->h_lean = S.h_lean;
+    c->lean_rnd_ok = S.lean_rnd_ok;
+    c->pack_G = S.pack_G;
+    c->pack_G_rnd = S.pack_G_rnd;
+    c->d_key = S.d_key;
+    c->key_bytes = S.key_bytes;
+}
+// the active fields (as build_basis / key_alloc leave them) -> basis[b]
+void save_basis(sgfhe_ctx *c, int b) {
+    sgfhe_ctx::Basis &S = c->basis[b];
+    S.npr = c->npr;
+    memcpy(S.primes, c->primes, sizeof S.primes);
+    S.d_primes = c->d_primes;
+    S.d_crt = c->d_crt;
+    S.h_crt = c->h_crt;
+    S.d_lean = c->d_lean;
+    S.h_lean = c->h_lean;
+    S.lean_rnd_ok = c->lean_rnd_ok;
+    S.pack_G = c->pack_G;
+    S.pack_G_rnd = c->pack_G_rnd;
+    S.d_key = c->d_key;
+    S.key_bytes = c->key_bytes;
+}
+// the basis of the present flatten mode
+int mode_basis(const sgfhe_ctx *c) { return c->rnd ? c->nb - 1 : 0; }
 
 size_t lds_bytes(int logm, int npoly) { return (size_t)npoly * ((size_t)4 << logm); }
 // points per thread of k_extprod: 16, or 8 where 16 would leave half a wavefront idle (m <= 512)
@@ -487,10 +548,10 @@ int32_t ensure_work(sgfhe_ctx *c, uint32_t cpad) {
     free_lanes(c);
     for (auto &L : c->lane) {
         HIPCHK(c, hipMalloc(&L.dig, (size_t)cpad * 4 * c->M * sizeof(uint64_t)));
-        HIPCHK(c, hipMalloc(&L.yres, (size_t)cpad * 2 * c->npr * c->M * 4));
+        HIPCHK(c, hipMalloc(&L.yres, (size_t)cpad * 2 * c->npr_max * c->M * 4));
         HIPCHK(c, hipMalloc(&L.ua, (size_t)cpad * c->n * 4));
         const uint32_t cs = cpad < c->small_max ? cpad : c->small_max;
-        if (cs) HIPCHK(c, hipMalloc(&L.zpart, (size_t)cs * c->npr * 8 * c->M * 4));
+        if (cs) HIPCHK(c, hipMalloc(&L.zpart, (size_t)cs * c->npr_max * 8 * c->M * 4));
     }
     c->cap = cpad;
     return SGFHE_OK;
@@ -848,41 +909,13 @@ int32_t bootstrap_device(sgfhe_ctx *c, const uint64_t *a1, const uint64_t *b1, c
 
 // ---- constants -------------------------------------------------------------------------------------
 
-int32_t build_constants(sgfhe_ctx *c) {
+// One basis: everything that depends on which primes are in use -- CRT / flatten constants, the
+// per-prime records, the twiddle tables of primes not yet on the device.  Leaves the result in the
+// ctx's active fields (the caller saves them into basis[b]).
+int32_t build_basis(sgfhe_ctx *c, uint32_t npr, const uint32_t *cand_primes, double log_have, double log_mbq) {
     const uint32_t M = c->M;
     const int logm = c->logm;
     const u128 Q = c->Q, B = c->B;
-
-    // RNS primes: the largest primes below 2^29 with p = 1 mod 2^15 (2 m | p - 1 for every
-    // supported m), as many as the exactness bound needs.  The exact integer the CRT has to
-    // recover is D = (x^j - 1) sum_row u_row (*) C_row with |u| <= B / 2 (deterministic flatten,
-    // utils.jl:155-189) and the key lifted to |C| <= Q / 2, so |D| <= 2 m B Q; k_crt_acc needs
-    // |D| <= 0.4 M_rns, i.e. 5 m B Q <= M_rns.  The randomised flatten (|u| <= 2 B,
-    // utils.jl:198-241) needs a factor 4 more: it is available when that fits the same number of
-    // primes, or when the ctx was created with SGFHE_CTX_RANDOM_FLATTEN (then one more prime is
-    // taken where necessary: Params(1024) runs on 5 primes deterministic-only, on 6 with the flag).
-    uint32_t cand_primes[NPR_MAX];
-    {
-        int found = 0;
-        for (uint64_t kk = ((1ull << 29) - 1) >> 15; kk > 0 && found < NPR_MAX; kk--) {
-            uint32_t cand = (uint32_t)((kk << 15) + 1);
-            if (cand < (1u << 29) && is_prime32(cand)) cand_primes[found++] = cand;
-        }
-        if (found < NPR_MAX) return fail(c, SGFHE_ERR_UNSUPPORTED, "could not find RNS primes");
-    }
-    const double log_mbq = logm + u128_log2(B) + u128_log2(Q);
-    const double log_need = log2(5.0) + log_mbq + 0.001;
-    const bool want_rnd = (c->create_flags & SGFHE_CTX_RANDOM_FLATTEN) != 0;
-    const double log_target = log_need + (want_rnd ? 2.0 : 0.0);
-    double log_have = 0;
-    uint32_t npr = 0;
-    while (npr < NPR_MAX && (npr < 2 || log_have < log_target)) {
-        log_have += log2((double)cand_primes[npr]);
-        npr++;
-    }
-    if (log_have < log_target)
-        return fail(c, SGFHE_ERR_UNSUPPORTED,
-                    "5 m B Q (20 m B Q with SGFHE_CTX_RANDOM_FLATTEN) exceeds the product of the RNS primes");
     c->npr = npr;
     for (uint32_t i = 0; i < npr; i++) c->primes[i] = cand_primes[i];
     const int NPR = (int)npr;  // the loops below run over the primes in use
@@ -919,13 +952,6 @@ int32_t build_constants(sgfhe_ctx *c) {
         const u128 stot = s + xmax;
         cc.xmax = (uint64_t)xmax;
         cc.offneg_rnd = (Q - (((1 + B) % Q) * (stot % Q)) % Q) % Q;
-        // |u| <= 2 B in that mode: the exactness bound needs 4 x more head-room.  Its reductions
-        // (random_digits, acc_from_digits, crt_reduce) divide values up to about 4 B^2 by Q with a
-        // double-precision quotient estimate, exact while the quotient stays below 2^50.
-        // (stored digits reach 4 B: above 2^48 they take the third plane of the digit record,
-        // MODE_WIDE; B < 2^47 is checked at ctx creation)
-        c->rnd_ok = (log_need + 2.0 <= log_have) &&
-                    (2.0 * u128_log2(B) + 2.0 - u128_log2(Q) < 50.0);
     }
     cc.DQ = ld128(c->par.DQ_tilde) % Q;
     cc.halfQ = Q / 2;
@@ -1013,10 +1039,6 @@ int32_t build_constants(sgfhe_ctx *c) {
             // parameter sets have three limbs and B ~ sqrt(Q); others fall back to k_crt_acc.
             c->lean_rnd_ok = (NL >= 3 || ((7 * B) >> 32) == 0 || K.B1 == 0) && B * B <= (Q << 27);
         }
-        const char *env = getenv("SGFHE_CRT_LEAN");
-        c->use_lean = !(env && env[0] == '0');
-        env = getenv("SGFHE_HOST_PIN");
-        c->use_pin = !(env && env[0] == '0');
     }
 
     // twiddle tables and per-prime constants (all residues centred: |.| <= (p - 1) / 2)
@@ -1025,9 +1047,9 @@ int32_t build_constants(sgfhe_ctx *c) {
     std::vector<int32_t> tw((size_t)NPR * 4 * M);
     std::vector<PrimeK> pk(NPR);
     cc.npr = npr;
-    HIPCHK(c, hipMalloc(&c->d_tw, tw.size() * sizeof(int32_t)));
     for (int i = 0; i < NPR; i++) {
         const uint32_t p = c->primes[i];
+        if ((uint32_t)i >= c->tw_done) {   // (a second, smaller basis shares the tables of the first)
         uint32_t psi = 0;
         for (uint32_t x = 2; x < 2000 && !psi; x++) {
             uint32_t g = powmod32(x, (p - 1) / (2 * M), p);
@@ -1054,6 +1076,7 @@ int32_t build_constants(sgfhe_ctx *c) {
             const uint32_t b = mulmod32(mulmod32(pv[j >> 1], pv[j], p), R1m, p);
             fp[j] = centre32((j & 1) ? (p - a) % p : a, p);
             vp[j] = centre32((j & 1) ? (p - b) % p : b, p);
+        }
         }
         PrimeK &P = pk[i];
         memset(&P, 0, sizeof P);
@@ -1087,16 +1110,118 @@ int32_t build_constants(sgfhe_ctx *c) {
         P.twi = c->d_tw + (size_t)(4 * i + 1) * M;
         P.npr = npr;
     }
-    HIPCHK(c, hipMemcpy(c->d_tw, tw.data(), tw.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    if (c->tw_done < npr) {
+        const size_t off = (size_t)c->tw_done * 4 * M;
+        HIPCHK(c, hipMemcpy(c->d_tw + off, tw.data() + off, ((size_t)npr * 4 * M - off) * sizeof(int32_t),
+                            hipMemcpyHostToDevice));
+        c->tw_done = npr;
+    }
     HIPCHK(c, hipMalloc(&c->d_primes, NPR * sizeof(PrimeK)));
     HIPCHK(c, hipMemcpy(c->d_primes, pk.data(), NPR * sizeof(PrimeK), hipMemcpyHostToDevice));
-    HIPCHK(c, hipMalloc(&c->d_bad, sizeof(uint32_t)));
-    HIPCHK(c, hipMemset(c->d_bad, 0, sizeof(uint32_t)));
     HIPCHK(c, hipMalloc(&c->d_crt, sizeof(CrtConst)));
     HIPCHK(c, hipMemcpy(c->d_crt, &cc, sizeof(CrtConst), hipMemcpyHostToDevice));
     HIPCHK(c, hipMalloc(&c->d_lean, sizeof(CrtLean)));
     HIPCHK(c, hipMemcpy(c->d_lean, &c->h_lean, sizeof(CrtLean), hipMemcpyHostToDevice));
     return SGFHE_OK;
+}
+
+int32_t build_constants(sgfhe_ctx *c) {
+    const int logm = c->logm;
+    const u128 Q = c->Q, B = c->B;
+
+    // RNS primes: the largest primes below 2^29 with p = 1 mod 2^15 (2 m | p - 1 for every
+    // supported m), as many as the exactness bound needs.  The exact integer the CRT has to
+    // recover is D = (x^j - 1) sum_row u_row (*) C_row with |u| <= B / 2 (deterministic flatten,
+    // utils.jl:155-189) and the key lifted to |C| <= Q / 2, so |D| <= 2 m B Q; k_crt_acc needs
+    // |D| <= 0.4 M_rns, i.e. 5 m B Q <= M_rns.  The randomised flatten (|u| <= 2 B,
+    // utils.jl:198-241) needs a factor 4 more.  Where that takes one more prime (Params(1024): six
+    // against five) the ctx gets a basis per mode (sgfhe_ctx::Basis), unless it was created with
+    // SGFHE_CTX_DETERMINISTIC_ONLY.
+    uint32_t cand_primes[NPR_MAX];
+    {
+        int found = 0;
+        for (uint64_t kk = ((1ull << 29) - 1) >> 15; kk > 0 && found < NPR_MAX; kk--) {
+            uint32_t cand = (uint32_t)((kk << 15) + 1);
+            if (cand < (1u << 29) && is_prime32(cand)) cand_primes[found++] = cand;
+        }
+        if (found < NPR_MAX) return fail(c, SGFHE_ERR_UNSUPPORTED, "could not find RNS primes");
+    }
+    const double log_mbq = logm + u128_log2(B) + u128_log2(Q);
+    const double log_need = log2(5.0) + log_mbq + 0.001;
+    auto fewest = [&](double target, double *have) {
+        uint32_t npr = 0;
+        double lh = 0;
+        while (npr < NPR_MAX && (npr < 2 || lh < target)) lh += log2((double)cand_primes[npr++]);
+        *have = lh;
+        return lh >= target ? npr : 0u;
+    };
+    double have_det = 0, have_rnd = 0;
+    const uint32_t npr_det = fewest(log_need, &have_det);
+    if (!npr_det)
+        return fail(c, SGFHE_ERR_UNSUPPORTED, "5 m B Q exceeds the product of the RNS primes");
+    // |u| <= 2 B in the randomised mode: the exactness bound needs 4 x more head-room.  Its reductions
+    // (random_digits, acc_from_digits, crt_reduce) divide values up to about 4 B^2 by Q with a
+    // double-precision quotient estimate, exact while the quotient stays below 2^50.
+    // (stored digits reach 4 B: above 2^48 they take the third plane of the digit record,
+    // MODE_WIDE; B < 2^47 is checked at ctx creation)
+    const bool rnd_width_ok = 2.0 * u128_log2(B) + 2.0 - u128_log2(Q) < 50.0;
+    const uint32_t npr_rnd = fewest(log_need + 2.0, &have_rnd);
+    const bool det_only = (c->create_flags & SGFHE_CTX_DETERMINISTIC_ONLY) != 0;
+    c->nb = (!det_only && rnd_width_ok && npr_rnd > npr_det) ? 2 : 1;
+    c->rnd_ok = rnd_width_ok && npr_rnd != 0 && (c->nb == 2 || npr_rnd == npr_det);
+    c->npr_max = c->nb == 2 ? npr_rnd : npr_det;
+    {
+        const char *env = getenv("SGFHE_CRT_LEAN");
+        c->use_lean = !(env && env[0] == '0');
+        env = getenv("SGFHE_HOST_PIN");
+        c->use_pin = !(env && env[0] == '0');
+    }
+    HIPCHK(c, hipMalloc(&c->d_tw, (size_t)c->npr_max * 4 * c->M * sizeof(int32_t)));
+    HIPCHK(c, hipMalloc(&c->d_bad, sizeof(uint32_t)));
+    HIPCHK(c, hipMemset(c->d_bad, 0, sizeof(uint32_t)));
+    // the larger basis first: its pass puts every prime's twiddle tables on the device
+    for (int b = c->nb - 1; b >= 0; b--) {
+        const bool big = b == c->nb - 1 && c->nb == 2;
+        int32_t rc = build_basis(c, big ? npr_rnd : npr_det, cand_primes, big ? have_rnd : have_det, log_mbq);
+        if (rc) return rc;
+        c->d_key = nullptr;
+        c->key_bytes = 0;
+        save_basis(c, b);
+    }
+    activate(c, 0);
+    return SGFHE_OK;
+}
+
+// Key uploads, generation and imports work on the LARGER basis (its key determines the other one);
+// key_finish derives the smaller basis's key from it and goes back to the basis of the present mode.
+void key_begin(sgfhe_ctx *c) { activate(c, c->nb - 1); }
+int32_t key_finish(sgfhe_ctx *c, int32_t rc) {
+    if (rc == SGFHE_OK && c->nb == 2) {
+        const sgfhe_ctx::Basis &Bg = c->basis[1];
+        sgfhe_ctx::Basis &Sm = c->basis[0];
+        hipError_t e = hipSuccess;
+        if (!Sm.d_key) {
+            Sm.key_bytes = (size_t)c->n * Sm.npr * 8 * c->M * 4;
+            e = hipMalloc(&Sm.d_key, Sm.key_bytes);
+        }
+        if (e == hipSuccess) {
+            KeyFactors fac = {};
+            for (uint32_t i = 0; i < Sm.npr; i++) {
+                const uint32_t p = Sm.primes[i];
+                uint32_t f = (uint32_t)((1ull << 32) % p);                   // R: Montgomery form
+                for (uint32_t j = Sm.npr; j < Bg.npr; j++) f = mulmod32(f, Bg.primes[j] % p, p);
+                fac.f[i] = centre32(f, p);
+            }
+            const size_t total = Sm.key_bytes / 4;
+            hipLaunchKernelGGL(k_key_derive, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream,
+                               Bg.d_key, Sm.d_key, Sm.d_primes, fac, Bg.npr, Sm.npr, (uint32_t)c->logm, total);
+            e = hipGetLastError();
+            if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        }
+        if (e != hipSuccess) { rc = fail(c, SGFHE_ERR_HIP, hipGetErrorString(e)); c->have_key = false; }
+    }
+    activate(c, mode_basis(c));
+    return rc;
 }
 
 // Device-form key blob = 64-byte header + payload keyhat[k][prime][row * 2 + col][slot].  The
@@ -1137,6 +1262,8 @@ int32_t key_alloc(sgfhe_ctx *c) {
     if (c->d_key) return SGFHE_OK;
     c->key_bytes = (size_t)c->n * c->npr * 8 * c->M * 4;
     HIPCHK(c, hipMalloc(&c->d_key, c->key_bytes));
+    c->basis[c->active].d_key = c->d_key;
+    c->basis[c->active].key_bytes = c->key_bytes;
     return SGFHE_OK;
 }
 
@@ -1208,7 +1335,7 @@ int32_t sgfhe_ctx_create(const sgfhe_params *p, int device, sgfhe_ctx **out) {
 int32_t sgfhe_ctx_create_ex(const sgfhe_params *p, int device, uint32_t flags, sgfhe_ctx **out) {
     if (!p || !out) return SGFHE_ERR_INVALID_ARG;
     *out = nullptr;
-    if (flags & ~(uint32_t)SGFHE_CTX_RANDOM_FLATTEN) return SGFHE_ERR_INVALID_ARG;
+    if (flags & ~(uint32_t)(SGFHE_CTX_RANDOM_FLATTEN | SGFHE_CTX_DETERMINISTIC_ONLY)) return SGFHE_ERR_INVALID_ARG;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev)
         return SGFHE_ERR_NO_DEVICE;
@@ -1267,16 +1394,18 @@ int32_t sgfhe_ctx_destroy(sgfhe_ctx *c) {
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
-    if (c->d_primes) (void)hipFree(c->d_primes);
-    if (c->d_crt) (void)hipFree(c->d_crt);
-    if (c->d_lean) (void)hipFree(c->d_lean);
+    for (auto &S : c->basis) {
+        if (S.d_primes) (void)hipFree(S.d_primes);
+        if (S.d_crt) (void)hipFree(S.d_crt);
+        if (S.d_lean) (void)hipFree(S.d_lean);
+        if (S.d_key) (void)hipFree(S.d_key);
+    }
     if (c->io_in) (void)hipFree(c->io_in);
     if (c->io_out) (void)hipFree(c->io_out);
     if (c->pin_in) (void)hipHostFree(c->pin_in);
     if (c->pin_out) (void)hipHostFree(c->pin_out);
     if (c->d_bad) (void)hipFree(c->d_bad);
     if (c->d_tw) (void)hipFree(c->d_tw);
-    if (c->d_key) (void)hipFree(c->d_key);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return SGFHE_OK;
@@ -1287,7 +1416,7 @@ int32_t sgfhe_set_chunk(sgfhe_ctx *c, uint32_t chunk) {
     SGFHE_LOCK(c);
     // the kernels index a chunk's planes with 32-bit byte offsets: residues [chunk][2][npr][m] x 4 B
     // and digit records [chunk][2] x 16 m B must stay below 4 GiB
-    const uint64_t cap_y = 0xFFFFFFFFull / ((uint64_t)2 * c->npr * c->M * 4);
+    const uint64_t cap_y = 0xFFFFFFFFull / ((uint64_t)2 * c->npr_max * c->M * 4);
     const uint64_t cap_d = 0xFFFFFFFFull / ((uint64_t)2 * 16 * c->M);
     const uint64_t cap = (cap_y < cap_d ? cap_y : cap_d) & ~7ull;
     if (chunk > cap) return fail(c, SGFHE_ERR_INVALID_ARG, "chunk too large for this ring size");
@@ -1298,11 +1427,12 @@ int32_t sgfhe_set_chunk(sgfhe_ctx *c, uint32_t chunk) {
 static int32_t set_random_flatten(sgfhe_ctx *c, int enable, const ChaChaKey &key) {
     if (enable && !c->rnd_ok)
         return fail(c, SGFHE_ERR_UNSUPPORTED,
-                    "randomised flatten: 20 m B Q exceeds the product of this ctx's RNS primes (or B^2 > 2^48 Q); "
-                    "create the ctx with sgfhe_ctx_create_ex(..., SGFHE_CTX_RANDOM_FLATTEN, ...)");
+                    "randomised flatten: not available on this ctx (created with SGFHE_CTX_DETERMINISTIC_ONLY "
+                    "where it needs a prime more, 20 m B Q beyond seven primes, or B^2 > 2^48 Q)");
     c->rnd = enable != 0;
     c->rnd_key = key;
     c->rnd_call = 0;
+    activate(c, mode_basis(c));   // constants and key form of the mode's basis (queued work keeps its own)
     return SGFHE_OK;
 }
 
@@ -1347,7 +1477,7 @@ int32_t sgfhe_set_lanes(sgfhe_ctx *c, uint32_t lanes) {
     return SGFHE_OK;
 }
 
-int32_t sgfhe_bkey_upload(sgfhe_ctx *c, const uint64_t *canonical, size_t n_words) {
+static int32_t sgfhe_bkey_upload_impl(sgfhe_ctx *c, const uint64_t *canonical, size_t n_words) {
     if (!c || !canonical) return SGFHE_ERR_INVALID_ARG;
     SGFHE_LOCK(c);
     (void)hipSetDevice(c->device);
@@ -1369,7 +1499,14 @@ int32_t sgfhe_bkey_upload(sgfhe_ctx *c, const uint64_t *canonical, size_t n_word
     return SGFHE_OK;
 }
 
-int32_t sgfhe_bkey_generate(sgfhe_ctx *c, const uint64_t *sk, size_t n_sk, const uint8_t *seed32,
+int32_t sgfhe_bkey_upload(sgfhe_ctx *c, const uint64_t *canonical, size_t n_words) {
+    if (!c) return SGFHE_ERR_INVALID_ARG;
+    SGFHE_LOCK(c);
+    key_begin(c);   // on the larger basis; the other basis's key is derived from it
+    return key_finish(c, sgfhe_bkey_upload_impl(c, canonical, n_words));
+}
+
+static int32_t sgfhe_bkey_generate_impl(sgfhe_ctx *c, const uint64_t *sk, size_t n_sk, const uint8_t *seed32,
                             uint32_t noise) {
     if (!c || !sk || !seed32) return SGFHE_ERR_INVALID_ARG;
     SGFHE_LOCK(c);
@@ -1433,6 +1570,14 @@ int32_t sgfhe_bkey_generate(sgfhe_ctx *c, const uint64_t *sk, size_t n_sk, const
     return rc;
 }
 
+int32_t sgfhe_bkey_generate(sgfhe_ctx *c, const uint64_t *sk, size_t n_sk, const uint8_t *seed32,
+                            uint32_t noise) {
+    if (!c) return SGFHE_ERR_INVALID_ARG;
+    SGFHE_LOCK(c);
+    key_begin(c);   // on the larger basis; the other basis's key is derived from it
+    return key_finish(c, sgfhe_bkey_generate_impl(c, sk, n_sk, seed32, noise));
+}
+
 static int32_t rns2_configure(sgfhe_ctx *c, uint64_t m1, uint64_t m2) {
     if ((u128)m1 * m2 != c->Q) return fail(c, SGFHE_ERR_INVALID_ARG, "m1 * m2 != Q");
     if (m1 >= (1ull << 47) || m2 >= (1ull << 47) || m1 < 2 || m2 < 2)
@@ -1458,7 +1603,7 @@ static int32_t rns2_configure(sgfhe_ctx *c, uint64_t m1, uint64_t m2) {
     return SGFHE_OK;
 }
 
-int32_t sgfhe_bkey_upload_rns2(sgfhe_ctx *c, const uint64_t *pairs, size_t n_words, uint64_t m1,
+static int32_t sgfhe_bkey_upload_rns2_impl(sgfhe_ctx *c, const uint64_t *pairs, size_t n_words, uint64_t m1,
                                uint64_t m2) {
     if (!c || !pairs) return SGFHE_ERR_INVALID_ARG;
     SGFHE_LOCK(c);
@@ -1481,6 +1626,14 @@ int32_t sgfhe_bkey_upload_rns2(sgfhe_ctx *c, const uint64_t *pairs, size_t n_wor
     }
     c->have_key = true;
     return SGFHE_OK;
+}
+
+int32_t sgfhe_bkey_upload_rns2(sgfhe_ctx *c, const uint64_t *pairs, size_t n_words, uint64_t m1,
+                               uint64_t m2) {
+    if (!c) return SGFHE_ERR_INVALID_ARG;
+    SGFHE_LOCK(c);
+    key_begin(c);   // on the larger basis; the other basis's key is derived from it
+    return key_finish(c, sgfhe_bkey_upload_rns2_impl(c, pairs, n_words, m1, m2));
 }
 
 int32_t sgfhe_rns2_convert(sgfhe_ctx *c, int to_pairs, const uint64_t *in, size_t count, uint64_t m1,
@@ -1524,11 +1677,11 @@ int32_t sgfhe_rns2_convert(sgfhe_ctx *c, int to_pairs, const uint64_t *in, size_
 int32_t sgfhe_bkey_device_form_bytes(const sgfhe_ctx *c, size_t *bytes) {
     if (!c || !bytes) return SGFHE_ERR_INVALID_ARG;
     SGFHE_LOCK(c);
-    *bytes = sizeof(KeyBlobHeader) + (size_t)c->n * c->npr * 8 * c->M * 4;
+    *bytes = sizeof(KeyBlobHeader) + (size_t)c->n * c->npr_max * 8 * c->M * 4;   // the larger basis's key
     return SGFHE_OK;
 }
 
-int32_t sgfhe_bkey_export_device_form(sgfhe_ctx *c, void *dst) {
+static int32_t sgfhe_bkey_export_device_form_impl(sgfhe_ctx *c, void *dst) {
     if (!c || !dst) return SGFHE_ERR_INVALID_ARG;
     SGFHE_LOCK(c);
     if (!c->have_key) return fail(c, SGFHE_ERR_NO_KEY, "no bootstrap key uploaded");
@@ -1542,7 +1695,16 @@ int32_t sgfhe_bkey_export_device_form(sgfhe_ctx *c, void *dst) {
     return SGFHE_OK;
 }
 
-int32_t sgfhe_bkey_import_device_form(sgfhe_ctx *c, const void *src) {
+int32_t sgfhe_bkey_export_device_form(sgfhe_ctx *c, void *dst) {
+    if (!c) return SGFHE_ERR_INVALID_ARG;
+    SGFHE_LOCK(c);
+    key_begin(c);   // the blob is the key of the larger basis
+    const int32_t rc = sgfhe_bkey_export_device_form_impl(c, dst);
+    activate(c, mode_basis(c));
+    return rc;
+}
+
+static int32_t sgfhe_bkey_import_device_form_impl(sgfhe_ctx *c, const void *src) {
     if (!c || !src) return SGFHE_ERR_INVALID_ARG;
     SGFHE_LOCK(c);
     (void)hipSetDevice(c->device);
@@ -1564,6 +1726,13 @@ int32_t sgfhe_bkey_import_device_form(sgfhe_ctx *c, const void *src) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->have_key = true;
     return SGFHE_OK;
+}
+
+int32_t sgfhe_bkey_import_device_form(sgfhe_ctx *c, const void *src) {
+    if (!c) return SGFHE_ERR_INVALID_ARG;
+    SGFHE_LOCK(c);
+    key_begin(c);   // on the larger basis; the other basis's key is derived from it
+    return key_finish(c, sgfhe_bkey_import_device_form_impl(c, src));
 }
 
 int32_t sgfhe_bootstrap_batch_device(sgfhe_ctx *c, const uint64_t *a1, const uint64_t *b1,

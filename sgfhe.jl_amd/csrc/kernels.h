@@ -1627,6 +1627,31 @@ k_key_transform(const ulonglong2 *__restrict__ canon, int32_t *__restrict__ keyh
     }
 }
 
+// ---- k_key_derive -------------------------------------------------------------------------------------
+// The key of a ctx's smaller basis (primes 0 .. nps-1, deterministic flatten) from the key of its larger
+// one (primes 0 .. npb-1, randomised flatten): the device form is scaled by (M_rns / p_i)^-1 mod p_i,
+// and M_big = M_small * (the extra primes), so keyhat_small = keyhat_big * (product of the extra primes)
+// mod p_i -- one constant per prime, no transform.  fac.f[i] = that constant in Montgomery form, centred.
+// The result is the centred canonical residue, i.e. byte for byte what k_key_transform writes for the
+// smaller basis.  One thread per element of the smaller key: keyhat[k][prime][row * 2 + col][slot].
+struct KeyFactors {
+    int32_t f[NPR_MAX];
+};
+__global__ void __launch_bounds__(256)
+k_key_derive(const int32_t *__restrict__ big, int32_t *__restrict__ small, PrimeSet PS, KeyFactors fac,
+             uint32_t npb, uint32_t nps, uint32_t logm, size_t total) {
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= total) return;
+    const size_t per_prime = (size_t)8 << logm;                 // 8 polynomials of m slots
+    const size_t e = t % per_prime;
+    const uint32_t i = (uint32_t)((t / per_prime) % nps);
+    const size_t k = t / (per_prime * nps);
+    const PrimeK P = PS[i];
+    const Mod md = mod_of(P);
+    const int32_t v = big[(k * npb + i) * per_prime + e];
+    small[t] = scentre(sred(smont(v, fac.f[i], md), md), md);
+}
+
 // ---- RNS2Number boundary conversions (src/rns.jl, BASELINE.json config 4) --------------------------
 // The reference's two-modulus residue type holds a coefficient of Z_Q, Q = m1 m2, as
 // (v1, v2) = (x mod m1, x mod m2) (rns.jl:16-18) and converts back with the Fermat idempotents

@@ -14,7 +14,8 @@ from . import _lib
 
 FLAG_RAW_MODQ = 1
 FLAG_RAW_RNS2 = 2
-CTX_RANDOM_FLATTEN = 1
+CTX_RANDOM_FLATTEN = 1          # accepted, without effect since ABI revision 6
+CTX_DETERMINISTIC_ONLY = 2
 
 
 class SgfheError(RuntimeError):
@@ -35,9 +36,13 @@ def _c(arr, dtype=np.uint64):
 class Engine:
     """One bootstrap engine (ctx) for one parameter set on one HIP device."""
 
-    def __init__(self, params, device=0, random_flatten=False):
-        """random_flatten=True sizes the RNS basis for the randomised flatten (the `rng` argument of
-        bootstrap / pack_encrypted_bits): one more prime at Params(1024), nothing elsewhere."""
+    def __init__(self, params, device=0, random_flatten=False, deterministic_only=False):
+        """Both flatten modes (the `rng` argument of bootstrap / pack_encrypted_bits) are available on
+        every engine: where the randomised one needs a prime more (Params(1024): six against five)
+        the ctx keeps a basis and a key form per mode and `set_random_flatten` switches between them.
+        deterministic_only=True keeps the smaller basis only (SGFHE_CTX_DETERMINISTIC_ONLY: no second
+        key form; the randomised mode is then refused where it needs the extra prime).
+        random_flatten is accepted for compatibility and has no effect."""
         self.params = params
         self.device = device
         # Held around every C call together with the read of its error string, and by the scheme
@@ -50,7 +55,8 @@ class Engine:
                               _words(params.B), _words(params.DQ_tilde))
         h = ctypes.c_void_p()
         rc = self._L.sgfhe_ctx_create_ex(ctypes.byref(sp), device,
-                                         CTX_RANDOM_FLATTEN if random_flatten else 0, ctypes.byref(h))
+                                         (CTX_RANDOM_FLATTEN if random_flatten else 0) |
+                                         (CTX_DETERMINISTIC_ONLY if deterministic_only else 0), ctypes.byref(h))
         self._h = h
         if rc != 0:
             msg = self._L.sgfhe_last_error_string(h).decode() if h else "ctx_create failed"

@@ -117,8 +117,9 @@ class BootstrapKey:
     `BootstrapKey(rng, sk, on_host=True)` generates it with host big-integer arithmetic."""
 
     def __init__(self, rng, sk, device=0, engine=None, on_host=False, random_flatten=False):
-        """random_flatten=True: the key will also be used with `rng != nothing` (randomised flatten);
-        at Params(1024) that takes a sixth RNS prime, so it is chosen when the key is made."""
+        """Both `rng = None` and `rng != None` calls work with every key (at Params(1024) the engine keeps
+        the key in the five-prime form of the deterministic flatten and the six-prime form of the
+        randomised one); random_flatten is accepted for compatibility and has no effect."""
         params = sk.params
         self.params = params
         self.engine = engine or Engine(params, device, random_flatten=random_flatten)

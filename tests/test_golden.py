@@ -110,7 +110,7 @@ def test_params1024_random_flatten_golden(oc):
     reference's Params(1024) on the engine's ChaCha8 stream): the C restatement of utils.jl:198-241
     reproduces the accumulator hashes after the first two iterations here, as bootstrap 0 of call 0
     and as bootstrap 5 of call 2; the full bootstrap is compared on the GPU box
-    (tests/test_gpu_round4.py::test_sixprime_ctx_matches_big_integer_golden)."""
+    (tests/test_gpu_round4.py::test_dual_basis_ctx_matches_big_integer_golden)."""
     d = load("p1024rnd")
     o = oc.Oracle.make(1024)
     assert str(o.Q) == d["params"]["Q"]

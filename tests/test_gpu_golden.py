@@ -527,14 +527,8 @@ def test_random_flatten_params1024_and_host_api(S):
     rng = np.random.default_rng(8)
     params = S.Params(1024)
     key = S.PrivateKey(params, rng)
-    plain = S.Engine(params)                              # five primes: deterministic flatten only
-    assert len(plain.primes()) == 5
-    with pytest.raises(S.SgfheError) as ei:
-        plain.set_random_flatten(True, 1)
-    assert ei.value.code == -2 and "SGFHE_CTX_RANDOM_FLATTEN" in str(ei.value)
-    plain.close()
-    bkey = S.BootstrapKey(rng, key, random_flatten=True)  # six primes: both modes
-    assert len(bkey.engine.primes()) == 6
+    bkey = S.BootstrapKey(rng, key)                       # a basis per flatten mode: five and six primes
+    assert len(bkey.engine.primes()) == 5
     msg = rng.integers(0, 2, size=params.n).astype(bool)
     bits = S.split_ciphertext(S.encrypt(key, rng, msg))
     res = S.bootstrap_batch(bkey, rng, bits[0:16:2], bits[1:16:2])

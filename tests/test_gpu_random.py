@@ -169,21 +169,36 @@ def test_randomised_pack_equals_oracle(S, oc):
     eng.close()
 
 
-def test_random_mode_needs_headroom_at_params1024(S):
-    """Params(1024) runs on five 29-bit primes (deterministic flatten); the randomised flatten
-    needs the sixth, chosen at ctx creation (SGFHE_CTX_RANDOM_FLATTEN)."""
+def test_both_modes_on_every_ctx_at_params1024(S):
+    """Params(1024): the deterministic flatten runs on five 29-bit primes, the randomised one needs
+    a sixth.  A default ctx keeps a basis per mode and switches (ABI revision 6; up to revision 5 the
+    sixth prime had to be asked for at ctx creation and then slowed the deterministic mode down as
+    well); a ctx created with SGFHE_CTX_DETERMINISTIC_ONLY has the smaller basis only and refuses."""
     params = S.Params(1024)
-    plain = S.Engine(params)
-    assert len(plain.primes()) == 5
+    eng = S.Engine(params)
+    assert len(eng.primes()) == 5 and eng.kernel_names()[1] == "k_crt_lean<5, 3>"
+    eng.set_random_flatten(True, 1)
+    assert len(eng.primes()) == 6 and eng.kernel_names()[1] == "k_crt_lean_rnd<6, 3, false>"
+    eng.set_random_flatten(False)
+    assert len(eng.primes()) == 5
+    six = 64 + params.n * 6 * 8 * params.m * 4
+    assert eng.key_device_form_bytes() == six            # the blob is the larger basis's key
+    eng.close()
+    old = S.Engine(params, random_flatten=True)          # the flag of revisions 3-5: no effect
+    assert len(old.primes()) == 5
+    old.close()
+    det = S.Engine(params, deterministic_only=True)
+    assert len(det.primes()) == 5 and det.key_device_form_bytes() == 64 + params.n * 5 * 8 * params.m * 4
     with pytest.raises(S.SgfheError) as ei:
-        plain.set_random_flatten(True, 1)
-    assert ei.value.code == -2
-    plain.close()
-    both = S.Engine(params, random_flatten=True)
-    assert len(both.primes()) == 6
-    both.set_random_flatten(True, 1)
-    both.set_random_flatten(False)
-    both.close()
+        det.set_random_flatten(True, 1)
+    assert ei.value.code == -2 and "SGFHE_CTX_DETERMINISTIC_ONLY" in str(ei.value)
+    det.close()
+    for n in (64, 512, 2048):                             # one basis serves both modes
+        e = S.Engine(S.Params(n), deterministic_only=True)
+        k = len(e.primes())
+        e.set_random_flatten(True, 1)
+        assert len(e.primes()) == k
+        e.close()
 
 
 def test_random_mode_refused_when_its_reductions_would_overflow(S):
@@ -192,7 +207,7 @@ def test_random_mode_refused_when_its_reductions_would_overflow(S):
     (SGFHE_ERR_UNSUPPORTED) instead of returning silently wrong digits; the deterministic flatten of
     the same ring works."""
     params = S.Params.custom(8, (1 << 17) + 1, 1 << 45)
-    eng = S.Engine(params, random_flatten=True)
+    eng = S.Engine(params)
     with pytest.raises(S.SgfheError) as ei:
         eng.set_random_flatten(True, 1)
     assert ei.value.code == -2

@@ -1,8 +1,9 @@
 """Round-4 parity evidence on the GPU:
 
- * the six-prime Params(1024) ctx (SGFHE_CTX_RANDOM_FLATTEN) -- the ctx behind the reference's
-   documented call bootstrap(bkey, rng, ...) (README.md:24, docs/src/manual.md:144,
-   src/utils.jl:198-241) -- under the oracle in both flatten modes, at its ring and at full batch;
+ * the Params(1024) ctx with a basis per flatten mode (five primes deterministic, six randomised:
+   the reference's documented call bootstrap(bkey, rng, ...), README.md:24, docs/src/manual.md:144,
+   src/utils.jl:198-241, works on every ctx) under the oracle in both modes, at its ring and at
+   full batch; the five-prime key form derived on the device from the six-prime one;
  * a soak on DISTINCT inputs at every full-size configuration (test/api.test.jl:45-83 widened);
  * calls on one ctx from two streams / two threads equal the same calls made one after the other
    (the reference call is pure, src/fhe.jl:608-621);
@@ -65,31 +66,36 @@ def _mixed_inputs(o, sk, p, count, seed):
 
 @pytest.fixture(scope="module")
 def p1024six(S, oc):
-    """Params(1024) on the six-prime ctx with the key of tests/golden/p1024*.json; the oracle's
-    key in both of its forms."""
+    """Params(1024) on a default ctx (a basis per flatten mode) with the key of
+    tests/golden/p1024*.json; the oracle's key in the NTT domain."""
     params = S.Params(1024)
     o = oc.Oracle.from_params(params)
     sk = o.private_key(21)
     bkey = o.bootstrap_key(sk, 22)
     khat = o.key_transform(bkey, threads=_threads())
     del bkey
-    eng = S.Engine(params, random_flatten=True)
-    assert len(eng.primes()) == 6
+    eng = S.Engine(params)
+    assert len(eng.primes()) == 5
     eng.generate_key(sk, 22)                    # byte-identical to the oracle's key (test_gpu_golden.py)
     yield params, o, sk, khat, eng
     eng.close()
 
 
-# ---- 1. the six-prime Params(1024) ctx, deterministic mode ------------------------------------------
+# ---- 1. the dual-basis Params(1024) ctx, deterministic mode (derived five-prime key) ----------------
 
 @pytest.mark.parametrize("form", ["small-batch form", "throughput form"])
-def test_sixprime_ctx_deterministic_mode_vs_oracle(S, oc, p1024six, form):
-    """k_extprod / k_fwd_phase with npr = 6 and k_crt_lean<6, 3>: accumulators after k = 1, 2 and n
-    iterations, raw LWEs mod Q and ModRed words of 4 bootstraps against the C restatement."""
+def test_dual_basis_ctx_deterministic_mode_vs_oracle(S, oc, p1024six, form):
+    """The deterministic mode of a ctx that also holds the randomised mode's six-prime basis: five
+    primes, the key form derived on the device (k_key_derive) -- accumulators after k = 1, 2 and n
+    iterations, raw LWEs mod Q and ModRed words of 4 bootstraps against the C restatement; the
+    same again after a round trip through the randomised mode."""
     params, o, sk, khat, eng = p1024six
     eng.set_random_flatten(False)
     eng.set_small_batch_max(0 if form == "throughput form" else 24)
-    assert eng.kernel_names() == ("k_extprod<13, 4, false>", "k_crt_lean<6, 3>")
+    eng.set_random_flatten(True, FKEY)          # there and back: the basis switch leaves nothing behind
+    assert len(eng.primes()) == 6
+    eng.set_random_flatten(False)
+    assert eng.kernel_names() == ("k_extprod<13, 4, false>", "k_crt_lean<5, 3>") and len(eng.primes()) == 5
     bits, a1, b1, a2, b2 = _mixed_inputs(o, sk, params, 4, 61)
     T = _threads()
     for it in (1, 2, params.n):
@@ -105,10 +111,11 @@ def test_sixprime_ctx_deterministic_mode_vs_oracle(S, oc, p1024six, form):
     eng.set_small_batch_max(24)
 
 
-def test_sixprime_ctx_deterministic_full_batch_4096(S, oc, p1024six):
-    """The bench's `--flatten random` ctx in its deterministic mode at the full batch: 8 distinct
-    oracle-verified input pairs tiled over 4096 rows in a shuffled order, every output word
-    pinned; equal to the five-prime ctx's bytes."""
+def test_dual_basis_ctx_deterministic_full_batch_4096(S, oc, p1024six):
+    """The dual-basis ctx in its deterministic mode at the full batch: 8 distinct oracle-verified
+    input pairs tiled over 4096 rows in a shuffled order, every output word pinned; equal to the
+    bytes of a ctx created with SGFHE_CTX_DETERMINISTIC_ONLY, whose five-prime key form comes
+    straight from the transform instead of the derivation."""
     params, o, sk, khat, eng = p1024six
     eng.set_random_flatten(False)
     bits, a1, b1, a2, b2 = _mixed_inputs(o, sk, params, 8, 62)
@@ -116,7 +123,7 @@ def test_sixprime_ctx_deterministic_full_batch_4096(S, oc, p1024six):
     idx = np.random.default_rng(63).permutation(np.repeat(np.arange(8), 512))
     out = eng.bootstrap_batch(a1[idx], b1[idx], a2[idx], b2[idx])
     assert np.array_equal(out, ref[idx])
-    five = S.Engine(params)
+    five = S.Engine(params, deterministic_only=True)
     assert len(five.primes()) == 5
     five.generate_key(sk, 22)
     assert five.bootstrap_batch(a1[idx[:64]], b1[idx[:64]], a2[idx[:64]], b2[idx[:64]]).tobytes() == \
@@ -124,9 +131,9 @@ def test_sixprime_ctx_deterministic_full_batch_4096(S, oc, p1024six):
     five.close()
 
 
-# ---- 1. the six-prime Params(1024) ctx, randomised mode ---------------------------------------------
+# ---- 1. the dual-basis Params(1024) ctx, randomised mode (six primes) ---------------------------------
 
-def test_sixprime_ctx_random_mode_accumulators_vs_oracle(S, oc, p1024six):
+def test_dual_basis_ctx_random_mode_accumulators_vs_oracle(S, oc, p1024six):
     """bootstrap(bkey, rng, ...) at the reference's own Params(1024): accumulators after k = 1, 2 and
     n iterations, raw LWEs and ModRed words of 4 bootstraps bit for bit against the C restatement of
     utils.jl:198-241 on the same ChaCha8 stream (small-batch and throughput kernels)."""
@@ -136,7 +143,7 @@ def test_sixprime_ctx_random_mode_accumulators_vs_oracle(S, oc, p1024six):
     for form in (24, 0):
         eng.set_small_batch_max(form)
         eng.set_random_flatten(True, FKEY)                      # call number back to 0
-        assert eng.kernel_names()[1] == "k_crt_lean_rnd<6, 3, false>"
+        assert eng.kernel_names()[1] == "k_crt_lean_rnd<6, 3, false>" and len(eng.primes()) == 6
         call = 0
         for it in (1, 2, params.n):
             _, ref = o.bootstrap_batch(khat, a1, b1, a2, b2, n_iters=it, want_acc=True, opt=True, threads=T,
@@ -156,7 +163,7 @@ def test_sixprime_ctx_random_mode_accumulators_vs_oracle(S, oc, p1024six):
     eng.set_random_flatten(False)
 
 
-def test_sixprime_ctx_random_mode_full_batch_4096(S, oc, p1024six):
+def test_dual_basis_ctx_random_mode_full_batch_4096(S, oc, p1024six):
     """The workload of `bench.py --flatten random` at its ring and batch.  In the randomised mode
     every row of a call has its own draws (counter word = its index in the call), so tiling inputs
     does not tile outputs: 8 distinct input pairs are tiled over the 4096 rows, and 96 rows -- the
@@ -188,7 +195,7 @@ def test_sixprime_ctx_random_mode_full_batch_4096(S, oc, p1024six):
     eng.set_random_flatten(False)
 
 
-def test_sixprime_ctx_matches_big_integer_golden(S, oc, p1024six):
+def test_dual_basis_ctx_matches_big_integer_golden(S, oc, p1024six):
     """tests/golden/p1024rnd.json, made by the literal big-integer restatement: accumulator hashes
     after 1, 2, 512 and 1024 iterations, raw and ModRed output hashes of the randomised bootstrap at
     Params(1024), as bootstrap 0 of call 0 and as bootstrap 5 of call 2 of the stream."""
