@@ -22,13 +22,16 @@ Prints ONE JSON line on rank 0.
 """
 
 import argparse
+import csv
 import glob
 import hashlib
 import json
 import os
+import shutil
 import socket
 import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -115,6 +118,58 @@ def _counters(config, chunk, build_id):
     if stale:
         return None, "the loaded library (build id %s) is not the one %s was collected on" % (build_id, stale)
     return None, "no committed counters for chunk %d" % chunk
+
+
+def live_counters(args, chunk, kernels, rnd):
+    """HBM traffic and VALU instruction counts of the two k-loop kernels measured NOW, on this box:
+    rocprofv3 --pmc passes run as child processes of this bench (one counter group per pass,
+    --kernel-trace only, as /opt/skills/guides/MI355X_MICROARCH.md prescribes), each over one chunk of
+    the same workload on one lane -- the launches are the ones of the timed region, the counters are
+    per launch.  FETCH_SIZE / WRITE_SIZE come in KB, and on gfx950 FETCH_SIZE counts half the bytes of
+    wide coalesced reads: traffic = (2 FETCH_SIZE + WRITE_SIZE) * 1024 B.  Returns (dict, None) or
+    (None, reason); the caller falls back to the committed profile of the same build."""
+    if shutil.which("rocprofv3") is None:
+        return None, "rocprofv3 is not on PATH"
+    one = ["python3", os.path.abspath(__file__), "--config", args.config, "--lanes", "1", "--chunk", str(chunk),
+           "--batch", str(chunk), "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-host-io",
+           "--no-live-counters", "--flatten", "random" if rnd else "deterministic"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["TMPDIR"] = "/tmp"
+    out = {k: {} for k in kernels}
+    t0 = time.perf_counter()
+    for group in (["FETCH_SIZE"], ["WRITE_SIZE"], ["SQ_INSTS_VALU", "SQ_WAVES"]):
+        d = tempfile.mkdtemp(prefix="sgfhe_pmc_", dir="/tmp")
+        try:
+            r = subprocess.run(["rocprofv3", "--pmc", *group, "--kernel-trace", "--output-format", "csv",
+                                "-d", d, "-o", "run", "--", *one], env=env, cwd="/tmp", timeout=300,
+                               stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True)
+            if r.returncode != 0:
+                return None, "rocprofv3 --pmc %s failed: %s" % (" ".join(group), r.stderr[-300:])
+            vals = {}   # kernel -> grid -> counter -> [values]
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    for k in kernels:
+                        if "::" + k + "<" in row["Kernel_Name"]:
+                            vals.setdefault(k, {}).setdefault(row["Grid_Size"], {}).setdefault(
+                                row["Counter_Name"], []).append(float(row["Counter_Value"]))
+            for k in kernels:
+                if k not in vals:
+                    return None, "no %s launches in the --pmc %s pass" % (k, " ".join(group))
+                # the k-loop's launches: the most frequent grid of that kernel
+                g = max(vals[k].values(), key=lambda cs: max(len(v) for v in cs.values()))
+                for cname, v in g.items():
+                    out[k][cname] = sum(v) / len(v)
+                    out[k]["launches"] = len(v)
+        except subprocess.TimeoutExpired:
+            return None, "rocprofv3 --pmc %s timed out" % " ".join(group)
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    for k in kernels:
+        out[k]["traffic_bytes_per_launch"] = (2 * out[k]["FETCH_SIZE"] + out[k]["WRITE_SIZE"]) * 1024
+    out["source"] = ("measured in this run: rocprofv3 --pmc child passes (FETCH_SIZE | WRITE_SIZE | SQ_INSTS_VALU "
+                     "SQ_WAVES, --kernel-trace only) over one %d-bootstrap chunk on one lane, %.0f s"
+                     % (chunk, time.perf_counter() - t0))
+    return out, None
 
 
 # Issue rates measured on the MI355X by tools/ubench_int.hip (profiles/r01_ubench_valu.txt,
@@ -280,6 +335,10 @@ def main():
                     help="skip the extra untimed step that measures each kernel alone (lanes = 1)")
     ap.add_argument("--no-host-io", action="store_true",
                     help="skip the extra step timed through host pointers (sgfhe_bootstrap_batch)")
+    ap.add_argument("--no-live-counters", action="store_true",
+                    help="do not run the rocprofv3 --pmc child passes that measure roofline.traffic and the "
+                         "VALU instruction count on this box (the committed profile of the same build is quoted "
+                         "instead); also skipped with --no-host-io or --no-cpu-baseline (quick A/B runs)")
     ap.add_argument("--cpu-threads", type=int, default=0,
                     help="cap on the cpu_baseline threads (0 = every core this process may use; "
                          "the leg on an eighth of them is reported beside it)")
@@ -462,6 +521,7 @@ def main():
         ext_s = tm["extprod_ms"] * 1e-3
         build_id = eng.build_id()
         ctr, why = _counters(args.config, chunk, build_id)
+        live = live_why = None
         how = ("overlapped with the other lane's kernels" if lanes == 2 else "alone on the device")
         # the kernels the engine actually launches for this parameter set and flatten mode
         # (k_crt_lean, or k_crt_lean_rnd / k_crt_acc2 / k_crt_acc outside its bounds)
@@ -478,9 +538,32 @@ def main():
             kern[k]["launch_ms_alone"] = alone[key]
             kern[k]["kernel_achieved"] = launch_bytes / (alone[key] * 1e-3) / 1e9 if alone[key] > 0 else 0.0
             kern[k]["kernel_frac"] = kern[k]["kernel_achieved"] / PEAK_HBM_GBS
+        # (part of the full line only: the quick modes of the A/B scripts, --no-host-io / --no-cpu-baseline,
+        # skip it, and so does a run that is itself under a profiler, e.g. tools/profile_round.sh)
+        if (world == 1 and not rehearsal and not args.no_live_counters and not args.no_host_io
+                and not args.no_cpu_baseline):
+            # (the engine of this process is idle meanwhile; its memory stays allocated)
+            live, live_why = live_counters(args, chunk, ["k_extprod", crt_name], rnd)
         traffic = None
         rp_ms = None
-        if ctr:
+        if live:   # this box, this run
+            for k in ("k_extprod", crt_name):
+                kern[k]["traffic"] = live[k]["traffic_bytes_per_launch"]
+                kern[k]["valu_insts_per_launch"] = live[k].get("SQ_INSTS_VALU")
+                kern[k]["waves_per_launch"] = live[k].get("SQ_WAVES")
+            traffic = live["k_extprod"]["traffic_bytes_per_launch"] + live[crt_name]["traffic_bytes_per_launch"]
+            if ctr:   # durations of the committed rocprofv3 trace, and the static instruction mix
+                rp = ctr.get("rocprof_avg_us") or {}
+                rpa = ctr.get("rocprof_alone_avg_us") or {}
+                for k in ("k_extprod", "k_crt_lean"):
+                    if k in rp and k in kern:
+                        kern[k]["launch_ms_rocprof"] = rp[k] * 1e-3
+                    if k in rpa and k in kern:
+                        kern[k]["launch_ms_alone_rocprof"] = rpa[k] * 1e-3
+                rp_ms = ctr.get("rocprof_iter_us") and ctr["rocprof_iter_us"] * 1e-3
+                ctr = dict(ctr, k_extprod=dict(ctr.get("k_extprod", {}), SQ_INSTS_VALU=live["k_extprod"]["SQ_INSTS_VALU"]),
+                           source=live["source"] + "; instruction mix from " + ctr["source"])
+        elif ctr:
             t_ext = ctr.get("k_extprod", {}).get("traffic_bytes_per_launch")
             t_crt = ctr.get("k_crt_lean", {}).get("traffic_bytes_per_launch")
             kern["k_extprod"]["traffic"] = t_ext
@@ -517,8 +600,10 @@ def main():
                          "frac": achieved / PEAK_HBM_GBS,
                          "traffic": traffic,
                          "traffic_ratio": traffic / launch_bytes if traffic else None,
-                         "traffic_note": ("HBM bytes of both launches from the committed PMC passes (%s), "
-                                          "not measured in this run" % ctr["source"]) if ctr else why,
+                         "traffic_note": (live["source"] if live else
+                                          (("HBM bytes of both launches from the committed PMC passes (%s), "
+                                            "not measured in this run: %s" % (ctr["source"], live_why)) if ctr
+                                           else "%s; %s" % (why, live_why))),
                          "algorithmic_bytes_per_launch": launch_bytes,
                          "launch_ms": iter_s * 1e3,
                          "launch_ms_source": "HIP events on the ctx stream around whole steps (first to last "

@@ -236,7 +236,8 @@ class Oracle:
     def key_transform(self, bkey, threads=None):
         """NTT-domain key for bootstrap_batch(..., opt=True) (sgo_key_transform)."""
         bkey = np.ascontiguousarray(bkey, dtype=np.uint64)
-        khat = np.zeros_like(bkey)
+        # (RNS2Number ring: the key limb-wise, [2][n][4][2][m] residues mod m_limb)
+        khat = np.zeros(((2,) if self.uses_rns2 and not self.uses_ntt else ()) + bkey.shape, dtype=np.uint64)
         rc = lib().sgo_key_transform(self._ctx, _p(bkey), _p(khat), threads or os.cpu_count() or 1)
         if rc:
             raise RuntimeError("sgo_key_transform failed: %d" % rc)

@@ -87,8 +87,10 @@ int sgo_bootstrap_batch(const sgo_ctx *ctx, const uint64_t *bkey, const uint64_t
  * `cpu_opt` of BASELINE.md section 3: the same bootstrap in the algebra of the GPU path -- key in
  * the NTT domain (sgo_key_transform), acc <- acc + (x^j - 1) sum_row u_row (*) C_k[row], i.e.
  * 4 forward + 2 inverse NTTs per iteration instead of 24 -- still 128-bit Montgomery arithmetic
- * mod Q, bit-identical outputs.  Prime NTT-friendly Q only.  Same arguments as
- * sgo_bootstrap_batch with khat in place of bkey.
+ * mod Q, bit-identical outputs.  Prime NTT-friendly Q, or the RNS2Number ring (sgo_ctx_set_rns2):
+ * there khat holds the key limb-wise, [2][n][4][2][m] residues mod m_limb (twice the size of bkey),
+ * and an iteration is 2 x (4 + 2) limb NTTs with the CRT of rns.jl:32-40 per column.  Same arguments
+ * as sgo_bootstrap_batch with khat in place of bkey.
  */
 int sgo_key_transform(const sgo_ctx *ctx, const uint64_t *bkey, uint64_t *khat, int threads);
 int sgo_bootstrap_batch_opt(const sgo_ctx *ctx, const uint64_t *khat, const uint64_t *a1,

@@ -40,7 +40,12 @@ struct CParams
     DQ_tilde::NTuple{2,UInt64}
 end
 
-words(x) = (UInt64(UInt128(x) & typemax(UInt64)), UInt64(UInt128(x) >> 64))
+# little-endian 64-bit words of a residue / modulus below 2^128, whatever unsigned type holds it
+# (UInt64, UInt128, or an MLUInt chosen with Params(n; rlwe_type = ...), src/fhe.jl:43,79-81)
+function words(x)
+    b = BigInt(x)
+    (UInt64(b & typemax(UInt64)), UInt64(b >> 64))
+end
 
 function check(ctx::Ptr{Cvoid}, rc::Int32)
     rc == 0 && return
@@ -49,13 +54,15 @@ function check(ctx::Ptr{Cvoid}, rc::Int32)
 end
 
 const CTX_RANDOM_FLATTEN = UInt32(1)
+const CTX_DETERMINISTIC_ONLY = UInt32(2)
 
-function create_ctx(p::Params, device::Integer, random_flatten::Bool)
+function create_ctx(p::Params, device::Integer, random_flatten::Bool, deterministic_only::Bool=false)
     cp = Ref(CParams(p.n, p.r, p.m, 2, words(p.Q), words(p.B), words(p.DQ_tilde)))
     ctx = Ref{Ptr{Cvoid}}(C_NULL)
     rc = ccall((:sgfhe_ctx_create_ex, libsgfhe_hip), Int32,
                (Ref{CParams}, Cint, UInt32, Ref{Ptr{Cvoid}}), cp, device,
-               random_flatten ? CTX_RANDOM_FLATTEN : UInt32(0), ctx)
+               (random_flatten ? CTX_RANDOM_FLATTEN : UInt32(0)) |
+               (deterministic_only ? CTX_DETERMINISTIC_ONLY : UInt32(0)), ctx)
     check(ctx[], rc)
     ctx
 end
@@ -68,11 +75,14 @@ mutable struct HipBootstrapKey
     scratch::Vector{UInt64}
     lock::ReentrantLock          # tasks sharing a key take turns from the ccall to the last read of `scratch`
 
-    # random_flatten = true sizes the engine's RNS basis for `rng::AbstractRNG` calls
-    # (SGFHE_CTX_RANDOM_FLATTEN: a sixth prime at Params(1024), nothing elsewhere).
-    function HipBootstrapKey(bkey::BootstrapKey; device::Integer=0, random_flatten::Bool=false)
+    # Both `rng = nothing` and `rng::AbstractRNG` calls work with every key (ABI revision 6: at
+    # Params(1024) the engine keeps a basis per flatten mode).  `random_flatten` is kept for callers
+    # written against revision 5 and has no effect; `deterministic_only = true` asks for the smaller
+    # basis only (SGFHE_CTX_DETERMINISTIC_ONLY: rng calls are then refused at Params(1024)).
+    function HipBootstrapKey(bkey::BootstrapKey; device::Integer=0, random_flatten::Bool=false,
+                             deterministic_only::Bool=false)
         p = bkey.params
-        ctx = create_ctx(p, device, random_flatten)
+        ctx = create_ctx(p, device, random_flatten, deterministic_only)
         # value.(p.coeffs) of every polynomial, order [k][row][col][coef], 2 x UInt64 each
         # (BootstrapKey.key is a Vector of 4x2 Matrix{Polynomial}, src/fhe.jl:176-201).
         canon = Vector{UInt64}(undef, p.n * 8 * p.m * 2)

@@ -50,9 +50,14 @@ def test_bench_line_contract():
     assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["launch_ms"] * 1e-3) / 1e9) < 1e-6 * r["achieved"]
     assert r["whole_job_frac"] > 0
     assert "HIP events" in r["launch_ms_source"]
-    # the committed counters are those of Params(1024): not quoted for another configuration
-    assert r["traffic"] is None and r["traffic_ratio"] is None and r["traffic_note"]
-    assert r["launch_ms_rocprof"] is None
+    # roofline.traffic is measured in the run itself (rocprofv3 --pmc child passes on this box): the HBM
+    # bytes of both launches of an iteration, at least what the kernels must move, with where it came from
+    assert r["traffic"] > 0.5 * r["algorithmic_bytes_per_launch"]
+    assert abs(r["traffic_ratio"] - r["traffic"] / r["algorithmic_bytes_per_launch"]) < 1e-9
+    assert r["traffic_note"].startswith("measured in this run")
+    assert k["k_extprod"]["traffic"] > 0 and k["k_crt_lean"]["traffic"] > 0
+    assert k["k_extprod"]["valu_insts_per_launch"] > 0
+    assert r["launch_ms_rocprof"] is None            # (the committed rocprofv3 trace is Params(1024)'s)
     assert d["config"]["build_id"]
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["value"] > 0 and c["cores_available"] >= c["cores"] >= 1
@@ -90,6 +95,7 @@ def test_host_buffers_run_at_the_device_resident_rate():
 
 def test_bench_flags():
     d = _run("--no-cpu-baseline", "--no-host-io", "--flatten", "random", "--lanes", "1", "--chunk", "64")
+    assert d["roofline"]["traffic"] is None and "counters" in d["roofline"]["traffic_note"]
     assert "cpu_baseline" not in d and "host_io" not in d
     assert "random flatten" in d["config"]["workload"] and d["value"] > 0
     assert d["config"]["lanes"] == 1 and d["config"]["chunk"] == 64

@@ -261,8 +261,8 @@ def test_soak_distinct_inputs_vs_oracle(S, oc, name, count):
         bkey = bench.random_key(p, 32)
         eng.upload_key(bkey)
     bits, a1, b1, a2, b2 = _mixed_inputs(o, sk, p, count, 33)
-    if o.uses_ntt:
-        khat = o.key_transform(bkey, threads=T)
+    if o.uses_ntt or o.uses_rns2:             # NTT-domain loop (for rns2: limb-wise, CRT per column;
+        khat = o.key_transform(bkey, threads=T)   # bit-identical to the reference-shaped loops: test_oracle_properties.py)
         del bkey
         ref = o.bootstrap_batch(khat, a1, b1, a2, b2, threads=T, opt=True)
         del khat

@@ -114,6 +114,30 @@ def test_extract_matches_reference_semantics(S):
             assert got == BO.extract(a, i, n, Q)
 
 
+def test_params_keyword_arguments_of_the_reference(S):
+    """Params(n; rlwe_type, mod_repr) (src/fhe.jl:43-47,71-85): the keywords choose how the reference
+    stores residues, not their values -- same numbers, the reference's assertions (a type too narrow
+    for Q, an unknown representation), the reference's defaults (UInt64 / UInt128 by the size of Q,
+    MgModUInt).  test/performance.test.jl:32,59,86 build Params(64) with MLUInt and both
+    representations."""
+    base = S.Params(64)
+    assert (base.rlwe_type, base.mod_repr) == ("UInt64", "MgModUInt")
+    assert S.Params(512).rlwe_type == "UInt128"
+    for kw in (dict(rlwe_type="UInt128"), dict(rlwe_type="MLUInt{2, UInt64}"), dict(rlwe_type=128),
+               dict(mod_repr="ModUInt"), dict(mod_repr="MgModUInt", rlwe_type="MLUInt{4, UInt32}")):
+        p = S.Params(64, **kw)
+        assert p == base and hash(p) == hash(base)             # values, not representation
+        assert p.rlwe_type == kw.get("rlwe_type", "UInt64") and p.mod_repr == kw.get("mod_repr", "MgModUInt")
+    with pytest.raises(AssertionError):
+        S.Params(512, rlwe_type="UInt64")                      # sizeof(rlwe_type) * 8 > log2(Q), src/fhe.jl:80
+    with pytest.raises(AssertionError):
+        S.Params(64, rlwe_type="MLUInt{1, UInt32}")
+    with pytest.raises(AssertionError):
+        S.Params(64, mod_repr="Montgomery")                    # src/fhe.jl:47
+    with pytest.raises(AssertionError):
+        S.Params(64, rlwe_type="Float64")
+
+
 def test_pack_selects_flatten_mode_and_checks_length(S):
     """pack_encrypted_bits(bkey, rng, enc_bits): a wrong number of bits is the reference's assertion
     (src/fhe.jl:667), raised before the engine is touched; otherwise rng picks the flatten mode on

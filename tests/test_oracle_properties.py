@@ -304,6 +304,43 @@ def test_cpu_opt_variant_is_bit_identical(oc):
         comp.key_transform(np.zeros((8, 4, 2, 64, 2), dtype=np.uint64))
 
 
+def test_cpu_opt_variant_on_the_rns2_ring(oc):
+    """The NTT-domain loop over the RNS2Number ring (src/rns.jl; key held limb-wise, digit polynomials
+    reduced into each limb, limb products put together by the CRT of rns.jl:32-40 per column) against
+    the reference-shaped limb-wise loop and against the schoolbook ring: accumulators, raw and ModRed
+    outputs, both flatten modes.  It is what lets the config-4 soak on the GPU box check 32 distinct
+    bootstraps in a third of the time."""
+    n, m = 16, 128
+    p1 = BO.find_modulus(2 * m, 1 << 25)
+    p2 = BO.find_modulus(2 * m, p1 + 1)
+    Q, B = p1 * p2, p2
+    o = oc.Oracle(n, 16 * n, m, Q, B, Q // 8, rns2=(p2, p1))
+    plain = oc.Oracle(n, 16 * n, m, Q, B, Q // 8)             # composite Q without limbs: schoolbook products
+    assert o.uses_rns2 and not o.uses_ntt and not plain.uses_rns2
+    sk = o.private_key(1)
+    bkey = o.bootstrap_key(sk, 2, noise=2)
+    khat = o.key_transform(bkey)
+    assert khat.shape == (2,) + bkey.shape
+    bits = np.array([1, 0, 1, 1, 0, 0], dtype=np.uint8)
+    a, b = o.lwe_encrypt_bits(sk, bits, 3)
+    lwe = (a[0::2], b[0::2], a[1::2], b[1::2])
+    for rnd in (None, (5, 1, 7)):
+        for it in (1, 2, n):
+            _, acc = o.bootstrap_batch(bkey, *lwe, n_iters=it, want_acc=True, rnd=rnd)
+            _, acc2 = o.bootstrap_batch(khat, *lwe, n_iters=it, want_acc=True, opt=True, rnd=rnd)
+            _, acc3 = plain.bootstrap_batch(bkey, *lwe, n_iters=it, want_acc=True, rnd=rnd)
+            assert np.array_equal(acc, acc2) and np.array_equal(acc, acc3)
+        assert np.array_equal(o.bootstrap_batch(bkey, *lwe, raw=True, rnd=rnd),
+                              o.bootstrap_batch(khat, *lwe, raw=True, opt=True, rnd=rnd))
+        out = o.bootstrap_batch(khat, *lwe, opt=True, rnd=rnd)
+        assert np.array_equal(out, o.bootstrap_batch(bkey, *lwe, rnd=rnd))
+        y1, y2 = bits[0::2], bits[1::2]
+        for g3, fn in enumerate((np.bitwise_and, np.bitwise_or, np.bitwise_xor)):
+            assert np.array_equal(o.lwe_decrypt_bits(sk, out[:, g3, :n], out[:, g3, n]), fn(y1, y2))
+    with pytest.raises(RuntimeError):
+        plain.key_transform(bkey)                              # no NTT and no limbs: refused
+
+
 def test_chacha20_key_stream_vectors(oc):
     """The bootstrap-key generator: RFC 8439 section 2.3.2 block test vector, and the C / Python
     generators produce the same key from an int seed and from 32 explicit bytes."""
