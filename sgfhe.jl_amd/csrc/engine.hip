@@ -699,6 +699,20 @@ int32_t bootstrap_device(sgfhe_ctx *c, const uint64_t *a1, const uint64_t *b1, c
         int32_t rc = fence_begin(c, st);
         if (rc) return rc;
     }
+    // From here on work is queued: should a later step fail, whatever has been queued still ends in
+    // ev_done, so that the next call (or the destructor) waits for it before touching the buffers.
+    struct QueuedWork {
+        sgfhe_ctx *c;
+        hipStream_t st;
+        bool closed = false;
+        ~QueuedWork() {
+            if (closed) return;
+            if (c->lanes == 2) {   // the second lane may hold part of it
+                if (hipEventRecord(c->ev_join, c->stream2) == hipSuccess) (void)hipStreamWaitEvent(st, c->ev_join, 0);
+            }
+            if (hipEventRecord(c->ev_done, st) == hipSuccess) c->pending = true;
+        }
+    } queued{c, st};
     hipEvent_t ecall0 = nullptr, ecall1 = nullptr;
     if (c->timing && c->ev_call.size() < 256) {
         HIPCHK(c, hipEventCreate(&ecall0));
@@ -876,6 +890,7 @@ int32_t bootstrap_device(sgfhe_ctx *c, const uint64_t *a1, const uint64_t *b1, c
     {
         int32_t rc = fence_end(c, st);
         if (rc) return rc;
+        queued.closed = true;
     }
     if (hp_single) {
         HIPCHK(c, hipMemcpyAsync(hp->p_out, hp->d_out, batch * hp->out_row_words * 8, hipMemcpyDeviceToHost, st));
@@ -1304,7 +1319,7 @@ int32_t key_transform_host(sgfhe_ctx *c, const uint64_t *canon, uint32_t npolys,
 
 extern "C" {
 
-const char *sgfhe_version(void) { return "sgfhe_hip 0.3.0 gfx950"; }
+const char *sgfhe_version(void) { return "sgfhe_hip 0.4.0 gfx950"; }
 
 uint32_t sgfhe_abi_version(void) { return SGFHE_ABI_VERSION; }
 

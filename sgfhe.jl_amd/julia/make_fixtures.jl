@@ -43,9 +43,10 @@ function key_words(bkey)
     canon
 end
 
-ints(v) = "[" * join(string.(v), ",") * "]"
-strs(v) = "[" * join(["\"" * string(x) * "\"" for x in v], ",") * "]"
-lwe_r(l) = (UInt64.(value.(l.a)), UInt64(value(l.b)))
+# (unsigned integers print in hexadecimal in Julia: everything goes through BigInt before it is written)
+ints(v) = "[" * join(string.(BigInt.(v)), ",") * "]"
+strs(v) = "[" * join(["\"" * string(BigInt(x)) * "\"" for x in v], ",") * "]"
+lwe_r(l) = (BigInt.(value.(l.a)), BigInt(value(l.b)))
 lwe_Q(l) = (BigInt.(value.(l.a)), BigInt(value(l.b)))
 
 function make(n::Int, outdir::String)
@@ -81,7 +82,7 @@ function make(n::Int, outdir::String)
     sk = Int.(value.(key.key.coeffs))
     json = "{\"generated_by\":\"julia/make_fixtures.jl: SGFHE.jl reference, rng = nothing\"," *
            "\"julia_version\":\"$(VERSION)\"," *
-           "\"params\":{\"n\":$(params.n),\"r\":$(params.r),\"m\":$(params.m)," *
+           "\"params\":{\"n\":$(Int(params.n)),\"r\":$(Int(params.r)),\"m\":$(Int(params.m))," *
            "\"Q\":\"$(BigInt(params.Q))\",\"B\":\"$(BigInt(params.B))\",\"DQ_tilde\":\"$(BigInt(params.DQ_tilde))\"}," *
            "\"sk\":$(ints(sk)),\"key_file\":\"$(keyfile)\",\"key_sha256\":\"$(key_sha)\"," *
            "\"cases\":[" * join(cases, ",") * "]}"
