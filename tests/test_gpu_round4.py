@@ -242,7 +242,8 @@ def test_soak_distinct_inputs_vs_oracle(S, oc, name, count):
     every rotation amount occurs, plus encryptions of all four bit pairs) tiled to a full batch so
     that the default schedule (two lanes of full chunks) runs; every output word of every copy
     against the C restatement; the encryption pairs decrypt to the truth table.  config 4 (rns2:
-    composite Q = B Bp) goes through the restatement's RNS2Number mode (src/rns.jl)."""
+    composite Q = B Bp) goes through the restatement's RNS2Number mode (src/rns.jl).  Then the same
+    batch in the randomised flatten mode (bootstrap(bkey, rng, ...)), 32 rows of it pinned."""
     import bench
     p = bench.make_params(S, name)
     T = _threads()
@@ -261,14 +262,10 @@ def test_soak_distinct_inputs_vs_oracle(S, oc, name, count):
         bkey = bench.random_key(p, 32)
         eng.upload_key(bkey)
     bits, a1, b1, a2, b2 = _mixed_inputs(o, sk, p, count, 33)
-    if o.uses_ntt or o.uses_rns2:             # NTT-domain loop (for rns2: limb-wise, CRT per column;
-        khat = o.key_transform(bkey, threads=T)   # bit-identical to the reference-shaped loops: test_oracle_properties.py)
-        del bkey
-        ref = o.bootstrap_batch(khat, a1, b1, a2, b2, threads=T, opt=True)
-        del khat
-    else:
-        ref = o.bootstrap_batch(bkey, a1, b1, a2, b2, threads=T)
-        del bkey
+    assert o.uses_ntt or o.uses_rns2
+    khat = o.key_transform(bkey, threads=T)       # NTT-domain loop (for rns2: limb-wise, CRT per column;
+    del bkey                                      # bit-identical to the reference-shaped loops: test_oracle_properties.py)
+    ref = o.bootstrap_batch(khat, a1, b1, a2, b2, threads=T, opt=True)
     full = 4096 if name != "params512" else 1024             # BASELINE.json's batch of each configuration
     idx = np.random.default_rng(35).permutation(np.resize(np.arange(count), full))
     out = eng.bootstrap_batch(a1[idx], b1[idx], a2[idx], b2[idx])
@@ -279,6 +276,20 @@ def test_soak_distinct_inputs_vs_oracle(S, oc, name, count):
         y1, y2 = bits[0::2], bits[1::2]
         for g, fn in enumerate((np.bitwise_and, np.bitwise_or, np.bitwise_xor)):
             assert np.array_equal(o.lwe_decrypt_bits(sk, ref[:k, g, :p.n], ref[:k, g, p.n]), fn(y1, y2))
+    # the randomised flatten on the same ring, key and batch (Params(1024) has its own tests above): every
+    # row draws at its own index in the call, so 32 rows spread over the chunks of both lanes are pinned
+    # word for word to the C restatement run at those stream indices
+    if name != "params1024":
+        eng.set_random_flatten(True, FKEY)
+        out_r = eng.bootstrap_batch(a1[idx], b1[idx], a2[idx], b2[idx])           # call 0
+        rows = np.unique(np.concatenate([[0, full - 1], np.random.default_rng(36).choice(full, size=30, replace=False)]))
+        src = idx[rows]
+        ref_r = o.bootstrap_batch(khat, a1[src], b1[src], a2[src], b2[src], threads=T, opt=True,
+                                  rnd=(FKEY, 0, rows.astype(np.uint32)))
+        assert np.array_equal(out_r[rows], ref_r)
+        assert not np.array_equal(out_r[rows], out[rows])
+        eng.set_random_flatten(False)
+        assert np.array_equal(eng.bootstrap_batch(a1[idx[:8]], b1[idx[:8]], a2[idx[:8]], b2[idx[:8]]), ref[idx[:8]])
     eng.close()
 
 

@@ -280,11 +280,39 @@ int main() {
     const uint32_t quads = 2 * M / 4;
     const double cf = chain_us([&] { hipLaunchKernelGGL((k_crt_loads<5, false>), dim3((quads + 255) / 256), dim3(256), 0, 0, d_y, d_dig, d_pk, quads); }, iters);
     const double cs = chain_us([&] { hipLaunchKernelGGL((k_crt_loads<5, true>), dim3((quads + 255) / 256), dim3(256), 0, 0, d_y, d_dig, d_pk, quads); }, iters);
+    // ---- where the in-situ launches lose their time: the engine's k_fwd_phase / k_inv_column take 11.3 /
+    // 9.3 us inside the k-loop (rocprofv3) where the same code takes 4-6 us in the chains above.  The
+    // chains above repeat ONE kernel on ONE key slice; the k-loop alternates three kernels and walks
+    // through a 1.34 GB key.  Mixed chains: (a) the three kernels alternating on one key slice, (b) the
+    // same with the key slice advancing by its 1.3 MB every iteration through a 1.34 GB buffer.
+    int32_t *d_bigkey = nullptr;
+    const size_t slice = (size_t)npr * 8 * M;             // int32 elements per key slice
+    const size_t nslices = 1024;
+    double mix_hot = 0, mix_cold = 0;
+    if (hipMalloc(&d_bigkey, nslices * slice * 4) == hipSuccess) {
+        (void)hipMemset(d_bigkey, 3, nslices * slice * 4);
+        size_t kk = 0;
+        auto iter_hot = [&] {
+            hipLaunchKernelGGL(k_fwd_full, dim3(npr * 4), dim3(1024), 4 * M, 0, d_dig, d_key, d_z, d_pk);
+            hipLaunchKernelGGL(k_inv_full, dim3(npr * 2), dim3(1024), 4 * M, 0, d_z, d_y, d_pk, 77u);
+            hipLaunchKernelGGL((k_crt_loads<5, false>), dim3((quads + 255) / 256), dim3(256), 0, 0, d_y, d_dig, d_pk, quads);
+        };
+        auto iter_cold = [&] {
+            hipLaunchKernelGGL(k_fwd_full, dim3(npr * 4), dim3(1024), 4 * M, 0, d_dig, d_bigkey + (kk++ % nslices) * slice, d_z, d_pk);
+            hipLaunchKernelGGL(k_inv_full, dim3(npr * 2), dim3(1024), 4 * M, 0, d_z, d_y, d_pk, 77u);
+            hipLaunchKernelGGL((k_crt_loads<5, false>), dim3((quads + 255) / 256), dim3(256), 0, 0, d_y, d_dig, d_pk, quads);
+        };
+        mix_hot = chain_us(iter_hot, 1024);
+        mix_cold = chain_us(iter_cold, 1024);
+        (void)hipFree(d_bigkey);
+    }
     printf("dependent chains of %d launches, one gate, five primes, m = 8192 (us per launch)\n", iters);
     printf("forward : full (20 x 1024 threads) %.2f   split (80 x 256 threads, 2048 points each) %.2f   saves %.2f\n", ff, fs, ff - fs);
     printf("inverse : full (10 x 1024 threads) %.2f   split (40 x 256 threads + diagonal product) %.2f   saves %.2f\n", vf, vs, vf - vs);
     printf("CRT side: one residue per prime %.2f   four partial residues + radix-4 combination %.2f   costs %.2f\n", cf, cs, cs - cf);
     printf("per k-loop iteration: %.2f us saved of the three launches; x 1024 iterations = %.2f ms of a 24-25 ms call\n",
            (ff - fs) + (vf - vs) - (cs - cf), ((ff - fs) + (vf - vs) - (cs - cf)) * 1.024);
+    printf("mixed chain (forward, inverse, CRT alternating), us per iteration: one key slice %.2f (sum of the three "
+           "chains above %.2f), key slice advancing through 1.34 GB %.2f\n", mix_hot, ff + vf + cf, mix_cold);
     return 0;
 }
