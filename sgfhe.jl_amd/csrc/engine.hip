@@ -153,6 +153,11 @@ struct sgfhe_ctx {
         int32_t *zpart = nullptr;  // small-batch form only: [cap_small][npr][4][2][m]
     } lane[2];
     bool use_lean = true;     // SGFHE_CRT_LEAN=0 in the environment: keep k_crt_acc2 (A/B measurements)
+    bool small_padded = false;  // SGFHE_SMALL_PADDED=1: small-batch grids padded to 8 bootstraps as up to round 3 (A/B)
+    uint32_t crt1_max = 0;      // k_crt_lean launches of at most this many coefficients take one per thread
+                                // (SGFHE_CRT1_GATES gates' worth: default 8; 0 = never.  Same call, 1 / 2 / 4 / 8
+                                // gates: 18.6 / 19.4 / 20.8 / 23.9 ms with four per thread, 17.9 / 18.6 / 20.2 / 23.4
+                                // with one, profiles/r04_exp_crt1.txt)
     uint32_t small_max = 24;  // chunks of at most this many bootstraps take the small-batch form
                               // (measured crossover at Params(1024): 24 -> 32.3 vs 40.9 ms, 32 -> 44.0 vs 42.3 ms)
     // staging buffers of the host-pointer entry point (sgfhe_bootstrap_batch: the drop-in signature of
@@ -450,6 +455,16 @@ int32_t launch_dbgntt(sgfhe_ctx *c, const uint32_t *in, uint32_t *out, uint32_t 
 #define SGFHE_FOR_NPR(X) X(2) X(3) X(4) X(5) X(6) X(7)
 template <int NP>
 void launch_crt_lean_t(sgfhe_ctx *c, const uint32_t *yres, uint64_t *dig, uint32_t total, hipStream_t st) {
+    // a handful of gates (the latency form): one coefficient per thread, four times the threads
+    if (total <= c->crt1_max) {
+        const dim3 grid1((total + 255) / 256), block1(256);
+        switch (c->h_lean.nl) {
+        case 2: hipLaunchKernelGGL((k_crt_lean1<NP, 2>), grid1, block1, 0, st, yres, dig, c->d_lean, total, (uint32_t)c->logm); break;
+        case 3: hipLaunchKernelGGL((k_crt_lean1<NP, 3>), grid1, block1, 0, st, yres, dig, c->d_lean, total, (uint32_t)c->logm); break;
+        default: hipLaunchKernelGGL((k_crt_lean1<NP, 4>), grid1, block1, 0, st, yres, dig, c->d_lean, total, (uint32_t)c->logm); break;
+        }
+        return;
+    }
     const dim3 grid((total / 4 + 255) / 256), block(256);
     switch (c->h_lean.nl) {
     case 2: hipLaunchKernelGGL((k_crt_lean<NP, 2>), grid, block, 0, st, yres, dig, c->d_lean, total / 4, (uint32_t)c->logm); break;
@@ -613,11 +628,14 @@ int32_t run_iterations(sgfhe_ctx *c, ChunkJob *jobs, int njobs, uint64_t n_iters
                 HIPCHK(c, hipEventCreate(&e2));
                 HIPCHK(c, hipEventRecord(e0, J.st));
             }
-            int32_t rc = small ? launch_small(c, *J.L, c->d_key + k * slice, J.cpad, (uint32_t)k, mode, J.st)
+            // (the small-batch kernels index bootstraps directly: no padding to a multiple of 8, which is
+            // k_extprod's XCD mapping's; a one-gate call then runs one gate's workgroups, not eight's)
+            const uint32_t cnt = small && !c->small_padded ? J.cb : J.cpad;
+            int32_t rc = small ? launch_small(c, *J.L, c->d_key + k * slice, cnt, (uint32_t)k, mode, J.st)
                                : launch_extprod(c, *J.L, c->d_key + k * slice, J.cpad, (uint32_t)k, mode, J.st);
             if (rc) return rc;
             if (sample) HIPCHK(c, hipEventRecord(e1, J.st));
-            rc = launch_crt(c, *J.L, J.cpad, mode, J.st, J.ra, (uint32_t)k + 1);
+            rc = launch_crt(c, *J.L, cnt, mode, J.st, J.ra, (uint32_t)k + 1);
             if (rc) return rc;
             if (sample) {
                 HIPCHK(c, hipEventRecord(e2, J.st));
@@ -1190,6 +1208,10 @@ int32_t build_constants(sgfhe_ctx *c) {
         c->use_lean = !(env && env[0] == '0');
         env = getenv("SGFHE_HOST_PIN");
         c->use_pin = !(env && env[0] == '0');
+        env = getenv("SGFHE_SMALL_PADDED");
+        c->small_padded = env && env[0] == '1';
+        env = getenv("SGFHE_CRT1_GATES");
+        c->crt1_max = (uint32_t)(env ? atoi(env) : 8) * 2u * c->M;
     }
     HIPCHK(c, hipMalloc(&c->d_tw, (size_t)c->npr_max * 4 * c->M * sizeof(int32_t)));
     HIPCHK(c, hipMalloc(&c->d_bad, sizeof(uint32_t)));

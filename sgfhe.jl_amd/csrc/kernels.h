@@ -941,6 +941,28 @@ k_crt_lean(const uint32_t *__restrict__ yres, uint64_t *__restrict__ dig,
                                                (uint32_t)(nhi[2] >> 32) | ((uint32_t)(nhi[3] >> 32) << 16)));
 }
 
+// The same with ONE coefficient per thread, for the latency form of the k-loop (a call of a few gates):
+// there the kernel is a dependent link of the launch chain, one wave per SIMD, and what counts is the
+// length of a thread's instruction stream (117 instead of 468), not the width of its memory accesses.
+template <int NP, int NL>
+__global__ void __launch_bounds__(256)
+k_crt_lean1(const uint32_t *__restrict__ yres, uint64_t *__restrict__ dig,
+            const CrtLean *__restrict__ K, uint32_t total, uint32_t logm) {
+    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= total) return;
+    const uint32_t M = 1u << logm;
+    const uint32_t i = t & (M - 1);
+    const uint32_t bc = t >> logm;
+    const uint32_t yo = 4u * ((bc * NP << logm) + i);
+    uint32_t y[NP];
+#pragma unroll
+    for (int q = 0; q < NP; q++) y[q] = ld_off<uint32_t>(yres, yo + ((uint32_t)(4 * q) << logm));
+    const ulonglong2 d = load_digits(dig, bc, i, M);
+    uint64_t lo, hi;
+    crt_lean_one<NP, NL>(y, d.x, d.y, K, lo, hi);
+    store_digits(dig, bc, i, M, lo, hi);
+}
+
 // The randomised flatten (utils.jl:198-241; random_digits above) through the same limb sums.  With
 // r_i the draws in [0, 2 xmax] and (e_lo, e_hi) the old stored digits, the value to flatten is
 //   x2 = (x_old + D - r_0 - r_1 B) mod Q,   x_old == e_hi B + e_lo  (mod Q),
