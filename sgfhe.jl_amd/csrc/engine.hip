@@ -628,6 +628,9 @@ int32_t run_iterations(sgfhe_ctx *c, ChunkJob *jobs, int njobs, uint64_t n_iters
                 HIPCHK(c, hipEventCreate(&e2));
                 HIPCHK(c, hipEventRecord(e0, J.st));
             }
+            // (Round 4 also tried warming the next iteration's key slice from a second stream, one iteration
+            // ahead, with k_fwd_phase's own workgroup -> XCD mapping: 18.06 / 19.01 / 20.85 ms against 17.94 /
+            // 18.80 / 20.24 for 1 / 2 / 4 gates, no gain, profiles/r04_exp_prefetch.txt.)
             // (the small-batch kernels index bootstraps directly: no padding to a multiple of 8, which is
             // k_extprod's XCD mapping's; a one-gate call then runs one gate's workgroups, not eight's)
             const uint32_t cnt = small && !c->small_padded ? J.cb : J.cpad;
