@@ -125,7 +125,13 @@ struct sgfhe_ctx {
     PrimeK *d_primes = nullptr;
     CrtConst *d_crt = nullptr;
     uint32_t *d_bad = nullptr;  // set by k_key_transform when a key residue is >= Q
-    int32_t *d_tw = nullptr;  // npr * 2 * M entries
+    int32_t *d_tw = nullptr;  // npr * 4 * M entries
+    int32_t *d_twq = nullptr; // quarter form of the latency kernels: per prime 4 blocks [f_q | v_q | fp_q | vp_q] of m / 4 words
+    int32_t *d_pow = nullptr; //   and psi^e * R mod p, e in [0, 2 m)
+    int32_t tw_head[NPR_MAX][8] = {};   // f[1..3], fp[2], fp[3], v[1..3] of every prime (PrimeK::f1 ... v3)
+    uint32_t split_max = 7;   // calls of at most this many gates take the quarter form (SGFHE_SMALL_SPLIT, 0 = never):
+                              // 1 / 2 / 4 / 6 / 8 gates 15.1 / 15.9 / 17.8 / 19.7 / 23.5 ms against 17.9 / 18.6 / 20.3 /
+                              // 22.0 / 23.3 with one workgroup per transform (profiles/r04_exp_quarter.txt)
     CrtConst h_crt;
     CrtLean *d_lean = nullptr;  // constants of k_crt_lean (nl = 0: this parameter set keeps k_crt_acc)
     CrtLean h_lean;
@@ -366,6 +372,34 @@ int32_t launch_small(sgfhe_ctx *c, const sgfhe_ctx::Lane &L, const int32_t *keyk
     return fail(c, SGFHE_ERR_UNSUPPORTED, "unsupported log2(m)");
 }
 
+// The quarter form of the two transform kernels (kernels.h k_fwd_quarter / k_inv_quarter), m >= 4096.
+template <int LOGM>
+int32_t launch_quarter_t(sgfhe_ctx *c, const sgfhe_ctx::Lane &L, const int32_t *keyk, uint32_t cnt,
+                         uint32_t k, hipStream_t st) {
+    if constexpr (LOGM >= 12) {
+        constexpr int LE = 3;
+        constexpr int TH = NttGeom<LOGM - 2, LE>::T;
+        const size_t lds = lds_bytes(LOGM - 2, 1);
+        hipLaunchKernelGGL((k_fwd_quarter<LOGM, LE>), dim3(cnt * c->npr * 16), dim3(TH), lds, st, L.dig, keyk,
+                           L.zpart, c->d_primes);
+        hipLaunchKernelGGL((k_inv_quarter<LOGM, LE>), dim3(cnt * c->npr * 8), dim3(TH), lds, st, L.zpart,
+                           reinterpret_cast<int32_t *>(L.yres), L.ua, c->d_primes, k, c->n);
+        HIPCHK(c, hipGetLastError());
+        return SGFHE_OK;
+    } else {
+        return fail(c, SGFHE_ERR_UNSUPPORTED, "quarter form needs m >= 4096");
+    }
+}
+int32_t launch_quarter(sgfhe_ctx *c, const sgfhe_ctx::Lane &L, const int32_t *keyk, uint32_t cnt, uint32_t k,
+                       hipStream_t st) {
+    switch (c->logm) {
+#define X(LM) case LM: return launch_quarter_t<LM>(c, L, keyk, cnt, k, st);
+        SGFHE_FOR_LOGM(X)
+#undef X
+    }
+    return fail(c, SGFHE_ERR_UNSUPPORTED, "unsupported log2(m)");
+}
+
 template <int LOGM>
 int32_t launch_shortprod_t(sgfhe_ctx *c, const uint64_t *pdig, uint32_t *yg, uint32_t count,
                            uint32_t G, uint32_t groups, uint32_t mode, hipStream_t st) {
@@ -518,6 +552,28 @@ int32_t launch_crt(sgfhe_ctx *c, const sgfhe_ctx::Lane &L, uint32_t cpad, uint32
     return launch_crt_raw(c, L.yres, L.dig, cpad * 2 * c->M, mode, st, ra, iter);
 }
 
+// CRT kernel of the quarter form: partial residues in, the last two inverse stages inside
+int32_t launch_crt_quarter(sgfhe_ctx *c, const sgfhe_ctx::Lane &L, uint32_t cnt, hipStream_t st) {
+    const uint32_t total = cnt * 2 * c->M;
+    const dim3 grid((total + 255) / 256), block(256);
+    const int32_t *yp = reinterpret_cast<const int32_t *>(L.yres);
+    switch (c->npr) {
+#define X(NP)                                                                                                     \
+    case NP:                                                                                                      \
+        switch (c->h_lean.nl) {                                                                                   \
+        case 2: hipLaunchKernelGGL((k_crt_lean1q<NP, 2>), grid, block, 0, st, yp, L.dig, c->d_primes, c->d_lean, total, (uint32_t)c->logm); break; \
+        case 3: hipLaunchKernelGGL((k_crt_lean1q<NP, 3>), grid, block, 0, st, yp, L.dig, c->d_primes, c->d_lean, total, (uint32_t)c->logm); break; \
+        default: hipLaunchKernelGGL((k_crt_lean1q<NP, 4>), grid, block, 0, st, yp, L.dig, c->d_primes, c->d_lean, total, (uint32_t)c->logm); break; \
+        }                                                                                                         \
+        break;
+        SGFHE_FOR_NPR(X)
+#undef X
+    default: return fail(c, SGFHE_ERR_UNSUPPORTED, "unsupported number of RNS primes");
+    }
+    HIPCHK(c, hipGetLastError());
+    return SGFHE_OK;
+}
+
 // ---- buffers ------------------------------------------------------------------------------------
 
 uint32_t round_up8(uint32_t x) { return (x + 7u) & ~7u; }
@@ -634,11 +690,16 @@ int32_t run_iterations(sgfhe_ctx *c, ChunkJob *jobs, int njobs, uint64_t n_iters
             // (the small-batch kernels index bootstraps directly: no padding to a multiple of 8, which is
             // k_extprod's XCD mapping's; a one-gate call then runs one gate's workgroups, not eight's)
             const uint32_t cnt = small && !c->small_padded ? J.cb : J.cpad;
-            int32_t rc = small ? launch_small(c, *J.L, c->d_key + k * slice, cnt, (uint32_t)k, mode, J.st)
-                               : launch_extprod(c, *J.L, c->d_key + k * slice, J.cpad, (uint32_t)k, mode, J.st);
+            // a few gates, deterministic flatten, m >= 4096: each transform cut across four workgroups
+            const bool quarter = small && mode == 0u && c->logm >= 12 && cnt <= c->split_max &&
+                                 c->h_lean.nl != 0 && c->use_lean;
+            int32_t rc = quarter ? launch_quarter(c, *J.L, c->d_key + k * slice, cnt, (uint32_t)k, J.st)
+                         : small ? launch_small(c, *J.L, c->d_key + k * slice, cnt, (uint32_t)k, mode, J.st)
+                                 : launch_extprod(c, *J.L, c->d_key + k * slice, J.cpad, (uint32_t)k, mode, J.st);
             if (rc) return rc;
             if (sample) HIPCHK(c, hipEventRecord(e1, J.st));
-            rc = launch_crt(c, *J.L, cnt, mode, J.st, J.ra, (uint32_t)k + 1);
+            rc = quarter ? launch_crt_quarter(c, *J.L, cnt, J.st)
+                         : launch_crt(c, *J.L, cnt, mode, J.st, J.ra, (uint32_t)k + 1);
             if (rc) return rc;
             if (sample) {
                 HIPCHK(c, hipEventRecord(e2, J.st));
@@ -1080,7 +1141,7 @@ int32_t build_basis(sgfhe_ctx *c, uint32_t npr, const uint32_t *cand_primes, dou
     // twiddle tables and per-prime constants (all residues centred: |.| <= (p - 1) / 2)
     // per prime four tables of m entries: forward twiddles, inverse twiddles, and at + 2 m from each the
     // product twiddles of the radix-4 steps (ntt.h fwd_step4): twp[j] = +-tw[j >> 1] tw[j], minus for odd j
-    std::vector<int32_t> tw((size_t)NPR * 4 * M);
+    std::vector<int32_t> tw((size_t)NPR * 4 * M), twq, pwt;
     std::vector<PrimeK> pk(NPR);
     cc.npr = npr;
     for (int i = 0; i < NPR; i++) {
@@ -1113,6 +1174,33 @@ int32_t build_basis(sgfhe_ctx *c, uint32_t npr, const uint32_t *cand_primes, dou
             fp[j] = centre32((j & 1) ? (p - a) % p : a, p);
             vp[j] = centre32((j & 1) ? (p - b) % p : b, p);
         }
+        // quarter form of the latency kernels: after the first two Cooley-Tukey stages quarter q of the
+        // array runs on the sub-tree of the twiddle table rooted at entry 4 + q, so its tables are a
+        // re-indexing of the big ones: entry mm' + i' (mm' a power of two, i' < mm') = big entry
+        // 4 mm' + q mm' + i'; the same for the inverse and for both product tables
+        if (M >= 16) {
+            const uint32_t MS = M / 4;
+            twq.assign((size_t)4 * M, 0);
+            for (uint32_t q = 0; q < 4; q++)
+                for (uint32_t jj = 1; jj < MS; jj++) {
+                    const uint32_t mmq = 1u << (31 - __builtin_clz(jj)), J = 4 * mmq + q * mmq + (jj - mmq);
+                    int32_t *blk = twq.data() + (size_t)q * M;
+                    blk[jj] = f[J];
+                    blk[MS + jj] = v[J];
+                    blk[2 * MS + jj] = jj >= 2 ? fp[J] : 0;
+                    blk[3 * MS + jj] = jj >= 2 ? vp[J] : 0;
+                }
+            HIPCHK(c, hipMemcpy(c->d_twq + (size_t)(4 * i) * M, twq.data(), (size_t)4 * M * sizeof(int32_t), hipMemcpyHostToDevice));
+        }
+        {   // psi^e R mod p, centred
+            pwt.resize((size_t)2 * M);
+            uint32_t pe = 1;
+            for (uint32_t e = 0; e < 2 * M; e++) { pwt[e] = centre32(mulmod32(pe, R1m, p), p); pe = mulmod32(pe, psi, p); }
+            HIPCHK(c, hipMemcpy(c->d_pow + (size_t)(2 * i) * M, pwt.data(), (size_t)2 * M * sizeof(int32_t), hipMemcpyHostToDevice));
+        }
+        const int32_t head[8] = {f[1], M > 2 ? f[2] : 0, M > 2 ? f[3] : 0, M > 2 ? fp[2] : 0, M > 2 ? fp[3] : 0,
+                                 v[1], M > 2 ? v[2] : 0, M > 2 ? v[3] : 0};
+        memcpy(c->tw_head[i], head, sizeof head);
         }
         PrimeK &P = pk[i];
         memset(&P, 0, sizeof P);
@@ -1145,6 +1233,11 @@ int32_t build_basis(sgfhe_ctx *c, uint32_t npr, const uint32_t *cand_primes, dou
         P.twf = c->d_tw + (size_t)(4 * i) * M;
         P.twi = c->d_tw + (size_t)(4 * i + 1) * M;
         P.npr = npr;
+        P.f1 = c->tw_head[i][0]; P.f2 = c->tw_head[i][1]; P.f3 = c->tw_head[i][2];
+        P.fp2 = c->tw_head[i][3]; P.fp3 = c->tw_head[i][4];
+        P.v1 = c->tw_head[i][5]; P.v2 = c->tw_head[i][6]; P.v3 = c->tw_head[i][7];
+        P.twq = c->d_twq + (size_t)(4 * i) * M;
+        P.pw = c->d_pow + (size_t)(2 * i) * M;
     }
     if (c->tw_done < npr) {
         const size_t off = (size_t)c->tw_done * 4 * M;
@@ -1217,6 +1310,12 @@ int32_t build_constants(sgfhe_ctx *c) {
         c->crt1_max = (uint32_t)(env ? atoi(env) : 8) * 2u * c->M;
     }
     HIPCHK(c, hipMalloc(&c->d_tw, (size_t)c->npr_max * 4 * c->M * sizeof(int32_t)));
+    HIPCHK(c, hipMalloc(&c->d_twq, (size_t)c->npr_max * 4 * c->M * sizeof(int32_t)));
+    HIPCHK(c, hipMalloc(&c->d_pow, (size_t)c->npr_max * 2 * c->M * sizeof(int32_t)));
+    {
+        const char *env = getenv("SGFHE_SMALL_SPLIT");
+        if (env) c->split_max = (uint32_t)atoi(env);
+    }
     HIPCHK(c, hipMalloc(&c->d_bad, sizeof(uint32_t)));
     HIPCHK(c, hipMemset(c->d_bad, 0, sizeof(uint32_t)));
     // the larger basis first: its pass puts every prime's twiddle tables on the device
@@ -1446,6 +1545,8 @@ int32_t sgfhe_ctx_destroy(sgfhe_ctx *c) {
     if (c->pin_out) (void)hipHostFree(c->pin_out);
     if (c->d_bad) (void)hipFree(c->d_bad);
     if (c->d_tw) (void)hipFree(c->d_tw);
+    if (c->d_twq) (void)hipFree(c->d_twq);
+    if (c->d_pow) (void)hipFree(c->d_pow);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return SGFHE_OK;

@@ -41,6 +41,11 @@ struct PrimeK {
     const int32_t *twf;  // forward twiddles psi^bitrev(i) * R mod p (Montgomery form, centred)
     const int32_t *twi;  // inverse twiddles psi^-bitrev(i) * R mod p
     uint32_t npr;     // number of primes of the ctx (the same in every record)
+    // quarter form of the latency kernels (k_fwd_quarter / k_inv_quarter / k_crt_lean1q):
+    int32_t f1, f2, f3, fp2, fp3;   // forward twiddles of the first two stages: twf[1..3], and the products twf[2 m + 2], [2 m + 3]
+    int32_t v1, v2, v3;             // inverse twiddles of the last two stages: twi[1..3]
+    const int32_t *twq;  // twiddle tables of the four quarter transforms: block q = [f_q | v_q | fp_q | vp_q], m / 4 words each
+    const int32_t *pw;   // psi^e * R mod p, centred, e in [0, 2 m): (x^j - 1) in the NTT domain is psi^(j (2 brv(s) + 1)) - 1 at slot s
 };
 __device__ __forceinline__ Mod mod_of(const PrimeK &P) { return Mod{P.p, -P.p, P.pinv}; }
 
@@ -1148,6 +1153,161 @@ k_inv_column(const int32_t *__restrict__ zpart, uint32_t *__restrict__ yres,
         const int32_t vs = (he & E) ? -v : v;  // x^m = -1
         yb[tid + T * e] = (uint32_t)(vs - z[0][e]) + yoff;
     }
+}
+
+// ---- quarter form of the latency kernels (round 4) ------------------------------------------------------
+// A call of a few gates is a dependent chain of 3 n launches, each a handful of workgroups on an
+// otherwise idle device: what counts is the length of one workgroup's work.  Here each transform of
+// m points is cut across four workgroups of m / 32 threads:
+//   k_fwd_quarter  (bootstrap, prime, key row, quarter q): reads all four quarters of the digit plane,
+//                  forms quarter q of the first two Cooley-Tukey stages (one radix-4 combination per
+//                  point: the arithmetic of ntt.h fwd_step4), runs the remaining log2(m) - 2 stages as
+//                  an (m / 4)-point transform on the twiddle sub-tree of that quarter (tables twq), and
+//                  multiplies with its quarter of the two key polynomials             -> zpart (unchanged layout)
+//   k_inv_quarter  (bootstrap, prime, column, quarter q): sums the four partial products of its slots,
+//                  applies (x^j - 1) in the NTT domain -- slot s holds the value at psi^(2 brv(s) + 1), so
+//                  the factor is psi^(j (2 brv(s) + 1)) - 1, from a table of psi powers -- and runs the first
+//                  log2(m) - 2 Gentleman-Sande stages on its quarter                   -> ypart[...][q][m / 4]
+//   k_crt_lean1q   one thread per coefficient: the last two inverse stages (a radix-4 combination of the
+//                  four partial values per prime, only the output this coefficient needs), then the CRT /
+//                  accumulate / flatten of k_crt_lean1.
+// No rotation epilogue, no LDS exchange for it, a quarter of the butterflies per workgroup.  Deterministic
+// flatten, m >= 4096, up to `split_max` gates (engine.hip); same residues, same digits, same bytes.
+template <int LOGM, int LE>
+__global__ void __launch_bounds__((NttGeom<LOGM - 2, LE>::T))
+k_fwd_quarter(const uint64_t *__restrict__ dig, const int32_t *__restrict__ keyk,
+              int32_t *__restrict__ zpart, PrimeSet PS) {
+    constexpr int LS = LOGM - 2;
+    using G = NttGeom<LS, LE>;
+    constexpr int M = 1 << LOGM, MS = G::M, T = G::T, E = G::E;
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const int tid = threadIdx.x;
+    const uint32_t npr = PS[0].npr;
+    const uint32_t q = blockIdx.x & 3u, ph = (blockIdx.x >> 2) & 3u;
+    const uint32_t pi = (blockIdx.x >> 4) % npr, b = (blockIdx.x >> 4) / npr;
+    const PrimeK P = PS[pi];
+    const Mod md = mod_of(P);
+    const uint32_t *dl = digit_lo_plane(dig, (size_t)b * 2 + (ph >> 1), M) + (ph & 1) * M;
+    const uint16_t *dh = digit_hi_plane(dig, (size_t)b * 2 + (ph >> 1), M) + (ph & 1) * M;
+    // quarter q of the first two stages: with X0..X3 the coefficients i, i + m/4, i + m/2, i + 3m/4,
+    //   u = f1 X2;  q < 2: (X0 + u) +- (f2 X1 + fp2 X3);  q >= 2: (X0 - u) +- (f3 X1 + fp3 X3)
+    const int32_t wB = (q & 2) ? P.f3 : P.f2, wP = (q & 2) ? P.fp3 : P.fp2;
+    int32_t x[1][E];
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+        const uint32_t i = (uint32_t)tid + (uint32_t)(T * e);
+        int32_t X[4];
+#pragma unroll
+        for (int t = 0; t < 4; t++)
+            X[t] = digit_reduce(dl[i + t * MS] | ((uint64_t)dh[i + t * MS] << 32), md, P.sR);   // |.| <= p + 2^16
+        const int32_t u = smont(X[2], P.f1, md);                                              // < 0.57 * 2^29
+        const int32_t a = (q & 2) ? X[0] - u : X[0] + u;
+        const int32_t w = sredc((int64_t)X[1] * wB + (int64_t)X[3] * wP, md);                   // < 0.63 * 2^29
+        x[0][e] = sred_floor((q & 1) ? a - w : a + w, md);                                    // [0, p]
+    }
+    ntt_forward<LS, 1, LE>(x, lds, P.twq + (size_t)q * M, tid, md);
+    const int32_t *kp = keyk + ((size_t)pi * 8 + ph * 2) * M + q * MS + E * tid;
+    int32_t *zp = zpart + ((((size_t)b * npr + pi) * 4 + ph) * 2) * M + q * MS + E * tid;
+#pragma unroll
+    for (int h = 0; h < E / 4; h++) {
+        const int4 a = reinterpret_cast<const int4 *>(kp)[h];
+        const int4 bq = reinterpret_cast<const int4 *>(kp + M)[h];
+        const int32_t ka[4] = {a.x, a.y, a.z, a.w};
+        const int32_t kb[4] = {bq.x, bq.y, bq.z, bq.w};
+        int32_t r0[4], r1[4];
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const int32_t u = x[0][4 * h + t];
+            r0[t] = smont(u, ka[t], md);  // |.| < 0.74 * 2^29
+            r1[t] = smont(u, kb[t], md);
+        }
+        reinterpret_cast<int4 *>(zp)[h] = make_int4(r0[0], r0[1], r0[2], r0[3]);
+        reinterpret_cast<int4 *>(zp + M)[h] = make_int4(r1[0], r1[1], r1[2], r1[3]);
+    }
+}
+
+template <int LOGM, int LE>
+__global__ void __launch_bounds__((NttGeom<LOGM - 2, LE>::T))
+k_inv_quarter(const int32_t *__restrict__ zpart, int32_t *__restrict__ ypart,
+              const uint32_t *__restrict__ ua, PrimeSet PS, uint32_t k, uint32_t n) {
+    constexpr int LS = LOGM - 2;
+    using G = NttGeom<LS, LE>;
+    constexpr int M = 1 << LOGM, MS = G::M, T = G::T, E = G::E;
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const int tid = threadIdx.x;
+    const uint32_t npr = PS[0].npr;
+    const uint32_t q = blockIdx.x & 3u, c = (blockIdx.x >> 2) & 1u;
+    const uint32_t pi = (blockIdx.x >> 3) % npr, b = (blockIdx.x >> 3) / npr;
+    const PrimeK P = PS[pi];
+    const Mod md = mod_of(P);
+    const uint32_t j = ua[(size_t)b * n + k];
+    // the factor of slot s = q m/4 + E tid + e: psi^(j (2 brv(s) + 1) mod 2m) - 1, requested first (a gather)
+    int32_t dfac[E];
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+        const uint32_t sl = q * (uint32_t)MS + (uint32_t)(E * tid + e);
+        const uint32_t br = __brev(sl) >> (32 - LOGM);
+        dfac[e] = P.pw[(j * (2u * br + 1u)) & (2u * M - 1u)];
+    }
+    int32_t z[1][E];
+    const int32_t *zp = zpart + ((((size_t)b * npr + pi) * 4) * 2 + c) * M + q * MS + E * tid;
+#pragma unroll
+    for (int h = 0; h < E / 4; h++) {
+        int32_t acc[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int ph = 0; ph < 4; ph++) {
+            const int4 v = reinterpret_cast<const int4 *>(zp + (size_t)ph * 2 * M)[h];
+            acc[0] += v.x; acc[1] += v.y; acc[2] += v.z; acc[3] += v.w;  // < 2.99 * 2^29
+        }
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            // (psi^e - 1) R mod p from two centred residues: in (-p, p), centred again for the product's bound
+            const int32_t d = scentre(dfac[4 * h + t] - P.r1, md);
+            z[0][4 * h + t] = smont(acc[t], d, md);                      // < 0.19 + 0.5 = 0.69 * 2^29
+        }
+    }
+    ntt_inverse<LS, 1, LE>(z, lds, P.twq + (size_t)q * M + MS, tid, md);   // natural order inside the quarter, |.| < 1.4 * 2^29
+    int32_t *yb = ypart + ((((size_t)b * 2 + c) * npr + pi) * 4 + q) * MS;
+#pragma unroll
+    for (int e = 0; e < E; e++) yb[tid + T * e] = z[0][e];
+}
+
+// One thread per coefficient i of (bootstrap, c): the last two Gentleman-Sande stages on the four partial
+// values Y_0..Y_3 at i mod m/4 of every prime --
+//   C0 = Y0 + Y1, C1 = v2 (Y0 - Y1), C2 = Y2 + Y3, C3 = v3 (Y2 - Y3);
+//   coefficient in quarter 0: C0 + C2;  1: C1 + C3;  2: v1 (C0 - C2);  3: v1 (C1 - C3)
+// (only the one this coefficient needs; the quarter is the same for a whole workgroup) -- then the residue in
+// the form k_extprod hands over (+ 3 p, + (p - 1) / 2 on the last prime) and crt_lean_one.
+template <int NP, int NL>
+__global__ void __launch_bounds__(256)
+k_crt_lean1q(const int32_t *__restrict__ ypart, uint64_t *__restrict__ dig, PrimeSet PS,
+             const CrtLean *__restrict__ K, uint32_t total, uint32_t logm) {
+    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= total) return;
+    const uint32_t M = 1u << logm, MS = M >> 2;
+    const uint32_t i = t & (M - 1);
+    const uint32_t bc = t >> logm;
+    const uint32_t jq = i & (MS - 1), qq = i >> (logm - 2);
+    uint32_t y[NP];
+#pragma unroll
+    for (int q = 0; q < NP; q++) {
+        const PrimeK P = PS[q];
+        const Mod md = mod_of(P);
+        const int32_t *yp = ypart + (((size_t)bc * NP + q) * 4) * MS + jq;
+        int32_t r;
+        if (qq & 1u) {          // C1, C3
+            const int32_t c1 = smont(yp[0] - yp[MS], P.v2, md), c3 = smont(yp[2 * MS] - yp[3 * MS], P.v3, md);
+            r = (qq & 2u) ? smont(c1 - c3, P.v1, md) : c1 + c3;             // < 0.75 / < 1.5 * 2^29
+        } else {                // C0, C2
+            const int32_t c0 = sred(yp[0] + yp[MS], md), c2 = sred(yp[2 * MS] + yp[3 * MS], md);   // sums < 2.8: reduced to 0.51
+            r = (qq & 2u) ? smont(c0 - c2, P.v1, md) : c0 + c2;             // < 0.75 / < 1.03 * 2^29
+        }
+        y[q] = (uint32_t)(r + 3 * P.p) + P.hoff;                            // non-negative, below 4.6 p
+    }
+    const ulonglong2 d = load_digits(dig, bc, i, M);
+    uint64_t lo, hi;
+    crt_lean_one<NP, NL>(y, d.x, d.y, K, lo, hi);
+    store_digits(dig, bc, i, M, lo, hi);
 }
 
 // ---- k_init -------------------------------------------------------------------------------------

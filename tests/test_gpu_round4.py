@@ -468,17 +468,21 @@ def test_host_staging_can_be_released(S, oc):
 
 # ---- the latency form at its true sizes (round 4: no padding to 8 gates, one coefficient per CRT thread) ----
 
-@pytest.mark.parametrize("ring", ["params64", "synthetic m = 256", "params512"])
+@pytest.mark.parametrize("ring", ["params64", "synthetic m = 256", "params512", "params1024"])
 def test_latency_form_calls_of_one_to_nine_gates(S, oc, ring):
     """A call of g gates launches g gates' workgroups (up to round 3 the small-batch grids were padded
-    to a multiple of 8, so the literal drop-in call -- one gate -- did eight gates' work), and up to 8
-    gates the CRT kernel takes one coefficient per thread (k_crt_lean1).  Every size from 1 to 9
-    against the C restatement, raw and ModRed, accumulators after 1 and 2 iterations; the padded
-    launches of rounds 1-3 (SGFHE_SMALL_PADDED=1) give the same bytes."""
+    to a multiple of 8, so the literal drop-in call -- one gate -- did eight gates' work); up to 8
+    gates the CRT kernel takes one coefficient per thread (k_crt_lean1); and for m >= 4096 calls of up
+    to 7 gates cut every transform across four workgroups (k_fwd_quarter / k_inv_quarter /
+    k_crt_lean1q: the first two forward stages and the last two inverse stages outside the
+    quarter-size transforms, (x^j - 1) applied in the NTT domain).  Sizes from 1 to 9 against the C
+    restatement, raw and ModRed, accumulators after 1 and 2 iterations; the one-workgroup transforms
+    (SGFHE_SMALL_SPLIT=0) and the padded launches of rounds 1-3 (SGFHE_SMALL_PADDED=1) give the same
+    bytes."""
     if ring == "params64":
         params, noise = S.Params(64), None
-    elif ring == "params512":
-        params, noise = S.Params(512), None
+    elif ring in ("params512", "params1024"):
+        params, noise = S.Params(int(ring[6:])), None
     else:
         n = 32
         params, noise = S.Params.custom(n, BO.find_modulus(16 * n, 1 << 50), 1 << 26), 2
@@ -490,24 +494,25 @@ def test_latency_form_calls_of_one_to_nine_gates(S, oc, ring):
     eng.upload_key(bkey)
     del bkey
     bits, a1, b1, a2, b2 = _mixed_inputs(o, sk, params, 9, 9)
-    sizes = (1, 2, 3, 4, 5, 8, 9) if ring != "params512" else (1, 3, 4, 5)
+    sizes = {"params512": (1, 3, 4, 5, 7, 8), "params1024": (1, 2, 6, 7, 8)}.get(ring, (1, 2, 3, 4, 5, 8, 9))
     for g in sizes:
         sl = slice(0, g)
         ref = o.bootstrap_batch(khat, a1[sl], b1[sl], a2[sl], b2[sl], opt=True, threads=_threads())
         assert np.array_equal(eng.bootstrap_batch(a1[sl], b1[sl], a2[sl], b2[sl]), ref), g
-        if ring != "params512":
+        if ring not in ("params512", "params1024") or g in (1, 7):
             assert np.array_equal(eng.bootstrap_batch(a1[sl], b1[sl], a2[sl], b2[sl], raw=True),
                                   o.bootstrap_batch(khat, a1[sl], b1[sl], a2[sl], b2[sl], raw=True, opt=True)), g
             for it in (1, 2):
                 _, acc = o.bootstrap_batch(khat, a1[sl], b1[sl], a2[sl], b2[sl], n_iters=it, want_acc=True, opt=True)
                 assert np.array_equal(eng.debug_accumulators(a1[sl], b1[sl], a2[sl], b2[sl], it), acc), (g, it)
     eng.close()
-    os.environ["SGFHE_SMALL_PADDED"] = "1"
-    try:
-        old = S.Engine(params)
-    finally:
-        del os.environ["SGFHE_SMALL_PADDED"]
-    old.generate_key(sk, 8, noise=noise) if noise is None else old.upload_key(o.bootstrap_key(sk, 8, noise=noise))
-    ref = o.bootstrap_batch(khat, a1[:3], b1[:3], a2[:3], b2[:3], opt=True)
-    assert np.array_equal(old.bootstrap_batch(a1[:3], b1[:3], a2[:3], b2[:3]), ref)
-    old.close()
+    ref = o.bootstrap_batch(khat, a1[:3], b1[:3], a2[:3], b2[:3], opt=True, threads=_threads())
+    for knob in ("SGFHE_SMALL_PADDED", "SGFHE_SMALL_SPLIT"):
+        os.environ[knob] = "1" if knob == "SGFHE_SMALL_PADDED" else "0"
+        try:
+            old = S.Engine(params)
+        finally:
+            del os.environ[knob]
+        old.generate_key(sk, 8, noise=noise) if noise is None else old.upload_key(o.bootstrap_key(sk, 8, noise=noise))
+        assert np.array_equal(old.bootstrap_batch(a1[:3], b1[:3], a2[:3], b2[:3]), ref), knob
+        old.close()
