@@ -375,13 +375,13 @@ int32_t launch_small(sgfhe_ctx *c, const sgfhe_ctx::Lane &L, const int32_t *keyk
 // The quarter form of the two transform kernels (kernels.h k_fwd_quarter / k_inv_quarter), m >= 4096.
 template <int LOGM>
 int32_t launch_quarter_t(sgfhe_ctx *c, const sgfhe_ctx::Lane &L, const int32_t *keyk, uint32_t cnt,
-                         uint32_t k, hipStream_t st) {
+                         uint32_t k, uint32_t mode, hipStream_t st) {
     if constexpr (LOGM >= 12) {
         constexpr int LE = 3;
         constexpr int TH = NttGeom<LOGM - 2, LE>::T;
         const size_t lds = lds_bytes(LOGM - 2, 1);
         hipLaunchKernelGGL((k_fwd_quarter<LOGM, LE>), dim3(cnt * c->npr * 16), dim3(TH), lds, st, L.dig, keyk,
-                           L.zpart, c->d_primes);
+                           L.zpart, c->d_primes, mode);
         hipLaunchKernelGGL((k_inv_quarter<LOGM, LE>), dim3(cnt * c->npr * 8), dim3(TH), lds, st, L.zpart,
                            reinterpret_cast<int32_t *>(L.yres), L.ua, c->d_primes, k, c->n);
         HIPCHK(c, hipGetLastError());
@@ -391,9 +391,9 @@ int32_t launch_quarter_t(sgfhe_ctx *c, const sgfhe_ctx::Lane &L, const int32_t *
     }
 }
 int32_t launch_quarter(sgfhe_ctx *c, const sgfhe_ctx::Lane &L, const int32_t *keyk, uint32_t cnt, uint32_t k,
-                       hipStream_t st) {
+                       uint32_t mode, hipStream_t st) {
     switch (c->logm) {
-#define X(LM) case LM: return launch_quarter_t<LM>(c, L, keyk, cnt, k, st);
+#define X(LM) case LM: return launch_quarter_t<LM>(c, L, keyk, cnt, k, mode, st);
         SGFHE_FOR_LOGM(X)
 #undef X
     }
@@ -509,6 +509,15 @@ void launch_crt_lean_t(sgfhe_ctx *c, const uint32_t *yres, uint64_t *dig, uint32
 template <int NP, bool WIDE>
 void launch_crt_lean_rnd_t(sgfhe_ctx *c, const uint32_t *yres, uint64_t *dig, uint32_t total, hipStream_t st,
                            RndArgs ra, uint32_t iter) {
+    if (!WIDE && total <= c->crt1_max) {   // the latency form: one coefficient per thread
+        const dim3 grid1((total + 255) / 256), block1(256);
+        switch (c->h_lean.nl) {
+        case 2: hipLaunchKernelGGL((k_crt_lean_rnd1<NP, 2, false>), grid1, block1, 0, st, yres, dig, c->d_lean, total, (uint32_t)c->logm, ra, iter, (const PrimeK *)nullptr); break;
+        case 3: hipLaunchKernelGGL((k_crt_lean_rnd1<NP, 3, false>), grid1, block1, 0, st, yres, dig, c->d_lean, total, (uint32_t)c->logm, ra, iter, (const PrimeK *)nullptr); break;
+        default: hipLaunchKernelGGL((k_crt_lean_rnd1<NP, 4, false>), grid1, block1, 0, st, yres, dig, c->d_lean, total, (uint32_t)c->logm, ra, iter, (const PrimeK *)nullptr); break;
+        }
+        return;
+    }
     const dim3 grid((total / 4 + 255) / 256), block(256);
     switch (c->h_lean.nl) {
     case 2: hipLaunchKernelGGL((k_crt_lean_rnd<NP, 2, WIDE>), grid, block, 0, st, yres, dig, c->d_lean, total / 4, (uint32_t)c->logm, ra, iter); break;
@@ -553,10 +562,28 @@ int32_t launch_crt(sgfhe_ctx *c, const sgfhe_ctx::Lane &L, uint32_t cpad, uint32
 }
 
 // CRT kernel of the quarter form: partial residues in, the last two inverse stages inside
-int32_t launch_crt_quarter(sgfhe_ctx *c, const sgfhe_ctx::Lane &L, uint32_t cnt, hipStream_t st) {
+int32_t launch_crt_quarter(sgfhe_ctx *c, const sgfhe_ctx::Lane &L, uint32_t cnt, uint32_t mode, hipStream_t st,
+                           RndArgs ra, uint32_t iter) {
     const uint32_t total = cnt * 2 * c->M;
     const dim3 grid((total + 255) / 256), block(256);
     const int32_t *yp = reinterpret_cast<const int32_t *>(L.yres);
+    if (mode & MODE_RANDOM) {   // the randomised flatten: one coefficient per thread here too (k_crt_lean_rnd1)
+        switch (c->npr) {
+#define X(NP)                                                                                                     \
+        case NP:                                                                                                  \
+            switch (c->h_lean.nl) {                                                                               \
+            case 2: hipLaunchKernelGGL((k_crt_lean_rnd1<NP, 2, true>), grid, block, 0, st, L.yres, L.dig, c->d_lean, total, (uint32_t)c->logm, ra, iter, c->d_primes); break; \
+            case 3: hipLaunchKernelGGL((k_crt_lean_rnd1<NP, 3, true>), grid, block, 0, st, L.yres, L.dig, c->d_lean, total, (uint32_t)c->logm, ra, iter, c->d_primes); break; \
+            default: hipLaunchKernelGGL((k_crt_lean_rnd1<NP, 4, true>), grid, block, 0, st, L.yres, L.dig, c->d_lean, total, (uint32_t)c->logm, ra, iter, c->d_primes); break; \
+            }                                                                                                     \
+            break;
+            SGFHE_FOR_NPR(X)
+#undef X
+        default: return fail(c, SGFHE_ERR_UNSUPPORTED, "unsupported number of RNS primes");
+        }
+        HIPCHK(c, hipGetLastError());
+        return SGFHE_OK;
+    }
     switch (c->npr) {
 #define X(NP)                                                                                                     \
     case NP:                                                                                                      \
@@ -691,14 +718,15 @@ int32_t run_iterations(sgfhe_ctx *c, ChunkJob *jobs, int njobs, uint64_t n_iters
             // k_extprod's XCD mapping's; a one-gate call then runs one gate's workgroups, not eight's)
             const uint32_t cnt = small && !c->small_padded ? J.cb : J.cpad;
             // a few gates, deterministic flatten, m >= 4096: each transform cut across four workgroups
-            const bool quarter = small && mode == 0u && c->logm >= 12 && cnt <= c->split_max &&
-                                 c->h_lean.nl != 0 && c->use_lean;
-            int32_t rc = quarter ? launch_quarter(c, *J.L, c->d_key + k * slice, cnt, (uint32_t)k, J.st)
+            // (both flatten modes; not the three-plane digit records of B >= 2^46, MODE_WIDE)
+            const bool quarter = small && c->logm >= 12 && cnt <= c->split_max && c->use_lean &&
+                                 (mode == 0u ? c->h_lean.nl != 0 : (mode == MODE_RANDOM && c->lean_rnd_ok));
+            int32_t rc = quarter ? launch_quarter(c, *J.L, c->d_key + k * slice, cnt, (uint32_t)k, mode, J.st)
                          : small ? launch_small(c, *J.L, c->d_key + k * slice, cnt, (uint32_t)k, mode, J.st)
                                  : launch_extprod(c, *J.L, c->d_key + k * slice, J.cpad, (uint32_t)k, mode, J.st);
             if (rc) return rc;
             if (sample) HIPCHK(c, hipEventRecord(e1, J.st));
-            rc = quarter ? launch_crt_quarter(c, *J.L, cnt, J.st)
+            rc = quarter ? launch_crt_quarter(c, *J.L, cnt, mode, J.st, J.ra, (uint32_t)k + 1)
                          : launch_crt(c, *J.L, cnt, mode, J.st, J.ra, (uint32_t)k + 1);
             if (rc) return rc;
             if (sample) {

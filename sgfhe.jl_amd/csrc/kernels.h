@@ -1044,6 +1044,63 @@ k_crt_lean_rnd(const uint32_t *__restrict__ yres, uint64_t *__restrict__ dig,
     }
 }
 
+// The randomised flatten with ONE coefficient per thread, for the latency form (a call of a few gates): every
+// thread computes the ChaCha block of its quad of coefficients -- four times the block function across the
+// launch, which an otherwise idle device does not notice -- and uses its own four words of it, so a thread's
+// instruction stream is one block and one CRT instead of one block and four.  Same stream addressing, same
+// digits as k_crt_lean_rnd.  QUARTER: residues from the partial values of the quarter kernels.  Not for the
+// three-plane digit records (B >= 2^46).
+template <int NP, int NL, bool QUARTER>
+__global__ void __launch_bounds__(256)
+k_crt_lean_rnd1(const uint32_t *__restrict__ yres, uint64_t *__restrict__ dig,
+                const CrtLean *__restrict__ K, uint32_t total, uint32_t logm, RndArgs ra, uint32_t iter,
+                const PrimeK *__restrict__ PS) {
+    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= total) return;
+    const uint32_t M = 1u << logm;
+    const uint32_t i = t & (M - 1);
+    const uint32_t bc = t >> logm;
+    uint32_t y[NP];
+    if constexpr (QUARTER) {
+        const uint32_t MS = M >> 2, jq = i & (MS - 1), qq = i >> (logm - 2);
+        const int32_t *ypart = reinterpret_cast<const int32_t *>(yres);
+#pragma unroll
+        for (int q = 0; q < NP; q++) {
+            const PrimeK P = PS[q];
+            const Mod md = mod_of(P);
+            const int32_t *yp = ypart + (((size_t)bc * NP + q) * 4) * MS + jq;
+            int32_t r;
+            if (qq & 1u) {
+                const int32_t c1 = smont(yp[0] - yp[MS], P.v2, md), c3 = smont(yp[2 * MS] - yp[3 * MS], P.v3, md);
+                r = (qq & 2u) ? smont(c1 - c3, P.v1, md) : c1 + c3;
+            } else {
+                const int32_t c0 = sred(yp[0] + yp[MS], md), c2 = sred(yp[2 * MS] + yp[3 * MS], md);
+                r = (qq & 2u) ? smont(c0 - c2, P.v1, md) : c0 + c2;
+            }
+            y[q] = (uint32_t)(r + 3 * P.p) + P.hoff;
+        }
+    } else {
+        const uint32_t yo = 4u * ((bc * NP << logm) + i);
+#pragma unroll
+        for (int q = 0; q < NP; q++) y[q] = ld_off<uint32_t>(yres, yo + ((uint32_t)(4 * q) << logm));
+    }
+    const ulonglong2 d = load_digits(dig, bc, i, M);
+    const uint64_t xm2 = ((uint64_t)K->xm2hi << 32) | K->xm2lo, span = xm2 + 1;
+    const uint32_t cx = ((bc & 1u) << logm) + i, cz = ra.chunk + (bc >> 1);
+    uint32_t rw[16];
+    chacha_block<SGFHE_RND_ROUNDS>(ra.key, cx >> 2, iter, cz, ra.call, rw);
+    const uint32_t sel = cx & 3u;   // this coefficient's four words of the block
+    const uint32_t w0 = sel == 0 ? rw[0] : sel == 1 ? rw[4] : sel == 2 ? rw[8] : rw[12];
+    const uint32_t w1 = sel == 0 ? rw[1] : sel == 1 ? rw[5] : sel == 2 ? rw[9] : rw[13];
+    const uint32_t w2 = sel == 0 ? rw[2] : sel == 1 ? rw[6] : sel == 2 ? rw[10] : rw[14];
+    const uint32_t w3 = sel == 0 ? rw[3] : sel == 1 ? rw[7] : sel == 2 ? rw[11] : rw[15];
+    const uint64_t r0 = __umul64hi(((uint64_t)w1 << 32) | w0, span);
+    const uint64_t r1 = __umul64hi(((uint64_t)w3 << 32) | w2, span);
+    uint64_t lo, hi;
+    crt_lean_one<NP, NL, true>(y, d.x + (xm2 - r0), d.y + (xm2 - r1), K, lo, hi);
+    store_digits(dig, bc, i, M, lo + r0, hi + r1);
+}
+
 // ---- small-batch ("latency") form of the external product --------------------------------------
 // A call with a handful of gates leaves most of the 256 CUs idle while one workgroup per
 // (bootstrap, prime) walks through 4 forward and 2 inverse transforms.  Here the same work is cut
@@ -1176,7 +1233,7 @@ k_inv_column(const int32_t *__restrict__ zpart, uint32_t *__restrict__ yres,
 template <int LOGM, int LE>
 __global__ void __launch_bounds__((NttGeom<LOGM - 2, LE>::T))
 k_fwd_quarter(const uint64_t *__restrict__ dig, const int32_t *__restrict__ keyk,
-              int32_t *__restrict__ zpart, PrimeSet PS) {
+              int32_t *__restrict__ zpart, PrimeSet PS, uint32_t mode) {
     constexpr int LS = LOGM - 2;
     using G = NttGeom<LS, LE>;
     constexpr int M = 1 << LOGM, MS = G::M, T = G::T, E = G::E;
@@ -1187,6 +1244,7 @@ k_fwd_quarter(const uint64_t *__restrict__ dig, const int32_t *__restrict__ keyk
     const uint32_t pi = (blockIdx.x >> 4) % npr, b = (blockIdx.x >> 4) / npr;
     const PrimeK P = PS[pi];
     const Mod md = mod_of(P);
+    const int32_t sRd = (mode & MODE_RANDOM) ? P.sRr : P.sR;   // digit offset of the flatten mode
     const uint32_t *dl = digit_lo_plane(dig, (size_t)b * 2 + (ph >> 1), M) + (ph & 1) * M;
     const uint16_t *dh = digit_hi_plane(dig, (size_t)b * 2 + (ph >> 1), M) + (ph & 1) * M;
     // quarter q of the first two stages: with X0..X3 the coefficients i, i + m/4, i + m/2, i + 3m/4,
@@ -1199,7 +1257,7 @@ k_fwd_quarter(const uint64_t *__restrict__ dig, const int32_t *__restrict__ keyk
         int32_t X[4];
 #pragma unroll
         for (int t = 0; t < 4; t++)
-            X[t] = digit_reduce(dl[i + t * MS] | ((uint64_t)dh[i + t * MS] << 32), md, P.sR);   // |.| <= p + 2^16
+            X[t] = digit_reduce(dl[i + t * MS] | ((uint64_t)dh[i + t * MS] << 32), md, sRd);   // |.| <= p + 2^16
         const int32_t u = smont(X[2], P.f1, md);                                              // < 0.57 * 2^29
         const int32_t a = (q & 2) ? X[0] - u : X[0] + u;
         const int32_t w = sredc((int64_t)X[1] * wB + (int64_t)X[3] * wP, md);                   // < 0.63 * 2^29

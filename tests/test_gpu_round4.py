@@ -505,6 +505,12 @@ def test_latency_form_calls_of_one_to_nine_gates(S, oc, ring):
             for it in (1, 2):
                 _, acc = o.bootstrap_batch(khat, a1[sl], b1[sl], a2[sl], b2[sl], n_iters=it, want_acc=True, opt=True)
                 assert np.array_equal(eng.debug_accumulators(a1[sl], b1[sl], a2[sl], b2[sl], it), acc), (g, it)
+    # the randomised flatten through the same forms (the quarter form serves both modes)
+    eng.set_random_flatten(True, FKEY)
+    for call, g in enumerate((1, 3, 7, 9) if ring != "params1024" else (1, 5)):
+        sl = slice(0, g)
+        ref = o.bootstrap_batch(khat, a1[sl], b1[sl], a2[sl], b2[sl], opt=True, threads=_threads(), rnd=(FKEY, call))
+        assert np.array_equal(eng.bootstrap_batch(a1[sl], b1[sl], a2[sl], b2[sl]), ref), ("random", g)
     eng.close()
     ref = o.bootstrap_batch(khat, a1[:3], b1[:3], a2[:3], b2[:3], opt=True, threads=_threads())
     for knob in ("SGFHE_SMALL_PADDED", "SGFHE_SMALL_SPLIT"):
