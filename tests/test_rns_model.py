@@ -328,3 +328,81 @@ def test_crt_lean_random_model(name, args):
             assert x2 == want
         lo, hq, alpha = L.digits_random(y, e_lo, e_hi, r0, r1)
         assert (lo, hq) == (x2 % C.B + r0, x2 // C.B + r1)
+
+
+# ---- the quarter form of the latency kernels (round 4: k_fwd_quarter / k_inv_quarter / k_crt_lean1q) ----
+
+def _quarter_tables(P, logm):
+    """engine.hip build_basis: entry mm' + i' of quarter q's tables = entry 4 mm' + q mm' + i' of the big ones."""
+    m, ms = 1 << logm, 1 << (logm - 2)
+    out = []
+    for q in range(4):
+        t = {k: np.zeros(ms, dtype=np.int64) for k in ("twf", "twi", "twfp", "twip")}
+        for jj in range(1, ms):
+            mmq = 1 << (jj.bit_length() - 1)
+            J = 4 * mmq + q * mmq + (jj - mmq)
+            t["twf"][jj], t["twi"][jj] = P["twf"][J], P["twi"][J]
+            if jj >= 2:
+                t["twfp"][jj], t["twip"][jj] = P["twfp"][J], P["twip"][J]
+        out.append(dict(P, **t))
+    return out
+
+
+@pytest.mark.parametrize("logm", [8, 12, 13])
+def test_quarter_form_equals_the_whole_transforms(logm):
+    """kernels.h k_fwd_quarter / k_inv_quarter / k_crt_lean1q in the numpy model, every operation checked
+    against int32: (a) the radix-4 combination of the four input quarters followed by the quarter-size
+    transform on the re-indexed twiddle sub-tree gives the slots of the whole forward transform;
+    (b) multiplying slot s by psi^(j (2 brv(s) + 1)) - 1 and running the quarter-size inverse
+    transforms, then the last two Gentleman-Sande stages on the four partial values, gives
+    x^j P - P of the whole inverse transform's P, for j across the wrap (0, 1, m - 1, m, 2m - 1)."""
+    m, ms = 1 << logm, 1 << (logm - 2)
+    C = RM.Consts(m // 8, m, (1 << 50) + 1, 1 << 26, 12345)
+    P = C.pk[1]
+    p = P["p"]
+    big = RM.NttModel(logm, 3)
+    sub = RM.NttModel(logm - 2, 3)
+    QT = _quarter_tables(P, logm)
+    rng = np.random.default_rng(logm)
+    # (a) forward: inputs as digit_reduce leaves them, |x| <= p + 2^16
+    poly = rng.integers(-(p + 65536), p + 65536 + 1, size=m, dtype=np.int64)
+    want = big.forward(big.to_regs(RM.sred_floor(poly, P)), P["twf"], P).reshape(-1) % p
+    X = poly.reshape(4, ms)                                        # X[t][i] = coefficient i + t m / 4
+    f1, f2, f3, fp2, fp3 = (int(P["twf"][1]), int(P["twf"][2]), int(P["twf"][3]), int(P["twfp"][2]), int(P["twfp"][3]))
+    u = RM.smont(X[2], f1, P)
+    for q in range(4):
+        a = RM.i32(X[0] - u) if q & 2 else RM.i32(X[0] + u)
+        wB, wP = (f3, fp3) if q & 2 else (f2, fp2)
+        w = RM.sredc(RM.i32(X[1]) * wB + RM.i32(X[3]) * wP, P)
+        xq = RM.sred_floor(RM.i32(a - w) if q & 1 else RM.i32(a + w), P)
+        got = sub.forward(sub.to_regs(xq), QT[q]["twf"], QT[q]).reshape(-1) % p
+        assert np.array_equal(got, want[q * ms:(q + 1) * ms]), "forward quarter %d" % q
+    # (b) inverse: slot values as the summed partial products leave them, |z| < 2.99 * 2^29
+    z = rng.integers(-int(2.9 * 2 ** 29), int(2.9 * 2 ** 29), size=m, dtype=np.int64)
+    R1 = (1 << 32) % p
+    # (inverse transforms take slots E tid + e per thread: a plain reshape, not to_regs)
+    whole = big.from_regs(big.inverse(RM.sred(z, P).reshape(big.T, big.E), P["twi"], P)) % p       # P, unscaled
+    v1, v2, v3 = int(P["twi"][1]), int(P["twi"][2]), int(P["twi"][3])
+    for j in (0, 1, 5, m - 1, m, m + 3, 2 * m - 1):
+        rot = np.zeros(m, dtype=object)
+        for i in range(m):
+            k = (i + j) % (2 * m)
+            rot[k % m] = (-int(whole[i]) if k >= m else int(whole[i])) % p
+        want = np.array([(int(a) - int(b)) % p for a, b in zip(rot, whole)], dtype=np.int64)   # x^j P - P
+        Y = []
+        for q in range(4):
+            s = q * ms + np.arange(ms)
+            br = np.array([RM.bitrev(int(v), logm) for v in s], dtype=np.int64)
+            e = (j * (2 * br + 1)) % (2 * m)
+            pw = np.array([RM.centre(pow(P["psi"], int(v), p) * R1, p) for v in e], dtype=np.int64)   # PrimeK::pw
+            d = RM.scentre(RM.i32(pw - P["r1"]), P)
+            zq = RM.smont(z[q * ms:(q + 1) * ms], d, P)
+            assert int(np.abs(zq).max()) < 0.75 * 2 ** 29
+            Y.append(sub.from_regs(sub.inverse(zq.reshape(sub.T, sub.E), QT[q]["twi"], QT[q])))
+            assert int(np.abs(Y[-1]).max()) < 1.4 * 2 ** 29
+        c0, c2 = RM.sred(RM.i32(Y[0] + Y[1]), P), RM.sred(RM.i32(Y[2] + Y[3]), P)
+        c1, c3 = RM.smont(RM.i32(Y[0] - Y[1]), v2, P), RM.smont(RM.i32(Y[2] - Y[3]), v3, P)
+        got = np.concatenate([RM.i32(c0 + c2), RM.i32(c1 + c3), RM.smont(RM.i32(c0 - c2), v1, P),
+                              RM.smont(RM.i32(c1 - c3), v1, P)])
+        assert int(np.abs(got).max()) < 1.5 * 2 ** 29                # + 3 p stays a residue below 4.6 p
+        assert np.array_equal(got % p, want), "inverse, j = %d" % j
