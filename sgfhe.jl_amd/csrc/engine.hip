@@ -160,6 +160,8 @@ struct sgfhe_ctx {
     } lane[2];
     bool use_lean = true;     // SGFHE_CRT_LEAN=0 in the environment: keep k_crt_acc2 (A/B measurements)
     bool small_padded = false;  // SGFHE_SMALL_PADDED=1: small-batch grids padded to 8 bootstraps as up to round 3 (A/B)
+    bool small_lanes = true;    // SGFHE_SMALL_LANES=0: a call of a few gates as one chunk on one stream (A/B)
+    uint32_t small_lanes_max = 24;   // ... up to this many gates (SGFHE_SMALL_LANES=<n>)
     uint32_t crt1_max = 0;      // k_crt_lean launches of at most this many coefficients take one per thread
                                 // (SGFHE_CRT1_GATES gates' worth: default 8; 0 = never.  Same call, 1 / 2 / 4 / 8
                                 // gates: 18.6 / 19.4 / 20.8 / 23.9 ms with four per thread, 17.9 / 18.6 / 20.2 / 23.4
@@ -787,6 +789,16 @@ int32_t bootstrap_device(sgfhe_ctx *c, const uint64_t *a1, const uint64_t *b1, c
         // split: 48 bootstraps run at 1277 per second as one chunk and at 1024 as 24 + 24.
         const size_t pairs = (batch + 2 * (size_t)chunk - 1) / (2 * (size_t)chunk);
         chunk = round_up8((uint32_t)((batch + 2 * pairs - 1) / (2 * pairs)));
+    } else if (!c->chunk && c->lanes == 2 && c->small_lanes && batch >= 8 && batch <= c->small_lanes_max &&
+               (batch + 1) / 2 <= c->small_max) {
+        // A call of 8 to 24 gates in the latency form: two halves on the two lanes.  Each half is a chain of
+        // dependent launches on a mostly idle device, and two chains overlap; the halves need no rounding
+        // to 8 (the latency kernels index their gates directly), so 8 gates run as 4 + 4 and 12 as 6 + 6
+        // in the quarter form.  Same call (profiles/r04_exp_small_lanes.txt): 8 / 10 / 12 / 16 / 20 / 24 gates
+        // 20.8 / 21.6 / 22.8 / 27.4 / 27.8 / 29.7 ms against 23.4 / 25.2 / 27.0 / 27.8 / 30.5 / 31.4 as one chunk;
+        // below 8 gates two chains cost more than they overlap (2 / 4 / 6 gates 18.3 / 18.3 / 19.0 against
+        // 15.8 / 17.8 / 19.8), so those stay on one stream.
+        chunk = (uint32_t)((batch + 1) / 2);
     }
     const uint32_t n = c->n, M = c->M;
     const bool raw = flags & SGFHE_FLAG_RAW_MODQ;
@@ -1334,6 +1346,8 @@ int32_t build_constants(sgfhe_ctx *c) {
         c->use_pin = !(env && env[0] == '0');
         env = getenv("SGFHE_SMALL_PADDED");
         c->small_padded = env && env[0] == '1';
+        env = getenv("SGFHE_SMALL_LANES");
+        if (env) { c->small_lanes = atoi(env) != 0; if (atoi(env) > 1) c->small_lanes_max = (uint32_t)atoi(env); }
         env = getenv("SGFHE_CRT1_GATES");
         c->crt1_max = (uint32_t)(env ? atoi(env) : 8) * 2u * c->M;
     }

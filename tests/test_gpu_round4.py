@@ -494,12 +494,12 @@ def test_latency_form_calls_of_one_to_nine_gates(S, oc, ring):
     eng.upload_key(bkey)
     del bkey
     bits, a1, b1, a2, b2 = _mixed_inputs(o, sk, params, 9, 9)
-    sizes = {"params512": (1, 3, 4, 5, 7, 8), "params1024": (1, 2, 6, 7, 8)}.get(ring, (1, 2, 3, 4, 5, 8, 9))
+    sizes = {"params512": (1, 3, 4, 5, 7, 8), "params1024": (1, 7, 8)}.get(ring, (1, 2, 3, 4, 5, 8, 9))
     for g in sizes:
         sl = slice(0, g)
         ref = o.bootstrap_batch(khat, a1[sl], b1[sl], a2[sl], b2[sl], opt=True, threads=_threads())
         assert np.array_equal(eng.bootstrap_batch(a1[sl], b1[sl], a2[sl], b2[sl]), ref), g
-        if ring not in ("params512", "params1024") or g in (1, 7):
+        if ring not in ("params512", "params1024") or g == 7:
             assert np.array_equal(eng.bootstrap_batch(a1[sl], b1[sl], a2[sl], b2[sl], raw=True),
                                   o.bootstrap_batch(khat, a1[sl], b1[sl], a2[sl], b2[sl], raw=True, opt=True)), g
             for it in (1, 2):
@@ -507,7 +507,7 @@ def test_latency_form_calls_of_one_to_nine_gates(S, oc, ring):
                 assert np.array_equal(eng.debug_accumulators(a1[sl], b1[sl], a2[sl], b2[sl], it), acc), (g, it)
     # the randomised flatten through the same forms (the quarter form serves both modes)
     eng.set_random_flatten(True, FKEY)
-    for call, g in enumerate((1, 3, 7, 9) if ring != "params1024" else (1, 5)):
+    for call, g in enumerate((1, 3, 7, 9) if ring != "params1024" else (1, 3)):
         sl = slice(0, g)
         ref = o.bootstrap_batch(khat, a1[sl], b1[sl], a2[sl], b2[sl], opt=True, threads=_threads(), rnd=(FKEY, call))
         assert np.array_equal(eng.bootstrap_batch(a1[sl], b1[sl], a2[sl], b2[sl]), ref), ("random", g)
