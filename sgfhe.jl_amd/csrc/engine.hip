@@ -129,6 +129,9 @@ struct sgfhe_ctx {
     int32_t *d_twq = nullptr; // quarter form of the latency kernels: per prime 4 blocks [f_q | v_q | fp_q | vp_q] of m / 4 words
     int32_t *d_pow = nullptr; //   and psi^e * R mod p, e in [0, 2 m)
     int32_t tw_head[NPR_MAX][8] = {};   // f[1..3], fp[2], fp[3], v[1..3] of every prime (PrimeK::f1 ... v3)
+    // the quarter form's two transform kernels as one launch (k_ext_quarter) from this many gates per chain, up to
+    // what fills the device once (fused_cap below); SGFHE_SMALL_FUSED=0: never, =n: from n gates
+    uint32_t fused_min = 7;
     uint32_t split_max = 7;   // calls of at most this many gates take the quarter form (SGFHE_SMALL_SPLIT, 0 = never):
                               // 1 / 2 / 4 / 6 / 8 gates 15.1 / 15.9 / 17.8 / 19.7 / 23.5 ms against 17.9 / 18.6 / 20.3 /
                               // 22.0 / 23.3 with one workgroup per transform (profiles/r04_exp_quarter.txt)
@@ -198,7 +201,7 @@ struct sgfhe_ctx {
     // per device; a ctx is bound to one device and used by one host thread)
     uint32_t attr_done = 0;
 };
-enum : uint32_t { ATTR_EXTPROD = 1u, ATTR_SMALL = 2u, ATTR_SHORTPROD = 4u };
+enum : uint32_t { ATTR_EXTPROD = 1u, ATTR_SMALL = 2u, ATTR_SHORTPROD = 4u, ATTR_FUSED = 8u };
 // Page-locked mirrors of the host-pointer entry point's staging buffers: per buffer at most this much
 // (a batch of 16384 at Params(1024) needs 268 + 403 MB).  Round 3 staged whole buffers and stopped at
 // 48 MB, where one CPU memcpy cost what pinning the caller's pages did; the copies are now pipelined
@@ -288,6 +291,20 @@ void save_basis(sgfhe_ctx *c, int b) {
 }
 // the basis of the present flatten mode
 int mode_basis(const sgfhe_ctx *c) { return c->rnd ? c->nb - 1 : 0; }
+// The quarter form of the latency kernels exists for m >= 4096 where the lean CRT kernel of the flatten mode does
+// (both modes; not the three-plane digit records of B >= 2^46, MODE_WIDE).
+bool quarter_ok(const sgfhe_ctx *c, uint32_t mode) {
+    return c->logm >= 12 && c->split_max && c->use_lean &&
+           (mode == 0u ? c->h_lean.nl != 0 : (mode == MODE_RANDOM && c->lean_rnd_ok));
+}
+// Largest chain the fused quarter kernel takes: one workgroup per (gate, prime, quarter), one round of the
+// device's 256 compute units (12 gates on five primes, 10 on six); 0 where it does not exist (m < 4096,
+// m = 16384: kernels.h) or is switched off.
+uint32_t fused_cap(const sgfhe_ctx *c, uint32_t mode) {
+    if (!c->fused_min || c->small_padded || (c->logm != 12 && c->logm != 13) || !quarter_ok(c, mode)) return 0;
+    return 256u / (c->npr * 4u);
+}
+bool fused_takes(const sgfhe_ctx *c, uint32_t cnt, uint32_t mode) { return cnt >= c->fused_min && cnt <= fused_cap(c, mode); }
 
 size_t lds_bytes(int logm, int npoly) { return (size_t)npoly * ((size_t)4 << logm); }
 // points per thread of k_extprod: 16, or 8 where 16 would leave half a wavefront idle (m <= 512)
@@ -381,6 +398,20 @@ int32_t launch_quarter_t(sgfhe_ctx *c, const sgfhe_ctx::Lane &L, const int32_t *
     if constexpr (LOGM >= 12) {
         constexpr int LE = 3;
         constexpr int TH = NttGeom<LOGM - 2, LE>::T;
+        // both transform kernels in one launch (kernels.h k_ext_quarter); at m = 16384 its workgroup of 1024
+        // threads leaves 128 registers per thread and spills: that ring keeps the two launches
+        if constexpr (LOGM <= 13) if (fused_takes(c, cnt, mode)) {
+            const size_t ldsf = (size_t)6 * (sizeof(uint32_t) << (LOGM - 2));
+            if (!(c->attr_done & ATTR_FUSED)) {
+                HIPCHK(c, hipFuncSetAttribute((const void *)k_ext_quarter<LOGM, LE>,
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsf));
+                c->attr_done |= ATTR_FUSED;
+            }
+            hipLaunchKernelGGL((k_ext_quarter<LOGM, LE>), dim3(cnt * c->npr * 4), dim3(2 * TH), ldsf, st, L.dig, keyk,
+                               reinterpret_cast<int32_t *>(L.yres), L.ua, c->d_primes, mode, k, c->n);
+            HIPCHK(c, hipGetLastError());
+            return SGFHE_OK;
+        }
         const size_t lds = lds_bytes(LOGM - 2, 1);
         hipLaunchKernelGGL((k_fwd_quarter<LOGM, LE>), dim3(cnt * c->npr * 16), dim3(TH), lds, st, L.dig, keyk,
                            L.zpart, c->d_primes, mode);
@@ -721,8 +752,7 @@ int32_t run_iterations(sgfhe_ctx *c, ChunkJob *jobs, int njobs, uint64_t n_iters
             const uint32_t cnt = small && !c->small_padded ? J.cb : J.cpad;
             // a few gates, deterministic flatten, m >= 4096: each transform cut across four workgroups
             // (both flatten modes; not the three-plane digit records of B >= 2^46, MODE_WIDE)
-            const bool quarter = small && c->logm >= 12 && cnt <= c->split_max && c->use_lean &&
-                                 (mode == 0u ? c->h_lean.nl != 0 : (mode == MODE_RANDOM && c->lean_rnd_ok));
+            const bool quarter = small && quarter_ok(c, mode) && (cnt <= c->split_max || fused_takes(c, cnt, mode));
             int32_t rc = quarter ? launch_quarter(c, *J.L, c->d_key + k * slice, cnt, (uint32_t)k, mode, J.st)
                          : small ? launch_small(c, *J.L, c->d_key + k * slice, cnt, (uint32_t)k, mode, J.st)
                                  : launch_extprod(c, *J.L, c->d_key + k * slice, J.cpad, (uint32_t)k, mode, J.st);
@@ -779,6 +809,7 @@ int32_t bootstrap_device(sgfhe_ctx *c, const uint64_t *a1, const uint64_t *b1, c
                          uint64_t *dig_out = nullptr, const HostPipe *hp = nullptr) {
     if (!c->have_key) return fail(c, SGFHE_ERR_NO_KEY, "no bootstrap key uploaded");
     uint32_t chunk = c->chunk ? c->chunk : default_chunk(c);
+    const uint32_t mode = c->rnd ? (MODE_RANDOM | ((c->B >> 46) ? MODE_WIDE : 0u)) : 0u;
     if (!c->chunk && c->lanes == 2 && batch > 2 * (size_t)c->small_max) {
         // Automatic chunk size with two lanes: cut the batch into an even number of equal chunks no
         // larger than the default, so that both lanes are busy from the first bootstrap to the last
@@ -789,8 +820,8 @@ int32_t bootstrap_device(sgfhe_ctx *c, const uint64_t *a1, const uint64_t *b1, c
         // split: 48 bootstraps run at 1277 per second as one chunk and at 1024 as 24 + 24.
         const size_t pairs = (batch + 2 * (size_t)chunk - 1) / (2 * (size_t)chunk);
         chunk = round_up8((uint32_t)((batch + 2 * pairs - 1) / (2 * pairs)));
-    } else if (!c->chunk && c->lanes == 2 && c->small_lanes && batch >= 8 && batch <= c->small_lanes_max &&
-               (batch + 1) / 2 <= c->small_max) {
+    } else if (!c->chunk && c->lanes == 2 && c->small_lanes && batch >= (fused_cap(c, mode) ? fused_cap(c, mode) + 1 : 8u) &&
+               batch <= c->small_lanes_max && (batch + 1) / 2 <= c->small_max) {
         // A call of 8 to 24 gates in the latency form: two halves on the two lanes.  Each half is a chain of
         // dependent launches on a mostly idle device, and two chains overlap; the halves need no rounding
         // to 8 (the latency kernels index their gates directly), so 8 gates run as 4 + 4 and 12 as 6 + 6
@@ -798,6 +829,10 @@ int32_t bootstrap_device(sgfhe_ctx *c, const uint64_t *a1, const uint64_t *b1, c
         // 20.8 / 21.6 / 22.8 / 27.4 / 27.8 / 29.7 ms against 23.4 / 25.2 / 27.0 / 27.8 / 30.5 / 31.4 as one chunk;
         // below 8 gates two chains cost more than they overlap (2 / 4 / 6 gates 18.3 / 18.3 / 19.0 against
         // 15.8 / 17.8 / 19.8), so those stay on one stream.
+        // With the fused quarter kernel (m = 4096, 8192) one chain takes up to 12 gates at the cost of two
+        // chains of half the size or less (8 / 10 / 12 gates 20.9 / 21.9 / 22.7 ms against 21.0 / 22.0 / 22.9;
+        // Params(512) 7.7 / 8.0 / 8.3 against 9.1 / 9.0 / 9.2), and the halves of 13 to 24 gates take it
+        // (profiles/r04_exp_fused.txt): two chains from 13 gates there.
         chunk = (uint32_t)((batch + 1) / 2);
     }
     const uint32_t n = c->n, M = c->M;
@@ -808,7 +843,6 @@ int32_t bootstrap_device(sgfhe_ctx *c, const uint64_t *a1, const uint64_t *b1, c
             return fail(c, SGFHE_ERR_INVALID_ARG, "SGFHE_FLAG_RAW_RNS2: no RNS2 moduli (upload the key with sgfhe_bkey_upload_rns2)");
     }
     const bool two_lanes = c->lanes == 2 && batch > chunk;
-    const uint32_t mode = c->rnd ? (MODE_RANDOM | ((c->B >> 46) ? MODE_WIDE : 0u)) : 0u;
     const uint32_t call = c->rnd ? c->rnd_call++ : 0u;
     c->last_call = call;
     {   // work buffers for the largest chunk of this call, before anything of it is queued
@@ -1357,6 +1391,8 @@ int32_t build_constants(sgfhe_ctx *c) {
     {
         const char *env = getenv("SGFHE_SMALL_SPLIT");
         if (env) c->split_max = (uint32_t)atoi(env);
+        env = getenv("SGFHE_SMALL_FUSED");
+        if (env) c->fused_min = (uint32_t)atoi(env);
     }
     HIPCHK(c, hipMalloc(&c->d_bad, sizeof(uint32_t)));
     HIPCHK(c, hipMemset(c->d_bad, 0, sizeof(uint32_t)));

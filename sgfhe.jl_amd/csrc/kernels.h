@@ -1330,6 +1330,112 @@ k_inv_quarter(const int32_t *__restrict__ zpart, int32_t *__restrict__ ypart,
     for (int e = 0; e < E; e++) yb[tid + T * e] = z[0][e];
 }
 
+// k_fwd_quarter and k_inv_quarter in one launch (round 4, second step): a quarter of the slots is closed
+// under everything between the radix-4 head of the forward transforms and the radix-4 tail of the inverse
+// ones, so one workgroup per (bootstrap, prime, quarter) can go from digit planes to partial products
+// without a hand-over through memory -- one dependent launch less per iteration of the chain.  Two groups
+// of m / 32 threads: group g transforms key rows 2 g and 2 g + 1 side by side (the two digits of one
+// accumulator polynomial), forms its share of both product columns with 64-bit multiply-adds,
+//   w_c = REDC(u_2g K[2g][c] + u_2g+1 K[2g+1][c]),   |.| < (2 * 3.95 * 2^29 * 2^28) / 2^32 + p / 2 < 0.99 * 2^29,
+// keeps w_g, hands w_(1-g) to the other group through LDS, and runs the inverse quarter of column g on
+// (w_g + w'_g) (psi^(j (2 brv(s) + 1)) - 1): |sum| < 1.98 * 2^29, after the Montgomery product < 0.63 * 2^29.
+// Same residues modulo every prime as the two-launch form, hence the same digits.
+//   lds: [group][2][m/4] transform exchange, then [2][m/4] hand-over  (6 m/4 words)
+template <int LOGM, int LE>
+__global__ void __launch_bounds__((2 * NttGeom<LOGM - 2, LE>::T))
+k_ext_quarter(const uint64_t *__restrict__ dig, const int32_t *__restrict__ keyk, int32_t *__restrict__ ypart,
+              const uint32_t *__restrict__ ua, PrimeSet PS, uint32_t mode, uint32_t k, uint32_t n) {
+    constexpr int LS = LOGM - 2;
+    using G = NttGeom<LS, LE>;
+    constexpr int M = 1 << LOGM, MS = G::M, T = G::T, E = G::E;
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const uint32_t g = (uint32_t)threadIdx.x / (uint32_t)T;          // key rows 2 g, 2 g + 1; product column g
+    const int tl = (int)((uint32_t)threadIdx.x & (uint32_t)(T - 1));
+    const uint32_t npr = PS[0].npr;
+    const uint32_t q = blockIdx.x & 3u;
+    const uint32_t pi = (blockIdx.x >> 2) % npr, b = (blockIdx.x >> 2) / npr;
+    const PrimeK P = PS[pi];
+    const Mod md = mod_of(P);
+    const int32_t sRd = (mode & MODE_RANDOM) ? P.sRr : P.sR;
+    uint32_t *const glds = lds + (size_t)g * 2 * MS;
+    int32_t *const hand = reinterpret_cast<int32_t *>(lds) + 4 * MS;
+
+    // requested first: the rotation factors of column g's slots (a gather behind the load of j) and the key
+    const uint32_t j = ua[(size_t)b * n + k];
+    int32_t dfac[E];
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+        const uint32_t sl = q * (uint32_t)MS + (uint32_t)(E * tl + e);
+        const uint32_t br = __brev(sl) >> (32 - LOGM);
+        dfac[e] = P.pw[(j * (2u * br + 1u)) & (2u * M - 1u)];
+    }
+    int4 kk[2][2][E / 4];                                           // [row of the pair][column][..]
+    {
+        const int32_t *kp = keyk + ((size_t)pi * 8 + g * 4) * M + q * MS + E * tl;
+#pragma unroll
+        for (int r = 0; r < 2; r++)
+#pragma unroll
+            for (int c = 0; c < 2; c++)
+#pragma unroll
+                for (int h = 0; h < E / 4; h++) kk[r][c][h] = reinterpret_cast<const int4 *>(kp + (size_t)(r * 2 + c) * M)[h];
+    }
+    // head: quarter q of the first two stages of both rows (k_fwd_quarter)
+    const int32_t wB = (q & 2) ? P.f3 : P.f2, wP = (q & 2) ? P.fp3 : P.fp2;
+    int32_t x[2][E];
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        const uint32_t *dl = digit_lo_plane(dig, (size_t)b * 2 + g, M) + r * M;
+        const uint16_t *dh = digit_hi_plane(dig, (size_t)b * 2 + g, M) + r * M;
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+            const uint32_t i = (uint32_t)tl + (uint32_t)(T * e);
+            int32_t X[4];
+#pragma unroll
+            for (int t = 0; t < 4; t++)
+                X[t] = digit_reduce(dl[i + t * MS] | ((uint64_t)dh[i + t * MS] << 32), md, sRd);
+            const int32_t u = smont(X[2], P.f1, md);
+            const int32_t a = (q & 2) ? X[0] - u : X[0] + u;
+            const int32_t w = sredc((int64_t)X[1] * wB + (int64_t)X[3] * wP, md);
+            x[r][e] = sred_floor((q & 1) ? a - w : a + w, md);
+        }
+    }
+    ntt_forward<LS, 2, LE>(x, glds, P.twq + (size_t)q * M, tl, md);
+    // products of the pair, both columns; the other group's column goes to the hand-over area
+    int32_t own[E];
+#pragma unroll
+    for (int h = 0; h < E / 4; h++) {
+        int32_t w[2][4];
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            const int4 a4 = kk[0][c][h], b4 = kk[1][c][h];
+            const int32_t ka[4] = {a4.x, a4.y, a4.z, a4.w}, kb[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+            for (int t = 0; t < 4; t++)
+                w[c][t] = sredc((int64_t)x[0][4 * h + t] * ka[t] + (int64_t)x[1][4 * h + t] * kb[t], md);
+        }
+        const int4 w0 = make_int4(w[0][0], w[0][1], w[0][2], w[0][3]), w1 = make_int4(w[1][0], w[1][1], w[1][2], w[1][3]);
+        const int4 keep = g ? w1 : w0, give = g ? w0 : w1;
+        own[4 * h] = keep.x; own[4 * h + 1] = keep.y; own[4 * h + 2] = keep.z; own[4 * h + 3] = keep.w;
+        reinterpret_cast<int4 *>(hand + (size_t)(1u - g) * MS + E * tl)[h] = give;
+    }
+    SGFHE_SYNC();   // hand-over written; every wave is through its forward exchanges
+    int32_t z[1][E];
+#pragma unroll
+    for (int h = 0; h < E / 4; h++) {
+        const int4 o = reinterpret_cast<const int4 *>(hand + (size_t)g * MS + E * tl)[h];
+        const int32_t ov[4] = {o.x, o.y, o.z, o.w};
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const int32_t d = scentre(dfac[4 * h + t] - P.r1, md);
+            z[0][4 * h + t] = smont(own[4 * h + t] + ov[t], d, md);
+        }
+    }
+    ntt_inverse<LS, 1, LE>(z, glds, P.twq + (size_t)q * M + MS, tl, md);
+    int32_t *yb = ypart + ((((size_t)b * 2 + g) * npr + pi) * 4 + q) * MS;
+#pragma unroll
+    for (int e = 0; e < E; e++) yb[tl + T * e] = z[0][e];
+}
+
 // One thread per coefficient i of (bootstrap, c): the last two Gentleman-Sande stages on the four partial
 // values Y_0..Y_3 at i mod m/4 of every prime --
 //   C0 = Y0 + Y1, C1 = v2 (Y0 - Y1), C2 = Y2 + Y3, C3 = v3 (Y2 - Y3);

@@ -477,8 +477,9 @@ def test_latency_form_calls_of_one_to_nine_gates(S, oc, ring):
     k_crt_lean1q: the first two forward stages and the last two inverse stages outside the
     quarter-size transforms, (x^j - 1) applied in the NTT domain).  Sizes from 1 to 9 against the C
     restatement, raw and ModRed, accumulators after 1 and 2 iterations; the one-workgroup transforms
-    (SGFHE_SMALL_SPLIT=0) and the padded launches of rounds 1-3 (SGFHE_SMALL_PADDED=1) give the same
-    bytes."""
+    (SGFHE_SMALL_SPLIT=0) and the padded launches of rounds 1-3 (SGFHE_SMALL_PADDED=1) give the same bytes.
+    From 7 gates per chain (m = 4096, 8192) the two transform kernels of the quarter form are one launch
+    (k_ext_quarter: sizes 7, 8 and the 7 + 6 of a 13-gate call here; SGFHE_SMALL_FUSED=1 takes it from one gate)."""
     if ring == "params64":
         params, noise = S.Params(64), None
     elif ring in ("params512", "params1024"):
@@ -494,7 +495,7 @@ def test_latency_form_calls_of_one_to_nine_gates(S, oc, ring):
     eng.upload_key(bkey)
     del bkey
     bits, a1, b1, a2, b2 = _mixed_inputs(o, sk, params, 9, 9)
-    sizes = {"params512": (1, 3, 4, 5, 7, 8), "params1024": (1, 7, 8)}.get(ring, (1, 2, 3, 4, 5, 8, 9))
+    sizes = {"params512": (1, 3, 4, 5, 7, 8, 13), "params1024": (1, 7, 8)}.get(ring, (1, 2, 3, 4, 5, 8, 9))
     for g in sizes:
         sl = slice(0, g)
         ref = o.bootstrap_batch(khat, a1[sl], b1[sl], a2[sl], b2[sl], opt=True, threads=_threads())
@@ -507,14 +508,14 @@ def test_latency_form_calls_of_one_to_nine_gates(S, oc, ring):
                 assert np.array_equal(eng.debug_accumulators(a1[sl], b1[sl], a2[sl], b2[sl], it), acc), (g, it)
     # the randomised flatten through the same forms (the quarter form serves both modes)
     eng.set_random_flatten(True, FKEY)
-    for call, g in enumerate((1, 3, 7, 9) if ring != "params1024" else (1, 3)):
+    for call, g in enumerate((1, 3, 7, 9) if ring != "params1024" else (1, 7)):
         sl = slice(0, g)
         ref = o.bootstrap_batch(khat, a1[sl], b1[sl], a2[sl], b2[sl], opt=True, threads=_threads(), rnd=(FKEY, call))
         assert np.array_equal(eng.bootstrap_batch(a1[sl], b1[sl], a2[sl], b2[sl]), ref), ("random", g)
     eng.close()
     ref = o.bootstrap_batch(khat, a1[:3], b1[:3], a2[:3], b2[:3], opt=True, threads=_threads())
-    for knob in ("SGFHE_SMALL_PADDED", "SGFHE_SMALL_SPLIT"):
-        os.environ[knob] = "1" if knob == "SGFHE_SMALL_PADDED" else "0"
+    for knob in ("SGFHE_SMALL_PADDED", "SGFHE_SMALL_SPLIT", "SGFHE_SMALL_FUSED"):
+        os.environ[knob] = "0" if knob == "SGFHE_SMALL_SPLIT" else "1"
         try:
             old = S.Engine(params)
         finally:

@@ -406,3 +406,33 @@ def test_quarter_form_equals_the_whole_transforms(logm):
                               RM.smont(RM.i32(c1 - c3), v1, P)])
         assert int(np.abs(got).max()) < 1.5 * 2 ** 29                # + 3 p stays a residue below 4.6 p
         assert np.array_equal(got % p, want), "inverse, j = %d" % j
+
+
+def test_fused_quarter_products_in_the_model():
+    """kernels.h k_ext_quarter between its two transforms: the pair products as one Montgomery step of a
+    64-bit sum (worst-case slot values 3.95 * 2^29 against key residues of magnitude p / 2), the two groups'
+    shares added unreduced, the rotation factor as a Montgomery product -- every step inside int32 / int64,
+    the inverse transform's entry bound kept, and the value equal modulo p to the two-launch form's
+    (four separate Montgomery products summed, k_fwd_quarter / k_inv_quarter)."""
+    C = RM.Consts(64, 512, (1 << 50) + 1, 1 << 26, 12345)
+    for P in C.pk:
+        p = P["p"]
+        rng = np.random.default_rng(p % 1000)
+        n = 4096
+        umax = int(3.95 * 2 ** 29)
+        u = rng.integers(-umax, umax + 1, size=(4, n), dtype=np.int64)
+        K = rng.integers(-(p // 2), p // 2 + 1, size=(4, n), dtype=np.int64)
+        u[:, :8] = umax * np.array([1, 1, -1, -1, 1, -1, 1, -1])            # corners
+        K[:, :8] = (p // 2) * np.array([1, -1, 1, -1, 1, 1, -1, -1])
+        d = RM.scentre(RM.i32(rng.integers(-(p // 2), p // 2 + 1, size=n, dtype=np.int64) - P["r1"]), P)
+        w = []
+        for g in range(2):
+            s = u[2 * g] * K[2 * g] + u[2 * g + 1] * K[2 * g + 1]
+            assert int(np.abs(s).max()) < 2 ** 62
+            w.append(RM.sredc(s, P))
+            assert int(np.abs(w[-1]).max()) < 0.99 * 2 ** 29
+        z = RM.smont(RM.i32(w[0] + w[1]), d, P)
+        assert int(np.abs(z).max()) < 0.75 * 2 ** 29
+        two = sum(RM.smont(u[r], K[r], P) for r in range(4))
+        assert int(np.abs(two).max()) < 2.99 * 2 ** 29
+        assert np.array_equal(z % p, RM.smont(two, d, P) % p)

@@ -8,7 +8,7 @@ for b in ${GATES:-1 2 4 8 16}; do
 import csv, glob, sys, os
 f = glob.glob(os.path.join(sys.argv[1], "**", "*kernel_stats.csv"), recursive=True)[0]
 for r in csv.DictReader(open(f)):
-    if any(k in r["Name"] for k in ("k_fwd_phase", "k_inv_column", "k_fwd_quarter", "k_inv_quarter", "k_crt_lean", "k_init", "k_final")):
+    if any(k in r["Name"] for k in ("k_fwd_phase", "k_inv_column", "k_fwd_quarter", "k_inv_quarter", "k_ext_quarter", "k_crt_lean", "k_init", "k_final")):
         print("   %-60s %8s %10.0f" % (r["Name"][:60], r["Calls"], float(r["AverageNs"])))
 PY
 done

@@ -1,10 +1,11 @@
-"""Latency of small batches at Params(1024): one call of bootstrap_batch_device per size."""
+"""Latency of small batches at Params(1024) (SGFHE_LATENCY_N=512: another Params(n)): one call of
+bootstrap_batch_device per size."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import sgfhe_jl_amd as S
 
-p = S.Params(1024)
+p = S.Params(int(os.environ.get("SGFHE_LATENCY_N", "1024")))
 eng = S.Engine(p)
 if os.environ.get("SGFHE_SMALL_MAX"):
     eng.set_small_batch_max(int(os.environ["SGFHE_SMALL_MAX"]))

@@ -24,6 +24,7 @@
 #include "../sgfhe.jl_amd/csrc/kernels.h"
 
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <vector>
 
@@ -32,6 +33,20 @@ using namespace sgfhe;
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
 
 constexpr int LOGM = 13, M = 1 << LOGM, LE3 = 3;
+
+// Round 4, second use: where a quarter kernel's microseconds go.  Timing-only switches for the two split
+// kernels (the ntt.h ones -- SGFHE_ABL_NO_TW, SGFHE_ABL_NO_LDS, SGFHE_ABL_NO_BARRIER -- apply as well):
+//   UB_NO_DIG   no input loads (digit planes / partial products)      UB_NO_KEY  no key / rotation-factor loads
+//   UB_CONST_PS the per-prime records from constant memory filled by the host instead of through the pointer
+#ifdef UB_CONST_PS
+__constant__ PrimeK c_pk[8];
+#define UB_NPR(PS) (c_pk[0].npr)
+#define UB_PRIME(PS, i) (c_pk[i])
+#else
+#define UB_NPR(PS) ((PS)[0].npr)
+#define UB_PRIME(PS, i) ((PS)[i])
+#endif
+__global__ void k_empty(uint32_t *p) { if (p && threadIdx.x == 9999) p[0] = 1; }
 
 // ---- forward -----------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(1024, 1)
@@ -73,8 +88,8 @@ k_fwd_split(const uint64_t *__restrict__ dig, const int32_t *__restrict__ keyk, 
     constexpr int T = G::T, E = G::E;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const int tid = threadIdx.x;
-    const uint32_t npr = PS[0].npr, q = blockIdx.x & 3u, ph = (blockIdx.x >> 2) & 3u, pi = (blockIdx.x >> 4) % npr;
-    const PrimeK P = PS[pi];
+    const uint32_t npr = UB_NPR(PS), q = blockIdx.x & 3u, ph = (blockIdx.x >> 2) & 3u, pi = (blockIdx.x >> 4) % npr;
+    const PrimeK P = UB_PRIME(PS, pi);
     const Mod md = mod_of(P);
     int32_t x[1][E];
     const uint32_t *dl = digit_lo_plane(dig, ph >> 1, M) + (ph & 1) * M;
@@ -88,7 +103,11 @@ k_fwd_split(const uint64_t *__restrict__ dig, const int32_t *__restrict__ keyk, 
         int32_t X[4];
 #pragma unroll
         for (int s = 0; s < 4; s++)
+#ifdef UB_NO_DIG
+            X[s] = digit_reduce((uint64_t)(i + s) * 0x9E3779B97F4Aull, md, P.sR);
+#else
             X[s] = digit_reduce(dl[i + s * MS] | ((uint64_t)dh[i + s * MS] << 32), md, P.sR);
+#endif
         const int32_t u = smont(X[2], wA, md);
         const int32_t a = (q & 2) ? X[0] - u : X[0] + u;
         const int32_t sgn = sredc((int64_t)X[1] * wB + (int64_t)X[3] * wP, md);
@@ -99,7 +118,11 @@ k_fwd_split(const uint64_t *__restrict__ dig, const int32_t *__restrict__ keyk, 
     int32_t *zp = zpart + (((size_t)pi * 4 + ph) * 2) * M + q * MS + E * tid;
 #pragma unroll
     for (int h = 0; h < E / 4; h++) {
+#ifdef UB_NO_KEY
+        const int4 a = make_int4(tid, h, 5, 7), bq = make_int4(h, tid, 3, 9);
+#else
         const int4 a = reinterpret_cast<const int4 *>(kp)[h], bq = reinterpret_cast<const int4 *>(kp + M)[h];
+#endif
         const int32_t ka[4] = {a.x, a.y, a.z, a.w}, kb[4] = {bq.x, bq.y, bq.z, bq.w};
         int32_t r0[4], r1[4];
 #pragma unroll
@@ -156,8 +179,8 @@ k_inv_split(const int32_t *__restrict__ zpart, uint32_t *__restrict__ ypart, Pri
     constexpr int T = G::T, E = G::E;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const int tid = threadIdx.x;
-    const uint32_t npr = PS[0].npr, q = blockIdx.x & 3u, c = (blockIdx.x >> 2) & 1u, pi = (blockIdx.x >> 3) % npr;
-    const PrimeK P = PS[pi];
+    const uint32_t npr = UB_NPR(PS), q = blockIdx.x & 3u, c = (blockIdx.x >> 2) & 1u, pi = (blockIdx.x >> 3) % npr;
+    const PrimeK P = UB_PRIME(PS, pi);
     const Mod md = mod_of(P);
     int32_t z[1][E];
     const int32_t *zp = zpart + (((size_t)pi * 4) * 2 + c) * M + q * MS + E * tid;
@@ -167,10 +190,18 @@ k_inv_split(const int32_t *__restrict__ zpart, uint32_t *__restrict__ ypart, Pri
         int32_t acc[4] = {0, 0, 0, 0};
 #pragma unroll
         for (int ph = 0; ph < 4; ph++) {
+#ifdef UB_NO_DIG
+            const int4 v = make_int4(tid + ph, h, 3, ph);
+#else
             const int4 v = reinterpret_cast<const int4 *>(zp + (size_t)ph * 2 * M)[h];
+#endif
             acc[0] += v.x; acc[1] += v.y; acc[2] += v.z; acc[3] += v.w;
         }
+#ifdef UB_NO_KEY
+        const int4 d = make_int4(tid, h, 11, 13);
+#else
         const int4 d = reinterpret_cast<const int4 *>(dg)[h];
+#endif
         const int32_t dd[4] = {d.x, d.y, d.z, d.w};
 #pragma unroll
         for (int t = 0; t < 4; t++) z[0][4 * h + t] = smont(acc[t], dd[t], md);   // (x^j - 1) in the NTT domain
@@ -257,6 +288,9 @@ int main() {
     PrimeK *d_pk;
     CHECK(hipMalloc(&d_pk, npr * sizeof(PrimeK)));
     CHECK(hipMemcpy(d_pk, pk.data(), npr * sizeof(PrimeK), hipMemcpyHostToDevice));
+#ifdef UB_CONST_PS
+    CHECK(hipMemcpyToSymbol(HIP_SYMBOL(c_pk), pk.data(), npr * sizeof(PrimeK)));
+#endif
     uint64_t *d_dig;
     int32_t *d_key, *d_z, *d_diag;
     uint32_t *d_y;
@@ -273,6 +307,16 @@ int main() {
     CHECK(hipFuncSetAttribute((const void *)k_fwd_full, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * M));
     CHECK(hipFuncSetAttribute((const void *)k_inv_full, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * M));
     const int iters = 2000;
+    if (getenv("UB_ANATOMY")) {   // the split kernels only, one line (for the ablation builds)
+        const double e0 = chain_us([&] { hipLaunchKernelGGL(k_empty, dim3(80), dim3(256), 0, 0, (uint32_t *)nullptr); }, iters);
+        const double fs = chain_us([&] { hipLaunchKernelGGL(k_fwd_split, dim3(npr * 16), dim3(256), M, 0, d_dig, d_key, d_z, d_pk); }, iters);
+        const double vs = chain_us([&] { hipLaunchKernelGGL(k_inv_split, dim3(npr * 8), dim3(256), M, 0, d_z, d_y, d_pk, d_diag); }, iters);
+        const uint32_t quads = 2 * M / 4;
+        const double cs = chain_us([&] { hipLaunchKernelGGL((k_crt_loads<5, true>), dim3((quads + 255) / 256), dim3(256), 0, 0, d_y, d_dig, d_pk, quads); }, iters);
+        printf("%-28s empty %.2f   forward quarter %.2f   inverse quarter %.2f   CRT loads %.2f  (us per dependent launch)\n",
+               getenv("UB_ANATOMY"), e0, fs, vs, cs);
+        return 0;
+    }
     const double ff = chain_us([&] { hipLaunchKernelGGL(k_fwd_full, dim3(npr * 4), dim3(1024), 4 * M, 0, d_dig, d_key, d_z, d_pk); }, iters);
     const double fs = chain_us([&] { hipLaunchKernelGGL(k_fwd_split, dim3(npr * 16), dim3(256), M, 0, d_dig, d_key, d_z, d_pk); }, iters);
     const double vf = chain_us([&] { hipLaunchKernelGGL(k_inv_full, dim3(npr * 2), dim3(1024), 4 * M, 0, d_z, d_y, d_pk, 77u); }, iters);
