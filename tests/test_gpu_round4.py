@@ -523,3 +523,35 @@ def test_latency_form_calls_of_one_to_nine_gates(S, oc, ring):
         old.generate_key(sk, 8, noise=noise) if noise is None else old.upload_key(o.bootstrap_key(sk, 8, noise=noise))
         assert np.array_equal(old.bootstrap_batch(a1[:3], b1[:3], a2[:3], b2[:3]), ref), knob
         old.close()
+
+
+def test_latency_form_boundaries_at_params512(S, oc):
+    """The call sizes at which the engine changes its form of the k-loop, Params(512) (m = 4096: every latency
+    form exists), both flatten modes, every output word against the C restatement: 6 gates (the last size of
+    the two-launch quarter form), 12 (the largest single chain of k_ext_quarter launches on five primes), 14
+    (7 + 7 on the two lanes), 24 (12 + 12, the largest call in the latency form), 25 (13 + 12 ... the first
+    call in the throughput form, an odd size) -- and with the randomised flatten 10, 11 (the fused chain's limit
+    on the basis that mode runs on), 13, 24, 25, each call on its own stream position (call counter)."""
+    params = S.Params(512)
+    o = oc.Oracle.from_params(params)
+    sk = o.private_key(31)
+    bkey = o.bootstrap_key(sk, 32)
+    khat = o.key_transform(bkey, threads=_threads())
+    eng = S.Engine(params)
+    eng.upload_key(bkey)
+    del bkey
+    bits, a1, b1, a2, b2 = _mixed_inputs(o, sk, params, 25, 33)
+    for g in (6, 12, 14, 24, 25):
+        sl = slice(25 - g, 25)                       # the tail: other rows than the sizes before
+        ref = o.bootstrap_batch(khat, a1[sl], b1[sl], a2[sl], b2[sl], opt=True, threads=_threads())
+        assert np.array_equal(eng.bootstrap_batch(a1[sl], b1[sl], a2[sl], b2[sl]), ref), g
+    y1, y2 = bits[0::2], bits[1::2]
+    out = eng.bootstrap_batch(a1, b1, a2, b2)
+    dec = o.lwe_decrypt_bits(sk, out[:len(y1), 2, :params.n], out[:len(y1), 2, params.n])
+    assert np.array_equal(dec, y1 ^ y2)
+    eng.set_random_flatten(True, FKEY)
+    for call, g in enumerate((10, 11, 13, 24, 25)):
+        sl = slice(0, g)
+        ref = o.bootstrap_batch(khat, a1[sl], b1[sl], a2[sl], b2[sl], opt=True, threads=_threads(), rnd=(FKEY, call))
+        assert np.array_equal(eng.bootstrap_batch(a1[sl], b1[sl], a2[sl], b2[sl]), ref), ("random", g)
+    eng.close()
