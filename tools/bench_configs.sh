@@ -16,7 +16,7 @@ run params512_b4096 --config params512 --batch 4096 --steps 5 --warmup 1 --no-cp
 run params64 --config params64 --batch 16384 --steps 10 --warmup 2 --no-cpu-baseline
 run params2048 --config params2048 --batch 1024 --steps 2 --warmup 1 --no-cpu-baseline
 run params2048_random --config params2048 --batch 1024 --flatten random --steps 2 --warmup 1 --no-cpu-baseline --no-host-io
-python tools/latency.py 1 8 16 24 32 64 256 512 > $O/latency_${TAG}.txt 2>&1
+python tools/latency.py 1 2 4 7 8 12 16 24 32 64 128 256 512 > $O/latency_${TAG}.txt 2>&1
 cat $O/latency_${TAG}.txt
 for f in $O/bench_${TAG}_*.json; do python - "$f" <<'PY'
 import json, sys
