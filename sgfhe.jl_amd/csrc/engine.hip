@@ -132,6 +132,7 @@ struct sgfhe_ctx {
     // the quarter form's two transform kernels as one launch (k_ext_quarter) from this many gates per chain, up to
     // what fills the device once (fused_cap below); SGFHE_SMALL_FUSED=0: never, =n: from n gates
     uint32_t fused_min = 7;
+    bool iter_all = false;     // -DSGFHE_WITH_ITER_ALL builds, SGFHE_ITER_ALL=1: one launch per iteration (prototype)
     uint32_t split_max = 7;   // calls of at most this many gates take the quarter form (SGFHE_SMALL_SPLIT, 0 = never):
                               // 1 / 2 / 4 / 6 / 8 gates 15.1 / 15.9 / 17.8 / 19.7 / 23.5 ms against 17.9 / 18.6 / 20.3 /
                               // 22.0 / 23.3 with one workgroup per transform (profiles/r04_exp_quarter.txt)
@@ -201,7 +202,7 @@ struct sgfhe_ctx {
     // per device; a ctx is bound to one device and used by one host thread)
     uint32_t attr_done = 0;
 };
-enum : uint32_t { ATTR_EXTPROD = 1u, ATTR_SMALL = 2u, ATTR_SHORTPROD = 4u, ATTR_FUSED = 8u };
+enum : uint32_t { ATTR_EXTPROD = 1u, ATTR_SMALL = 2u, ATTR_SHORTPROD = 4u, ATTR_FUSED = 8u, ATTR_ITER = 16u };
 // Page-locked mirrors of the host-pointer entry point's staging buffers: per buffer at most this much
 // (a batch of 16384 at Params(1024) needs 268 + 403 MB).  Round 3 staged whole buffers and stopped at
 // 48 MB, where one CPU memcpy cost what pinning the caller's pages did; the copies are now pipelined
@@ -349,6 +350,23 @@ int32_t launch_extprod(sgfhe_ctx *c, const sgfhe_ctx::Lane &L, const int32_t *ke
     }
     return fail(c, SGFHE_ERR_UNSUPPORTED, "unsupported log2(m)");
 }
+
+#ifdef SGFHE_WITH_ITER_ALL   // prototype, not in the default build (kernels.h)
+// One launch per iteration (kernels.h k_iter_all): deterministic flatten, m = 8192, five primes, lean CRT constants.
+int32_t launch_iter_all(sgfhe_ctx *c, const sgfhe_ctx::Lane &L, const int32_t *keyk, uint32_t cnt, uint32_t k,
+                        hipStream_t st) {
+    constexpr int LM = 13;
+    const size_t lds = lds_bytes(LM, 2 + SGFHE_IA_LP);   // exchange buffer of the inverse pair + the private accumulator planes
+    if (!(c->attr_done & ATTR_ITER)) {
+        HIPCHK(c, hipFuncSetAttribute((const void *)k_iter_all<LM, 5, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        c->attr_done |= ATTR_ITER;
+    }
+    hipLaunchKernelGGL((k_iter_all<LM, 5, 3>), dim3(cnt), dim3(NttGeom<LM, 3>::T), lds, st, L.dig, keyk, L.ua,
+                       c->d_primes, c->d_lean, k, c->n);
+    HIPCHK(c, hipGetLastError());
+    return SGFHE_OK;
+}
+#endif
 
 template <int LOGM>
 int32_t launch_small_t(sgfhe_ctx *c, const sgfhe_ctx::Lane &L, const int32_t *keyk, uint32_t cpad,
@@ -753,6 +771,13 @@ int32_t run_iterations(sgfhe_ctx *c, ChunkJob *jobs, int njobs, uint64_t n_iters
             // a few gates, deterministic flatten, m >= 4096: each transform cut across four workgroups
             // (both flatten modes; not the three-plane digit records of B >= 2^46, MODE_WIDE)
             const bool quarter = small && quarter_ok(c, mode) && (cnt <= c->split_max || fused_takes(c, cnt, mode));
+#ifdef SGFHE_WITH_ITER_ALL
+            if (!small && c->iter_all && mode == 0u && c->logm == 13 && c->npr == 5 && c->use_lean && c->h_lean.nl == 3) {
+                const int32_t rci = launch_iter_all(c, *J.L, c->d_key + k * slice, J.cpad, (uint32_t)k, J.st);
+                if (rci) return rci;
+                continue;
+            }
+#endif
             int32_t rc = quarter ? launch_quarter(c, *J.L, c->d_key + k * slice, cnt, (uint32_t)k, mode, J.st)
                          : small ? launch_small(c, *J.L, c->d_key + k * slice, cnt, (uint32_t)k, mode, J.st)
                                  : launch_extprod(c, *J.L, c->d_key + k * slice, J.cpad, (uint32_t)k, mode, J.st);
@@ -1391,6 +1416,8 @@ int32_t build_constants(sgfhe_ctx *c) {
     {
         const char *env = getenv("SGFHE_SMALL_SPLIT");
         if (env) c->split_max = (uint32_t)atoi(env);
+        env = getenv("SGFHE_ITER_ALL");
+        c->iter_all = env && env[0] == '1';
         env = getenv("SGFHE_SMALL_FUSED");
         if (env) c->fused_min = (uint32_t)atoi(env);
     }

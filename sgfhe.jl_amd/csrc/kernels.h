@@ -913,7 +913,9 @@ k_crt_lean(const uint32_t *__restrict__ yres, uint64_t *__restrict__ dig,
     uint4 yv[NP];
 #pragma unroll
     for (int q = 0; q < NP; q++) {
-#ifdef SGFHE_CRT_PLAIN_LOADS  // (A/B builds)
+#ifdef SGFHE_ABL_NO_YLOAD       // timing-only build: no residue loads (wrong results)
+        yv[q] = make_uint4(t + q, yo, i + 7u * q, bc);
+#elif defined(SGFHE_CRT_PLAIN_LOADS)  // (A/B builds)
         yv[q] = ld_off<uint4>(yres, yo + ((uint32_t)(4 * q) << logm));
 #else
         const v4u t = __builtin_nontemporal_load(reinterpret_cast<const v4u *>(
@@ -1100,6 +1102,158 @@ k_crt_lean_rnd1(const uint32_t *__restrict__ yres, uint64_t *__restrict__ dig,
     crt_lean_one<NP, NL, true>(y, d.x + (xm2 - r0), d.y + (xm2 - r1), K, lo, hi);
     store_digits(dig, bc, i, M, lo + r0, hi + r1);
 }
+
+// ---- one launch per iteration: the residues never leave the compute unit (round 4, PROTOTYPE) -------------------
+// Compiled only with -DSGFHE_WITH_ITER_ALL (tools/exp_r4_iter_all.sh); selected at run time by SGFHE_ITER_ALL=1.
+// Bit-exact (tests/test_gpu_parity.py::test_params1024_vs_oracle under that switch), and 17 % SLOWER than the two
+// kernels it replaces (1737 against 2083 bootstraps/s, same call, profiles/r04_exp_iter_all.txt): one workgroup of
+// 1024 threads per compute unit means every one of its ~135 workgroup barriers per iteration stalls the whole
+// compute unit, where two co-resident k_extprod workgroups fill each other's stalls; 8 points per thread cost a
+// fifth LDS pass per transform; and the register file (128 per thread) holds the transform's working set beside
+// 56 accumulators only, so column 1 of three primes lives in LDS.  Kept as the starting point for a design that
+// removes the hand-off without giving up two independent instruction streams per compute unit.
+#ifdef SGFHE_WITH_ITER_ALL
+// k_extprod hands 20 bytes per coefficient to the CRT kernel through memory, and that hand-off costs 11 % of the
+// path's throughput -- as clock: the socket is at its power limit (profiles/r04_exp_clock_handoff.txt).  Here one
+// workgroup of m / 8 threads owns a bootstrap with ALL its primes: every thread keeps the NTT-domain sums of both
+// product columns for every prime in registers (NP x 2 x 8), runs the forward transforms prime by prime inside the
+// phase loop, then per prime the inverse pair and the rotation in place, and ends with the CRT / accumulate /
+// flatten of its own 16 coefficients (crt_lean_one) -- no yres, no second kernel.  8 points per thread (the
+// register file holds 128 registers for each of 1024 threads); deterministic flatten, NP <= 5.
+// The prime index is a template parameter (recursion over PI) so that the accumulator arrays are only ever
+// indexed by constants: a `#pragma unroll` inside the rolled phase loop is not honoured, and a dynamically
+// indexed array lives in scratch memory.  Column 1 of the first LP primes accumulates in LDS (private words, as
+// k_extprod's z1), the rest in registers.
+template <int LOGM, int NP, int LP>
+struct IterAll {
+    static constexpr int LE = 3;
+    using G = NttGeom<LOGM, LE>;
+    static constexpr int M = G::M, T = G::T, E = G::E;
+    // private LDS word e of prime pi's column 1 (pi < LP): behind the 2 m words of the exchange buffer
+    static __device__ __forceinline__ int32_t *priv(uint32_t *lds, int pi, int tid) {
+        return reinterpret_cast<int32_t *>(lds) + (2 + pi) * M + tid;
+    }
+    template <int PI>
+    static __device__ __forceinline__ void forward(int32_t (&a0)[NP][E], int32_t (&a1)[NP - LP][E],
+                                                   const uint64_t *__restrict__ dig, uint32_t b,
+                                                   const int32_t *__restrict__ keyk, PrimeSet PS, uint32_t *lds, int ph) {
+        if constexpr (PI < NP) {
+            const PrimeK P = PS[PI];
+            const Mod md = mod_of(P);
+            // addresses behind an opaque zero: the loads of this prime are not hoisted over the work of the one before
+            const int tid = (int)threadIdx.x + (int)opaque_zero();
+            const uint32_t *dl = digit_lo_plane(dig, (size_t)b * 2 + (ph >> 1), M) + (ph & 1) * M;
+            const uint16_t *dh = digit_hi_plane(dig, (size_t)b * 2 + (ph >> 1), M) + (ph & 1) * M;
+            int32_t x[1][E];
+#pragma unroll
+            for (int e = 0; e < E; e++)
+                x[0][e] = digit_reduce(dl[tid + T * e] | ((uint64_t)dh[tid + T * e] << 32), md, P.sR);
+            SGFHE_SYNC();   // the exchange buffer is reused
+            ntt_forward<LOGM, 1, LE>(x, lds, P.twf, tid, md);
+            const int32_t *kp = keyk + ((size_t)PI * 8 + ph * 2) * M + E * (tid + (int)opaque_zero());
+#pragma unroll
+            for (int h = 0; h < E / 4; h++) {
+                const int4 a = reinterpret_cast<const int4 *>(kp)[h];
+                const int4 bq = reinterpret_cast<const int4 *>(kp + M)[h];
+                const int32_t ka[4] = {a.x, a.y, a.z, a.w}, kb[4] = {bq.x, bq.y, bq.z, bq.w};
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    const int e = 4 * h + t;
+                    a0[PI][e] += smont(x[0][e], ka[t], md);   // four phases: < 2.99 * 2^29
+                    if constexpr (PI < LP) priv(lds, PI, tid)[e * T] += smont(x[0][e], kb[t], md);
+                    else a1[PI - LP][e] += smont(x[0][e], kb[t], md);
+                }
+            }
+            forward<PI + 1>(a0, a1, dig, b, keyk, PS, lds, ph);
+        }
+    }
+    // inverse pair, rotation and residue form of prime PI, back into the accumulators' places
+    template <int PI>
+    static __device__ __forceinline__ void inverse(int32_t (&a0)[NP][E], int32_t (&a1)[NP - LP][E], PrimeSet PS,
+                                                   uint32_t *lds, uint32_t j) {
+        if constexpr (PI < NP) {
+            const PrimeK P = PS[PI];
+            const Mod md = mod_of(P);
+            const int tid = (int)threadIdx.x + (int)opaque_zero();
+            int32_t z[2][E];
+#pragma unroll
+            for (int e = 0; e < E; e++) {
+                z[0][e] = sred(a0[PI][e], md);
+                if constexpr (PI < LP) z[1][e] = sred(priv(lds, PI, tid)[e * T], md);
+                else z[1][e] = sred(a1[PI - LP][e], md);
+            }
+            SGFHE_SYNC();
+            ntt_inverse<LOGM, 2, LE>(z, lds, P.twi, tid, md);   // |.| < 1.4 * 2^29
+            lds_store<LOGM, 2, LE, G::STOP>(z, lds, tid);
+            SGFHE_SYNC();
+            constexpr uint32_t LOWMASK = (1u << G::STOP) - 1u;
+            const uint32_t s0 = ((uint32_t)tid - j) & (2 * M - 1);
+            const uint32_t lowswz = swz<LE>(s0 & LOWMASK);
+            const uint32_t h0 = s0 >> G::STOP;
+            const uint32_t yoff = 3u * (uint32_t)P.p + P.hoff;
+#pragma unroll
+            for (int e = 0; e < E; e++) {
+                const uint32_t he = h0 + e;
+                const uint32_t hipart = (he & (E - 1)) << G::STOP;
+                const uint32_t addr = hipart ^ lowswz ^ (G::STOP >= 9 ? 0u : swz_bits<LE>(hipart));
+                const uint32_t smask = 0u - ((he >> LE) & 1u);
+                const uint32_t yoe = yoff - smask;
+                // the residues k_extprod stores
+                a0[PI][e] = (int32_t)((lds[addr] ^ smask) + (yoe - (uint32_t)z[0][e]));
+                const int32_t y1 = (int32_t)((lds[M + addr] ^ smask) + (yoe - (uint32_t)z[1][e]));
+                if constexpr (PI < LP) priv(lds, PI, tid)[e * T] = y1;
+                else a1[PI - LP][e] = y1;
+            }
+            inverse<PI + 1>(a0, a1, PS, lds, j);
+        }
+    }
+};
+
+template <int LOGM, int NP, int NL>
+__global__ void __launch_bounds__((NttGeom<LOGM, 3>::T))
+k_iter_all(uint64_t *__restrict__ dig, const int32_t *__restrict__ keyk, const uint32_t *__restrict__ ua,
+           PrimeSet PS, const CrtLean *__restrict__ K, uint32_t k, uint32_t n) {
+#ifndef SGFHE_IA_LP
+#define SGFHE_IA_LP 3
+#endif
+    constexpr int LP = SGFHE_IA_LP;
+    using IA = IterAll<LOGM, NP, LP>;
+    constexpr int M = IA::M, T = IA::T, E = IA::E;
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];   // (2 + LP) m words
+    const uint32_t b = blockIdx.x;
+    int32_t a0[NP][E], a1[NP - LP][E];
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+#pragma unroll
+        for (int q = 0; q < NP; q++) a0[q][e] = 0;
+#pragma unroll
+        for (int q = 0; q < NP - LP; q++) a1[q][e] = 0;
+#pragma unroll
+        for (int q = 0; q < LP; q++) IA::priv(lds, q, (int)threadIdx.x)[e * T] = 0;
+    }
+#pragma unroll 1
+    for (int ph = 0; ph < 4; ph++) IA::template forward<0>(a0, a1, dig, b, keyk, PS, lds, ph);
+    IA::template inverse<0>(a0, a1, PS, lds, ua[(size_t)b * n + k]);
+#pragma unroll
+    for (int c = 0; c < 2; c++)
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+#ifdef SGFHE_IA_NOCRT
+            if (c + e >= 0) continue;
+#endif
+            const int tid = (int)threadIdx.x + (int)opaque_zero();   // one coefficient's loads at a time
+            uint32_t y[NP];
+#pragma unroll
+            for (int q = 0; q < NP; q++)
+                y[q] = (uint32_t)(c == 0 ? a0[q][e] : q < LP ? IA::priv(lds, q, tid)[e * T] : a1[q < LP ? 0 : q - LP][e]);
+            const uint32_t i = (uint32_t)tid + (uint32_t)(T * e);
+            const ulonglong2 d = load_digits(dig, (size_t)b * 2 + c, i, M);
+            uint64_t lo, hi;
+            crt_lean_one<NP, NL>(y, d.x, d.y, K, lo, hi);
+            store_digits(dig, (size_t)b * 2 + c, i, M, lo, hi);
+        }
+}
+#endif  // SGFHE_WITH_ITER_ALL
 
 // ---- small-batch ("latency") form of the external product --------------------------------------
 // A call with a handful of gates leaves most of the 256 CUs idle while one workgroup per
