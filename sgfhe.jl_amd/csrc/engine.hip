@@ -845,7 +845,8 @@ int32_t bootstrap_device(sgfhe_ctx *c, const uint64_t *a1, const uint64_t *b1, c
         // split: 48 bootstraps run at 1277 per second as one chunk and at 1024 as 24 + 24.
         const size_t pairs = (batch + 2 * (size_t)chunk - 1) / (2 * (size_t)chunk);
         chunk = round_up8((uint32_t)((batch + 2 * pairs - 1) / (2 * pairs)));
-    } else if (!c->chunk && c->lanes == 2 && c->small_lanes && batch >= (fused_cap(c, mode) ? fused_cap(c, mode) + 1 : 8u) &&
+    } else if (!c->chunk && c->lanes == 2 && c->small_lanes && c->logm >= 12 &&
+               batch >= (fused_cap(c, mode) ? fused_cap(c, mode) + 1 : 8u) &&
                batch <= c->small_lanes_max && (batch + 1) / 2 <= c->small_max) {
         // A call of 8 to 24 gates in the latency form: two halves on the two lanes.  Each half is a chain of
         // dependent launches on a mostly idle device, and two chains overlap; the halves need no rounding
@@ -858,6 +859,9 @@ int32_t bootstrap_device(sgfhe_ctx *c, const uint64_t *a1, const uint64_t *b1, c
         // chains of half the size or less (8 / 10 / 12 gates 20.9 / 21.9 / 22.7 ms against 21.0 / 22.0 / 22.9;
         // Params(512) 7.7 / 8.0 / 8.3 against 9.1 / 9.0 / 9.2), and the halves of 13 to 24 gates take it
         // (profiles/r04_exp_fused.txt): two chains from 13 gates there.
+        // Rings below m = 4096 stay on one chain: their launches are too short for two chains to overlap, and
+        // the halves then cost their sum (Params(64) / (128) / (256), 8 to 24 gates: 1.4 / 2.75 / 5.4 ms as two
+        // halves against 0.7 / 1.4 / 3.3 as one chunk, profiles/r04_exp_small_rings_lanes.txt).
         chunk = (uint32_t)((batch + 1) / 2);
     }
     const uint32_t n = c->n, M = c->M;
