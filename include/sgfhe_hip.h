@@ -117,7 +117,7 @@ const char *sgfhe_last_error_string(const sgfhe_ctx *ctx);
  * other, with twice the default chunk.  Every setting gives bit-identical results, in both
  * flatten modes. */
 int32_t sgfhe_set_chunk(sgfhe_ctx *ctx, uint32_t chunk);
-/* Chunks of at most this many bootstraps (default 24, 0 = never, at most 256) run the k-loop in
+/* Chunks of at most this many bootstraps (default 24, 16 at m = 16384; 0 = never, at most 256) run the k-loop in
  * its small-batch form: 6 workgroups per (bootstrap, RNS prime) and three launches per iteration
  * instead of 1 and two, which shortens the serial chain a single bootstrap() call waits for.
  * Same results bit for bit. */

@@ -1413,6 +1413,9 @@ int32_t build_constants(sgfhe_ctx *c) {
         if (env) { c->small_lanes = atoi(env) != 0; if (atoi(env) > 1) c->small_lanes_max = (uint32_t)atoi(env); }
         env = getenv("SGFHE_CRT1_GATES");
         c->crt1_max = (uint32_t)(env ? atoi(env) : 8) * 2u * c->M;
+        // m = 16384: the latency form ends at 16 gates (20 / 24 gates take 114 / 144 ms in it, 112 / 112 in the
+        // throughput form; 12 / 14 gates 86 / 93 against 107; profiles/r04_exp_small_rings_lanes.txt)
+        if (c->logm >= 14) { c->small_max = 16; if (c->small_lanes_max > 16) c->small_lanes_max = 16; }
     }
     HIPCHK(c, hipMalloc(&c->d_tw, (size_t)c->npr_max * 4 * c->M * sizeof(int32_t)));
     HIPCHK(c, hipMalloc(&c->d_twq, (size_t)c->npr_max * 4 * c->M * sizeof(int32_t)));
