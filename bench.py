@@ -40,6 +40,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_HBM_GBS = 8000.0     # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+NOMINAL_SCLK_HZ = 2.4e9   # "Max clock 2400 MHz", same guide (the clock under this workload is 2.1-2.3 GHz)
 W_BYTES = {"params1024": 16, "params512": 16, "params2048": 16, "params64": 8, "synth64": 8,
            "rns2": 16}
 
@@ -120,7 +121,32 @@ def _counters(config, chunk, build_id):
     return None, "no committed counters for chunk %d" % chunk
 
 
+def _elf_interpreter():
+    """The interpreter binary to put after `rocprofv3 ... --`: the resolved sys.executable, and only if it
+    is an ELF file.  The profiler's preloaded library initialises the GPU before the program starts, so a
+    shim in between (pyenv / conda wrapper script, `#!/usr/bin/env`) would be an exec from a process that
+    has initialised the GPU -- which this pool forbids.  Returns (path, None) or (None, reason)."""
+    exe = os.path.realpath(sys.executable or "")
+    try:
+        with open(exe, "rb") as f:
+            magic = f.read(4)
+    except OSError as e:
+        return None, "cannot read the interpreter %r: %s" % (exe, e)
+    if magic != b"\x7fELF":
+        return None, "the interpreter %r is not an ELF binary (a wrapper script must not sit behind rocprofv3)" % exe
+    return exe, None
+
+
 def live_counters(args, chunk, kernels, rnd):
+    """Never raises: whatever goes wrong in the child passes or in reading their output, the headline line
+    is still printed, with the committed counters of the same build and the reason."""
+    try:
+        return _live_counters(args, chunk, kernels, rnd)
+    except Exception as e:                              # noqa: BLE001 -- a measurement aid must not cost the line
+        return None, "live counter passes failed: %r" % (e,)
+
+
+def _live_counters(args, chunk, kernels, rnd):
     """HBM traffic and VALU instruction counts of the two k-loop kernels measured NOW, on this box:
     rocprofv3 --pmc passes run as child processes of this bench (one counter group per pass,
     --kernel-trace only, as /opt/skills/guides/MI355X_MICROARCH.md prescribes), each over one chunk of
@@ -130,7 +156,10 @@ def live_counters(args, chunk, kernels, rnd):
     (None, reason); the caller falls back to the committed profile of the same build."""
     if shutil.which("rocprofv3") is None:
         return None, "rocprofv3 is not on PATH"
-    one = ["python3", os.path.abspath(__file__), "--config", args.config, "--lanes", "1", "--chunk", str(chunk),
+    exe, why = _elf_interpreter()
+    if exe is None:
+        return None, why
+    one = [exe, os.path.abspath(__file__), "--config", args.config, "--lanes", "1", "--chunk", str(chunk),
            "--batch", str(chunk), "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-host-io",
            "--no-live-counters", "--flatten", "random" if rnd else "deterministic"]
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
@@ -147,11 +176,12 @@ def live_counters(args, chunk, kernels, rnd):
                 return None, "rocprofv3 --pmc %s failed: %s" % (" ".join(group), r.stderr[-300:])
             vals = {}   # kernel -> grid -> counter -> [values]
             for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
-                for row in csv.DictReader(open(f)):
-                    for k in kernels:
-                        if "::" + k + "<" in row["Kernel_Name"]:
-                            vals.setdefault(k, {}).setdefault(row["Grid_Size"], {}).setdefault(
-                                row["Counter_Name"], []).append(float(row["Counter_Value"]))
+                with open(f, newline="") as fh:
+                    for row in csv.DictReader(fh):
+                        for k in kernels:
+                            if "::" + k + "<" in row["Kernel_Name"]:
+                                vals.setdefault(k, {}).setdefault(row["Grid_Size"], {}).setdefault(
+                                    row["Counter_Name"], []).append(float(row["Counter_Value"]))
             for k in kernels:
                 if k not in vals:
                     return None, "no %s launches in the --pmc %s pass" % (k, " ".join(group))
@@ -165,6 +195,8 @@ def live_counters(args, chunk, kernels, rnd):
         finally:
             shutil.rmtree(d, ignore_errors=True)
     for k in kernels:
+        if "FETCH_SIZE" not in out[k] or "WRITE_SIZE" not in out[k]:
+            return None, "the --pmc passes returned no FETCH_SIZE / WRITE_SIZE for %s" % k
         out[k]["traffic_bytes_per_launch"] = (2 * out[k]["FETCH_SIZE"] + out[k]["WRITE_SIZE"]) * 1024
     out["source"] = ("measured in this run: rocprofv3 --pmc child passes (FETCH_SIZE | WRITE_SIZE | SQ_INSTS_VALU "
                      "SQ_WAVES, --kernel-trace only) over one %d-bootstrap chunk on one lane, %.0f s"
@@ -180,7 +212,10 @@ VALU_RATE = {"mad64": 32.39, "mul": 34.38, "fast": 56.08, "slow": 36.0,
              "simple": 56.08}   # "simple": profiles before r03_v10 did not split fast / slow
 
 
-def valu_roofline(c, ext_s):
+RAW_LANES_PER_CU = 4 * 32   # four SIMDs issuing 32 lanes per clock (a wave64 instruction in two passes)
+
+
+def valu_roofline(c, ext_s, cus=None, sclk_hz=None):
     """The bound that actually limits k_extprod: integer VALU issue.  achieved = VALU
     instructions per launch (PMC SQ_INSTS_VALU) x 64 lanes / launch time; peak = the
     micro-benchmarked issue rate of the kernel's own static instruction mix (fractions of
@@ -191,8 +226,17 @@ def valu_roofline(c, ext_s):
     insts = c["k_extprod"]["SQ_INSTS_VALU"]
     peak = 1.0 / sum(mix[k] / VALU_RATE[k] for k in VALU_RATE if k in mix)
     ach = insts * 64 / ext_s / 1e12
-    return {"bound": "valu-int32", "achieved": ach, "peak": peak, "unit": "Tlane-op/s",
-            "frac": ach / peak, "valu_insts_per_launch": insts, "mix": mix, "source": c["source"]}
+    res = {"bound": "valu-int32", "achieved": ach, "peak": peak, "unit": "Tlane-op/s",
+           "frac": ach / peak,
+           "peak_is": "issue rate of this kernel's own static instruction mix, priced with tools/ubench_int.hip "
+                      "(64-bit multiply-adds and 32-bit multiplies issue at about half the add rate): NOT the "
+                      "device's raw lane rate -- that is raw_peak / raw_frac",
+           "valu_insts_per_launch": insts, "mix": mix, "source": c["source"]}
+    if cus and sclk_hz:   # the unpriced figure beside it: every lane, every clock, nominal clock
+        raw = cus * RAW_LANES_PER_CU * sclk_hz / 1e12
+        res.update({"raw_peak": raw, "raw_frac": ach / raw,
+                    "raw_peak_is": "%d CUs x 4 SIMDs x 32 lanes x %.2f GHz nominal" % (cus, sclk_hz / 1e9)})
+    return res
 
 
 def _cpu_budget():
@@ -211,12 +255,13 @@ def _cpu_budget():
     return avail, quota
 
 
-def cpu_baseline(p, sk, key_seed, cap, seconds_target=8.0):
+def cpu_baseline(p, sk, key_seed, cap, seconds_target=8.0, seconds_full=30.0):
     """The CPU path timed on the host cores of this box, in the same run.
     `port` = oracle/sgfhe_oracle.c, reference-shaped (128-bit Montgomery, 24 NTTs per iteration --
     what the Julia reference executes), one independent bootstrap per thread (OpenMP over the
-    batch, the sharding the GPUs use), over a k-loop truncated to about `seconds_target` seconds
-    and scaled to the full loop; `opt` = the same arithmetic in the GPU path's algebra (key in the
+    batch, the sharding the GPUs use), over the WHOLE k-loop when that is estimated to take at most
+    `seconds_full` seconds (Params(1024) on this pool's boxes: about 16 s -- "1024 of 1024 iterations", no
+    scaling), else over a k-loop truncated to about `seconds_target` seconds and scaled to the full loop; `opt` = the same arithmetic in the GPU path's algebra (key in the
     NTT domain, 4 + 2 NTTs per iteration; bit-identical).  Timed on every core this process may
     use -- the affinity mask, or the cgroup CPU quota where that is smaller (the GPU boxes of the
     pool show 256 cores and a quota of 16: 32 threads measured no faster than 16) -- as the
@@ -242,7 +287,7 @@ def cpu_baseline(p, sk, key_seed, cap, seconds_target=8.0):
         t0 = time.perf_counter()
         o.bootstrap_batch(k, a[0], b[0], a[1], b[1], n_iters=4, threads=cores, opt=opt)
         per_iter = max((time.perf_counter() - t0) / 4, 1e-6)
-        iters = int(min(p.n, max(4, seconds_target / per_iter)))
+        iters = p.n if per_iter * p.n <= seconds_full else int(min(p.n, max(4, seconds_target / per_iter)))
         t0 = time.perf_counter()
         o.bootstrap_batch(k, a[0], b[0], a[1], b[1], n_iters=iters, threads=cores, opt=opt)
         dt = time.perf_counter() - t0
@@ -252,14 +297,18 @@ def cpu_baseline(p, sk, key_seed, cap, seconds_target=8.0):
         t, iters, dt = timed(key, False, cores)
         r = {"value": cores / t, "unit": "bootstraps/sec", "cores": cores, "kind": "port",
              "per_core": 1.0 / t,
-             "sample": "%d bootstraps in parallel (one per thread), first %d of %d k-loop iterations "
-                       "(%.1f s), scaled x%.2f; reference-shaped C restatement"
-                       % (cores, iters, p.n, dt, p.n / iters)}
+             "sample": "%d bootstraps in parallel (one per thread), %s%d of %d k-loop iterations "
+                       "(%.1f s)%s; reference-shaped C restatement"
+                       % (cores, "" if iters == p.n else "first ", iters, p.n, dt,
+                          "" if iters == p.n else ", scaled x%.2f" % (p.n / iters)),
+             "iterations_timed": iters, "iterations_total": p.n}
         if khat is not None:
             ot, oiters, odt = timed(khat, True, cores)
             r["opt"] = {"value": cores / ot, "per_core": 1.0 / ot,
                         "sample": "same threads, GPU-path algebra (NTT-domain key, 6 NTTs per iteration "
-                                  "instead of 24), first %d iterations (%.1f s)" % (oiters, odt)}
+                                  "instead of 24), %s%d of %d iterations (%.1f s)"
+                                  % ("" if oiters == p.n else "first ", oiters, p.n, odt),
+                        "iterations_timed": oiters}
         return r
     res = leg(full)
     res.update({"cores_available": avail, "cores_cap": cap or None,
@@ -310,13 +359,21 @@ def dry_run(args):
         t = torch.tensor([1.0 + rank], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         tmax = float(t.item())
+        ones = torch.ones(1, dtype=torch.int64)          # the proof-of-ranks field of the real line
+        dist.all_reduce(ones, op=dist.ReduceOp.SUM)
+        group_ranks = int(ones.item())
+        backend = dist.get_backend()
         dist.barrier()
         dist.destroy_process_group()
+        if group_ranks != args.gpus:
+            raise SystemExit("the process group holds %d ranks, --gpus says %d: no line" % (group_ranks, args.gpus))
     else:
-        tmax = 1.0
+        tmax, group_ranks, backend = 1.0, None, None
     if rank == 0:
         print(json.dumps({"dry_run": True, "n_gpus": world, "max_over_ranks": tmax,
-                          "steps": args.steps, "warmup": args.warmup}))
+                          "steps": args.steps, "warmup": args.warmup,
+                          "config": {"group_ranks": group_ranks, "collective_backend": backend, "rccl_ranks": None,
+                                     "key_broadcast_gbs": None}}))
 
 
 def main():
@@ -504,6 +561,18 @@ def main():
                            "= time of the device-resident steps / time of the host-pointer steps of one "
                            "alternating sequence (one synchronous call each per step)"}
 
+    # ---- N ranks: proof on the line that they talked ---------------------------
+    # all-reduce(SUM) of 1 over the process group the ranks were given: RCCL over xGMI when launched by
+    # torch.distributed.run on N devices (gloo in a rehearsal).  The line is refused unless it equals --gpus.
+    group_ranks = None
+    if dist:
+        ones = torch.ones(1, dtype=torch.int64, device="cuda" if not rehearsal else "cpu")
+        dist.all_reduce(ones, op=dist.ReduceOp.SUM)
+        group_ranks = int(ones.item())
+        if group_ranks != args.gpus:
+            raise SystemExit("the process group holds %d ranks, --gpus says %d: no line" % (group_ranks, args.gpus))
+    props = torch.cuda.get_device_properties(local_rank)
+
     if rank == 0:
         total = world * args.steps * B
         value = total / dt
@@ -590,7 +659,14 @@ def main():
                        "rns_primes": len(eng.primes()),
                        "key": "generated on the device from a seed (valid key)",
                        "keygen_s": round(keygen_s, 3), "key_bytes": eng.key_device_form_bytes(),
-                       "key_broadcast_s": round(bcast_s, 4), "build_id": build_id,
+                       "key_broadcast_s": round(bcast_s, 4),
+                       # one broadcast of the device-form key blob rank 0 -> peers (null without peers)
+                       "key_broadcast_gbs": (round(eng.key_device_form_bytes() / bcast_s / 1e9, 2)
+                                             if dist and world > 1 and bcast_s > 0 else None),
+                       "collective_backend": (dist.get_backend() if dist else None),
+                       "rccl_ranks": group_ranks if (dist and not rehearsal) else None,
+                       "group_ranks": group_ranks,
+                       "build_id": build_id,
                        **({"rehearsal": "ranks share %d GPU(s) over gloo: not a measurement"
                                         % torch.cuda.device_count()} if rehearsal else {})},
             "roofline": {"bound": "hbm",
@@ -612,7 +688,8 @@ def main():
                          "launch_ms_rocprof": rp_ms,
                          "kernels": kern,
                          "whole_job_frac": per_boot * value / world / (PEAK_HBM_GBS * 1e9),
-                         "valu": valu_roofline(ctr, (alone["extprod_ms"]) * 1e-3)},
+                         "valu": valu_roofline(ctr, (alone["extprod_ms"]) * 1e-3, props.multi_processor_count,
+                                               NOMINAL_SCLK_HZ)},
         }
         if host_io:
             res["host_io"] = host_io

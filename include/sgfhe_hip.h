@@ -18,7 +18,10 @@
  *     whatever stream each call names (each call's first kernel waits, on the device, for the
  *     previous call's last one: the ctx owns the work buffers every call uses), so two threads
  *     or two streams sharing a ctx get the bytes of the same calls made one after the other
- *     (the reference call is pure, src/fhe.jl:608-621)
+ *     (the reference call is pure, src/fhe.jl:608-621).  Callers that want their calls to OVERLAP on
+ *     the device -- Julia tasks each running bootstrap(bkey, ...) on one key -- take one clone of the
+ *     ctx each (sgfhe_ctx_clone, ABI revision 7): clones share the device key and constants and own
+ *     their work buffers and streams
  *   - residues mod Q cross the boundary as canonical representatives in [0, Q), little-endian
  *     `limbs` x uint64 each, limbs = 2 (16 bytes, the reference's UInt128 storage width) unless
  *     stated otherwise; LWE words over Z_r are one uint64 each, exactly the memory of
@@ -76,7 +79,7 @@ const char *sgfhe_version(void);
  * SGFHE_ABI_VERSION it was written for and refuses a stale library (julia/SGFHEHip.jl __init__,
  * sgfhe.jl_amd/_lib.py).  Bumped whenever a signature, a struct layout, a flag value or the
  * meaning of an argument changes. */
-#define SGFHE_ABI_VERSION 6u
+#define SGFHE_ABI_VERSION 7u
 uint32_t sgfhe_abi_version(void);
 /* Identity of the kernel sources the library was compiled from: the first 16 hex digits of the
  * SHA-256 over csrc/{*.h, *.hip} (in file-name order), followed by "+<flags>" when the build used
@@ -104,6 +107,46 @@ int32_t sgfhe_ctx_create(const sgfhe_params *p, int device, sgfhe_ctx **out);
 #define SGFHE_CTX_RANDOM_FLATTEN 1u
 #define SGFHE_CTX_DETERMINISTIC_ONLY 2u
 int32_t sgfhe_ctx_create_ex(const sgfhe_params *p, int device, uint32_t flags, sgfhe_ctx **out);
+/*
+ * A second ctx on the same device, parameter set and KEY, for an independent caller (ABI revision 7).
+ * The reference call is pure (src/fhe.jl:608-621): any number of Julia tasks may run
+ * bootstrap(bkey, ...) on one BootstrapKey side by side.  Calls on ONE ctx are serialised and ordered
+ * on the device, because the ctx owns the work buffers every call uses; a clone is what gives a second
+ * caller its own: it SHARES with `ctx` everything a bootstrap only reads -- the device key in every
+ * form (1.34 + 1.61 GB at Params(1024): not copied), twiddle tables, per-prime and CRT constants -- and
+ * OWNS its lanes' work buffers (allocated by its first call, sized by its largest), streams, events,
+ * host staging, flatten mode (deterministic to begin with; its own ChaCha key and call counter), error
+ * string and lock.  The scheduling knobs (sgfhe_set_chunk / _lanes / _small_batch_max) are inherited as
+ * they stand.  Calls on different clones are independent -- each gives the bytes the same call gives on
+ * `ctx` -- and small host-pointer calls made at the same time are gathered into one launch chain
+ * (sgfhe_set_coalesce below), which is how eight callers get six times one caller's rate.
+ * `ctx` must hold a key (SGFHE_ERR_NO_KEY otherwise).  While a key is shared -- by `ctx` and at least
+ * one clone, or by clones alone -- it is read-only: sgfhe_bkey_upload / _upload_rns2 / _generate /
+ * _import_device_form on any of the sharers fail with SGFHE_ERR_INVALID_ARG (export is allowed).  The
+ * shared memory is freed with the last ctx that holds it, so `ctx` and its clones may be destroyed in
+ * any order; every one of them is destroyed with sgfhe_ctx_destroy.
+ * As with sgfhe_ctx_create, *out is set even when the call fails after allocating it (read the error,
+ * then destroy it).
+ */
+int32_t sgfhe_ctx_clone(sgfhe_ctx *ctx, sgfhe_ctx **out);
+/*
+ * Gathering of small calls across the ctxs that share a key (ABI revision 7).  This device runs about two
+ * dependent launch chains side by side however many streams feed it, while ONE chain of g gates costs little more
+ * than a chain of one (Params(1024): 15 ms for 1 gate, 21 ms for 8, 27 ms for 16).  So sgfhe_bootstrap_batch calls
+ * of at most `req_max` gates (default 32) made at the same time on ctxs that share a key -- a ctx and its clones,
+ * each driven by its own host thread -- are run as ONE call: the caller that finds no combined call in flight takes
+ * every request waiting (up to `gates_max` gates, default 256), runs them as one batch on its own ctx and hands each
+ * caller its rows; callers arriving meanwhile form the next round, whose leader waits up to `window_us` (default 300)
+ * for as many callers as the previous round had.  A caller on its own never waits, and a ctx without clones is not
+ * affected at all.  Deterministic flatten only (every clone has its own draw stream): a row of the result does not
+ * depend on the rows beside it, so every caller gets the bytes its call gives alone.  The asynchronous entry point
+ * (sgfhe_bootstrap_batch_device) is never gathered.
+ * The setting belongs to the shared key: it applies to every ctx that shares it.  enable = 0 switches gathering off
+ * (SGFHE_COALESCE=0 in the environment does the same at ctx creation); the other arguments are then ignored.
+ * sgfhe_coalesce_stats: stats[4] = {combined calls run, requests served, gates, most requests in one call}.
+ */
+int32_t sgfhe_set_coalesce(sgfhe_ctx *ctx, int enable, uint32_t req_max, uint32_t gates_max, uint32_t window_us);
+int32_t sgfhe_coalesce_stats(sgfhe_ctx *ctx, uint64_t *stats, int reset);
 int32_t sgfhe_ctx_destroy(sgfhe_ctx *ctx);
 const char *sgfhe_last_error_string(const sgfhe_ctx *ctx);
 

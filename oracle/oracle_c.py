@@ -62,6 +62,8 @@ def lib():
         L.sgo_bootstrap_batch_opt.argtypes = L.sgo_bootstrap_batch.argtypes
         L.sgo_pack_encrypted_bits.argtypes = [ctypes.c_void_p, _u64p, _u64p, _u64p, _u64p, _u64p,
                                               ctypes.c_int]
+        L.sgo_pack_encrypted_bits_ex.argtypes = [ctypes.c_void_p, _u64p, _u64p, _u64p, _u64p, _u64p, _u64p,
+                                                 ctypes.c_int, ctypes.c_char_p, ctypes.c_uint32, ctypes.c_uint32]
         L.sgo_flatten_random.argtypes = [ctypes.c_void_p, _u64p, ctypes.c_int64, ctypes.c_int64, _u64p]
         L.sgo_flatten_draws.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_uint, ctypes.c_uint32,
                                         ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(ctypes.c_int64)]
@@ -287,15 +289,23 @@ class Oracle:
         return (out, acc) if want_acc else out
 
 
-def _pack(self, bkey, a, b, threads=None):
-    """fhe.jl:660-696: n LWEs (a [n][n], b [n]) -> RLWE (w, v) over Z_r, [m] each."""
+def _pack(self, bkey, a, b, threads=None, khat=None, rnd=None):
+    """fhe.jl:660-696: n LWEs (a [n][n], b [n]) -> RLWE (w, v) over Z_r, [m] each.
+    khat: the NTT-domain key (key_transform) for the n bootstraps (same bytes, faster).
+    rnd = (seed, ct, call): pack_encrypted_bits(bkey, rng, ...) on the engine's ChaCha8 stream, this
+    ciphertext being number `ct` of call `call`."""
     bkey = np.ascontiguousarray(bkey, dtype=np.uint64)
     a = np.ascontiguousarray(a, dtype=np.uint64).reshape(self.n, self.n)
     b = np.ascontiguousarray(b, dtype=np.uint64).reshape(self.n)
     w = np.zeros(self.m, dtype=np.uint64)
     v = np.zeros(self.m, dtype=np.uint64)
-    rc = lib().sgo_pack_encrypted_bits(self._ctx, _p(bkey), _p(a), _p(b), _p(w), _p(v),
-                                       threads or os.cpu_count() or 1)
+    if khat is not None:
+        khat = np.ascontiguousarray(khat, dtype=np.uint64)
+    rc = lib().sgo_pack_encrypted_bits_ex(self._ctx, _p(bkey), _p(khat) if khat is not None else None, _p(a),
+                                          _p(b), _p(w), _p(v), threads or os.cpu_count() or 1,
+                                          seed_bytes(rnd[0]) if rnd is not None else None,
+                                          int(rnd[1]) if rnd is not None else 0,
+                                          int(rnd[2]) if rnd is not None else 0)
     if rc:
         raise RuntimeError("sgo_pack_encrypted_bits failed: %d" % rc)
     return w, v

@@ -895,13 +895,14 @@ int sgo_bootstrap_batch_rnd(const sgo_ctx *c, int opt, const uint64_t *key, cons
 
 /* ---------------------------------------------------------------- packing */
 
-/* fhe.jl:632-641: flatten(a) * A[l+1:2l, :]; A is the 4x2 slice [4][2][m]. */
+/* fhe.jl:632-641: flatten(rng, a) * A[l+1:2l, :]; A is the 4x2 slice [4][2][m].  g != NULL: the randomised
+ * flatten, the draws of the polynomial addressed as accumulator 0 of the flatten tagged y. */
 static void shortened_external_product(const sgo_ctx *c, const u128 *a, const u128 *A, u128 *a_res,
-                                       u128 *b_res, u128 *scratch /* 3 m */) {
+                                       u128 *b_res, u128 *scratch /* 3 m */, const rnd_t *g, uint32_t y) {
     size_t m = c->m;
     u128 Q = c->Q;
     u128 *u = scratch, *prod = scratch + 2 * m;
-    for (size_t i = 0; i < m; i++) flatten2(c, a[i], &u[i], &u[m + i]);          /* fhe.jl:637 */
+    flatten_poly2(c, g, 0, y, a, u, u + m);                                        /* fhe.jl:637 */
     memset(a_res, 0, m * sizeof(u128));
     memset(b_res, 0, m * sizeof(u128));
     for (int i = 0; i < 2; i++) {
@@ -912,13 +913,27 @@ static void shortened_external_product(const sgo_ctx *c, const u128 *a, const u1
     }
 }
 
-/* fhe.jl:660-696 with rng = nothing.  a: [n][n] LWE vectors over Z_r, b: [n]; w, v: [m] words in
- * [0, r).  Returns 0 on success. */
-int sgo_pack_encrypted_bits(const sgo_ctx *c, const uint64_t *bkey, const uint64_t *a,
-                            const uint64_t *b, uint64_t *w, uint64_t *v, int threads) {
+/* fhe.jl:660-696.  a: [n][n] LWE vectors over Z_r, b: [n]; w, v: [m] words in [0, r).
+ * khat != NULL: the n bootstraps run in the NTT-domain algebra (sgo_key_transform; same bytes, a quarter
+ * of the time); bkey is needed either way, for the half-width products.  key32 != NULL: rng != nothing on the
+ * engine's ChaCha8 stream -- this ciphertext is number `ct` of call `call`: its bootstrap j draws as bootstrap
+ * ct n + j of the call (fhe.jl:673), the flatten of as_i as accumulator 0 of the flatten tagged 2^31 | i of
+ * "bootstrap" ct (fhe.jl:683-684).  Returns 0 on success. */
+int sgo_pack_encrypted_bits_ex(const sgo_ctx *c, const uint64_t *bkey, const uint64_t *khat, const uint64_t *a,
+                               const uint64_t *b, uint64_t *w, uint64_t *v, int threads, const uint8_t *key32,
+                               uint32_t ct, uint32_t call) {
     size_t n = c->n, m = c->m;
     u128 Q = c->Q;
     int rc = 0;
+    rnd_t g0;
+    if (key32) {
+        for (int i = 0; i < 8; i++)
+            g0.key[i] = (uint32_t)key32[4 * i] | ((uint32_t)key32[4 * i + 1] << 8) |
+                        ((uint32_t)key32[4 * i + 2] << 16) | ((uint32_t)key32[4 * i + 3] << 24);
+        g0.call = call;
+        g0.boot = ct;
+    }
+    if (khat && !c->use_ntt) return -2;
     u128 *raw = (u128 *)malloc(n * (n + 1) * sizeof(u128)); /* AND LWE of every bit: a[0..n), b */
     uint64_t *zeros = (uint64_t *)calloc(n, sizeof(uint64_t));
     u128 *wt = (u128 *)calloc(m, sizeof(u128)), *vt = (u128 *)calloc(m, sizeof(u128));
@@ -927,8 +942,10 @@ int sgo_pack_encrypted_bits(const sgo_ctx *c, const uint64_t *bkey, const uint64
 #pragma omp parallel for num_threads(threads > 0 ? threads : 1) schedule(dynamic)
     for (long t = 0; t < (long)n; t++) {
         u128 *out3 = (u128 *)malloc(3 * (n + 1) * sizeof(u128));
-        int r1 = bootstrap_one(c, (const u128 *)bkey, NULL, zeros, c->Dr, a + (size_t)t * n, b[t], n,
-                               out3, NULL, NULL);
+        rnd_t g = g0;
+        g.boot = ct * (uint32_t)n + (uint32_t)t;
+        int r1 = bootstrap_one(c, khat ? NULL : (const u128 *)bkey, (const u128 *)khat, zeros, c->Dr,
+                               a + (size_t)t * n, b[t], n, out3, NULL, key32 ? &g : NULL);
         if (r1) {
 #pragma omp atomic write
             rc = r1;
@@ -949,7 +966,7 @@ int sgo_pack_encrypted_bits(const sgo_ctx *c, const uint64_t *bkey, const uint64
             for (long i = 0; i < (long)n; i++) {
                 for (size_t j = 0; j < n; j++) as[j] = raw[j * (n + 1) + (size_t)i];   /* :676 */
                 shortened_external_product(c, as, (const u128 *)bkey + (size_t)i * 8 * m, ar, ar + m,
-                                           scratch);
+                                           scratch, key32 ? &g0 : NULL, (1u << 31) | (uint32_t)i);
                 for (size_t k = 0; k < m; k++) {
                     wl[k] = addmod(wl[k], ar[k], Q);
                     vl[k] = addmod(vl[k], ar[m + k], Q);
@@ -972,4 +989,9 @@ int sgo_pack_encrypted_bits(const sgo_ctx *c, const uint64_t *bkey, const uint64
     }
     free(raw); free(zeros); free(wt); free(vt);
     return rc;
+}
+
+int sgo_pack_encrypted_bits(const sgo_ctx *c, const uint64_t *bkey, const uint64_t *a,
+                            const uint64_t *b, uint64_t *w, uint64_t *v, int threads) {
+    return sgo_pack_encrypted_bits_ex(c, bkey, NULL, a, b, w, v, threads, NULL, 0, 0);
 }

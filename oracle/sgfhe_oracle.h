@@ -121,6 +121,14 @@ int sgo_bootstrap_batch_rnd(const sgo_ctx *ctx, int opt, const uint64_t *key, co
  * RLWE (w, v), [m] words in [0, r) each. */
 int sgo_pack_encrypted_bits(const sgo_ctx *ctx, const uint64_t *bkey, const uint64_t *a,
                             const uint64_t *b, uint64_t *w, uint64_t *v, int threads);
+/* The same with the bootstraps in the NTT-domain algebra when khat (sgo_key_transform) is given -- bkey is
+ * needed either way for the half-width products -- and, with key32 != NULL, pack_encrypted_bits(bkey, rng,
+ * enc_bits) on the engine's ChaCha8 stream: ciphertext `ct` of call `call`; bootstrap j of the group draws as
+ * bootstrap ct n + j of the call (fhe.jl:673), the flatten of as_i with tag 2^31 | i as "bootstrap" ct
+ * (fhe.jl:683-684; the layout oracle/bigint_oracle.py pack_encrypted_bits restates). */
+int sgo_pack_encrypted_bits_ex(const sgo_ctx *ctx, const uint64_t *bkey, const uint64_t *khat, const uint64_t *a,
+                               const uint64_t *b, uint64_t *w, uint64_t *v, int threads, const uint8_t *key32,
+                               uint32_t ct, uint32_t call);
 
 #ifdef __cplusplus
 }

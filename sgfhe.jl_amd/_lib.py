@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.environ.get("SGFHE_HIP_LIB") or os.path.join(CSRC, "libsgfhe_hip.so")
 
-ABI_VERSION = 6   # SGFHE_ABI_VERSION of include/sgfhe_hip.h this binding was written for
+ABI_VERSION = 7   # SGFHE_ABI_VERSION of include/sgfhe_hip.h this binding was written for
 
 _u64p = ctypes.POINTER(ctypes.c_uint64)
 _u32p = ctypes.POINTER(ctypes.c_uint32)
@@ -96,6 +96,9 @@ def lib():
         "sgfhe_build_id": (ctypes.c_char_p, []),
         "sgfhe_ctx_create": (i32, [ctypes.POINTER(SgfheParams), ctypes.c_int, ctypes.POINTER(vp)]),
         "sgfhe_ctx_create_ex": (i32, [ctypes.POINTER(SgfheParams), ctypes.c_int, u32, ctypes.POINTER(vp)]),
+        "sgfhe_ctx_clone": (i32, [vp, ctypes.POINTER(vp)]),
+        "sgfhe_set_coalesce": (i32, [vp, ctypes.c_int, u32, u32, u32]),
+        "sgfhe_coalesce_stats": (i32, [vp, _u64p, ctypes.c_int]),
         "sgfhe_ctx_destroy": (i32, [vp]),
         "sgfhe_last_error_string": (ctypes.c_char_p, [vp]),
         "sgfhe_set_chunk": (i32, [vp, u32]),
@@ -149,7 +152,7 @@ def lib():
 
 
 EXPORTED_SYMBOLS = (
-    "sgfhe_version", "sgfhe_abi_version", "sgfhe_build_id", "sgfhe_ctx_create", "sgfhe_ctx_create_ex", "sgfhe_ctx_destroy", "sgfhe_last_error_string",
+    "sgfhe_version", "sgfhe_abi_version", "sgfhe_build_id", "sgfhe_ctx_create", "sgfhe_ctx_create_ex", "sgfhe_ctx_clone", "sgfhe_set_coalesce", "sgfhe_coalesce_stats", "sgfhe_ctx_destroy", "sgfhe_last_error_string",
     "sgfhe_set_chunk", "sgfhe_set_lanes", "sgfhe_set_small_batch_max", "sgfhe_set_random_flatten", "sgfhe_set_random_flatten_key", "sgfhe_bkey_upload", "sgfhe_bkey_upload_rns2", "sgfhe_rns2_convert", "sgfhe_bkey_generate",
     "sgfhe_bkey_device_form_bytes", "sgfhe_bkey_export_device_form",
     "sgfhe_bkey_import_device_form", "sgfhe_bootstrap_batch", "sgfhe_bootstrap_batch_device",

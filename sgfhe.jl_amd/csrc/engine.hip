@@ -9,6 +9,9 @@
 #include <string.h>
 
 #include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -68,6 +71,57 @@ double u128_dbl(u128 x) { return (double)(uint64_t)(x >> 64) * 18446744073709551
 
 // ---------------------------------------------------------------- ctx
 
+// Device memory that a ctx and its clones (sgfhe_ctx_clone) have in common: the per-prime records and
+// CRT / flatten constants of every basis, the twiddle tables, and the key in every form -- everything a
+// bootstrap only reads.  Each allocation is registered here when it is made and freed when the last ctx
+// that holds the block goes, so a clone may outlive the ctx it was taken from.
+// Independent callers on one key, gathered (round 5).  The device runs about two dependent launch chains side by
+// side, whatever streams and hardware queues they are given (tools/ubench_streams.hip, profiles/r05_concurrent.txt:
+// 2 / 4 / 8 threads with a stream each reach 1.9 / 1.9 / 2.5 x one thread), but ONE chain of g gates costs little
+// more than a chain of one (15.1 ms for 1 gate, 20.8 for 8, 26.5 for 16 at Params(1024)).  So small host-pointer
+// calls that arrive together on ctxs sharing a key (sgfhe_ctx_clone) are run as one call: the caller that finds no
+// combined call in flight leads -- it takes every request waiting, runs them as one batch on ITS OWN ctx (its lock,
+// lanes and streams) and hands each caller its rows -- and callers that arrive meanwhile wait for the next round.
+// Deterministic flatten only: a row's result does not depend on the rows beside it (src/fhe.jl:579-582 is per
+// bootstrap; tests/test_gpu_golden.py batch-position test), so every caller gets the bytes of its call made alone.
+struct Coalescer {
+    struct Req {
+        const uint64_t *a1, *b1, *a2, *b2;
+        size_t batch;
+        uint64_t *out;
+        uint32_t flags;
+        int32_t rc = 0;
+        bool done = false;
+        std::string err;
+    };
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<Req *> pending;
+    bool running = false;        // a leader is running a combined call
+    size_t last_reqs = 0;        // requests in the previous combined call: how many callers to expect back
+    // knobs (sgfhe_set_coalesce): on / off, largest request that is gathered, gates per combined call, how long a
+    // leader waits for the callers of the previous round to come back
+    bool enabled = true;
+    uint32_t req_max = 32, gates_max = 256, window_us = 300;
+    // statistics (sgfhe_coalesce_stats)
+    uint64_t n_calls = 0, n_reqs = 0, n_gates = 0, max_reqs = 0;
+};
+
+struct SharedDev {
+    int device = 0;
+    std::mutex mu;
+    std::vector<void *> mem;
+    Coalescer co;
+    void own(void *p) {
+        std::lock_guard<std::mutex> g(mu);
+        mem.push_back(p);
+    }
+    ~SharedDev() {
+        (void)hipSetDevice(device);
+        for (void *p : mem) (void)hipFree(p);
+    }
+};
+
 struct sgfhe_ctx {
     sgfhe_params par;
     int device = 0;
@@ -102,6 +156,9 @@ struct sgfhe_ctx {
     uint32_t primes[NPR_MAX];
     uint32_t npr = 0;  // RNS primes in use: the fewest whose product covers the exactness bound
     std::string err;
+    // the read-only device memory of this ctx, shared with its clones (use_count() > 1: the key may not
+    // be replaced, sgfhe_ctx_clone)
+    std::shared_ptr<SharedDev> shared;
     // Every C-ABI entry point that takes a ctx holds this lock for the whole call: a ctx may be
     // shared by host threads (their calls are serialised), different ctxs run concurrently.
     mutable std::recursive_mutex mu;
@@ -184,6 +241,7 @@ struct sgfhe_ctx {
     // copies through its own pinned buffers instead (one CPU memcpy + one true DMA).
     uint64_t *pin_in = nullptr, *pin_out = nullptr;
     size_t pin_in_words = 0, pin_out_words = 0;
+    std::vector<uint64_t> co_buf;   // gathered inputs and results of a combined call this ctx leads (Coalescer)
     bool use_pin = true;   // SGFHE_HOST_PIN=0 in the environment: direct copies (A/B measurements)
     // timing
     bool timing = false;
@@ -208,6 +266,16 @@ enum : uint32_t { ATTR_EXTPROD = 1u, ATTR_SMALL = 2u, ATTR_SHORTPROD = 4u, ATTR_
 // 48 MB, where one CPU memcpy cost what pinning the caller's pages did; the copies are now pipelined
 // chunk by chunk beside the kernels (HostPipe), so their size no longer matters.
 static constexpr size_t PIN_MAX_BYTES = (size_t)1 << 30;
+// SGFHE_PIN_MAX_MB=<n> in the environment lowers the limit (read at every host-pointer call): lets a test
+// send a small batch down the direct-copy path that batches above 1 GiB take (tests/test_gpu_round5.py).
+static size_t pin_max_bytes() {
+    const char *env = getenv("SGFHE_PIN_MAX_MB");
+    if (env && *env) {
+        const long mb = atol(env);
+        if (mb >= 0 && (size_t)mb < (PIN_MAX_BYTES >> 20)) return (size_t)mb << 20;
+    }
+    return PIN_MAX_BYTES;
+}
 
 namespace {
 
@@ -798,17 +866,27 @@ int32_t run_iterations(sgfhe_ctx *c, ChunkJob *jobs, int njobs, uint64_t n_iters
 // memcpy between the caller's pageable arrays and the page-locked mirrors.  The copies of the first
 // chunk's inputs and of the last chunks' results are the part of a host-pointer call that no kernel
 // hides: above 2 MB they are cut across up to four threads (one thread moves 5-8 GB/s).
+// Called inside extern "C" entry points: nothing may throw out of it.  std::thread's constructor throws
+// std::system_error when the process may not start another thread (EAGAIN: ulimit -u, a container's pid
+// limit); the part that thread would have copied, and everything after it, is then copied here.
 void host_copy(void *dst, const void *src, size_t bytes) {
     const size_t parts = bytes >= ((size_t)2 << 20) ? (bytes >= ((size_t)8 << 20) ? 4 : 2) : 1;
     if (parts == 1) { memcpy(dst, src, bytes); return; }
-    const size_t step = ((bytes / parts) + 4095) & ~(size_t)4095;
+    const size_t step = ((bytes / parts) + 4095) & ~(size_t)4095;   // parts 1 .. of `step` bytes; the last takes the rest
     std::thread th[3];
     size_t nth = 0, off = step;
-    for (; nth < parts - 1 && off < bytes; nth++, off += step) {
-        const size_t len = bytes - off < step ? bytes - off : step;
+    for (; nth < parts - 1 && off < bytes; off += step) {
+        const size_t len = (nth == parts - 2 || bytes - off < step) ? bytes - off : step;
         char *d = static_cast<char *>(dst) + off;
         const char *sr = static_cast<const char *>(src) + off;
-        th[nth] = std::thread([d, sr, len] { memcpy(d, sr, len); });
+        try {
+            th[nth] = std::thread([d, sr, len] { memcpy(d, sr, len); });
+            nth++;
+        } catch (...) {            // no thread to be had: this part and the rest, on the caller's thread
+            memcpy(d, sr, bytes - off);
+            break;
+        }
+        if (len == bytes - off) break;
     }
     memcpy(dst, src, step < bytes ? step : bytes);
     for (size_t i = 0; i < nth; i++) th[i].join();
@@ -1349,10 +1427,13 @@ int32_t build_basis(sgfhe_ctx *c, uint32_t npr, const uint32_t *cand_primes, dou
         c->tw_done = npr;
     }
     HIPCHK(c, hipMalloc(&c->d_primes, NPR * sizeof(PrimeK)));
+    c->shared->own(c->d_primes);
     HIPCHK(c, hipMemcpy(c->d_primes, pk.data(), NPR * sizeof(PrimeK), hipMemcpyHostToDevice));
     HIPCHK(c, hipMalloc(&c->d_crt, sizeof(CrtConst)));
+    c->shared->own(c->d_crt);
     HIPCHK(c, hipMemcpy(c->d_crt, &cc, sizeof(CrtConst), hipMemcpyHostToDevice));
     HIPCHK(c, hipMalloc(&c->d_lean, sizeof(CrtLean)));
+    c->shared->own(c->d_lean);
     HIPCHK(c, hipMemcpy(c->d_lean, &c->h_lean, sizeof(CrtLean), hipMemcpyHostToDevice));
     return SGFHE_OK;
 }
@@ -1418,8 +1499,11 @@ int32_t build_constants(sgfhe_ctx *c) {
         if (c->logm >= 14) { c->small_max = 16; if (c->small_lanes_max > 16) c->small_lanes_max = 16; }
     }
     HIPCHK(c, hipMalloc(&c->d_tw, (size_t)c->npr_max * 4 * c->M * sizeof(int32_t)));
+    c->shared->own(c->d_tw);
     HIPCHK(c, hipMalloc(&c->d_twq, (size_t)c->npr_max * 4 * c->M * sizeof(int32_t)));
+    c->shared->own(c->d_twq);
     HIPCHK(c, hipMalloc(&c->d_pow, (size_t)c->npr_max * 2 * c->M * sizeof(int32_t)));
+    c->shared->own(c->d_pow);
     {
         const char *env = getenv("SGFHE_SMALL_SPLIT");
         if (env) c->split_max = (uint32_t)atoi(env);
@@ -1445,7 +1529,19 @@ int32_t build_constants(sgfhe_ctx *c) {
 
 // Key uploads, generation and imports work on the LARGER basis (its key determines the other one);
 // key_finish derives the smaller basis's key from it and goes back to the basis of the present mode.
-void key_begin(sgfhe_ctx *c) { activate(c, c->nb - 1); }
+// A key that clones share (sgfhe_ctx_clone) is read-only: their calls may be reading it on the device.
+int32_t key_begin(sgfhe_ctx *c) {
+    if (c->shared.use_count() > 1)
+        return fail(c, SGFHE_ERR_INVALID_ARG,
+                    "the bootstrap key of this ctx is shared with clones (sgfhe_ctx_clone): destroy them before replacing it");
+    activate(c, c->nb - 1);
+    return SGFHE_OK;
+}
+// A key writer calls this once its arguments are accepted, before the first byte of the key changes:
+// from here to the end of key_finish the ctx has no key, so a writer that fails part-way (or whose second
+// key form cannot be derived) leaves a ctx that refuses to bootstrap instead of one whose two bases hold
+// different keys.
+void key_dirty(sgfhe_ctx *c) { c->have_key = false; }
 int32_t key_finish(sgfhe_ctx *c, int32_t rc) {
     if (rc == SGFHE_OK && c->nb == 2) {
         const sgfhe_ctx::Basis &Bg = c->basis[1];
@@ -1454,6 +1550,7 @@ int32_t key_finish(sgfhe_ctx *c, int32_t rc) {
         if (!Sm.d_key) {
             Sm.key_bytes = (size_t)c->n * Sm.npr * 8 * c->M * 4;
             e = hipMalloc(&Sm.d_key, Sm.key_bytes);
+            if (e == hipSuccess) c->shared->own(Sm.d_key);
         }
         if (e == hipSuccess) {
             KeyFactors fac = {};
@@ -1513,6 +1610,7 @@ int32_t key_alloc(sgfhe_ctx *c) {
     if (c->d_key) return SGFHE_OK;
     c->key_bytes = (size_t)c->n * c->npr * 8 * c->M * 4;
     HIPCHK(c, hipMalloc(&c->d_key, c->key_bytes));
+    c->shared->own(c->d_key);
     c->basis[c->active].d_key = c->d_key;
     c->basis[c->active].key_bytes = c->key_bytes;
     return SGFHE_OK;
@@ -1545,6 +1643,18 @@ int32_t key_transform_host(sgfhe_ctx *c, const uint64_t *canon, uint32_t npolys,
     }
     (void)hipFree(d_stage);
     return rc;
+}
+
+int32_t create_streams(sgfhe_ctx *c) {
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming) != hipSuccess ||
+        hipStreamCreateWithFlags(&c->stream_io, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&c->stream_io2, hipStreamNonBlocking) != hipSuccess)
+        return fail(c, SGFHE_ERR_HIP, "hipStreamCreate / hipEventCreate failed");
+    return SGFHE_OK;
 }
 
 }  // namespace
@@ -1597,6 +1707,16 @@ int32_t sgfhe_ctx_create_ex(const sgfhe_params *p, int device, uint32_t flags, s
     c->par = *p;
     c->device = device;
     c->create_flags = flags;
+    try {
+        c->shared = std::make_shared<SharedDev>();
+    } catch (...) {
+        return fail(c, SGFHE_ERR_OOM, "out of host memory");
+    }
+    c->shared->device = device;
+    {   // SGFHE_COALESCE=0 in the environment: ctxs sharing a key never gather their calls (A/B measurements)
+        const char *env = getenv("SGFHE_COALESCE");
+        if (env && env[0] == '0') c->shared->co.enabled = false;
+    }
     const uint64_t m = p->m;
     if (p->ell != 2) return fail(c, SGFHE_ERR_UNSUPPORTED, "ell must be 2 (fhe.jl:576)");
     if (m < 64 || m > 16384 || (m & (m - 1)))
@@ -1617,15 +1737,63 @@ int32_t sgfhe_ctx_create_ex(const sgfhe_params *p, int device, uint32_t flags, s
         if (c->B * c->B < c->Q) return fail(c, SGFHE_ERR_INVALID_ARG, "B^2 must be >= Q");
     }
     if (ld128(p->DQ_tilde) >= c->Q) return fail(c, SGFHE_ERR_INVALID_ARG, "DQ_tilde must be < Q");
-    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming) != hipSuccess ||
-        hipStreamCreateWithFlags(&c->stream_io, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&c->stream_io2, hipStreamNonBlocking) != hipSuccess)
-        return fail(c, SGFHE_ERR_HIP, "hipStreamCreate / hipEventCreate failed");
+    int32_t rc = create_streams(c);
+    if (rc) return rc;
     return build_constants(c);
+}
+
+int32_t sgfhe_ctx_clone(sgfhe_ctx *src, sgfhe_ctx **out) {
+    if (!src || !out) return SGFHE_ERR_INVALID_ARG;
+    *out = nullptr;
+    SGFHE_LOCK(src);
+    if (!src->have_key) return fail(src, SGFHE_ERR_NO_KEY, "ctx_clone: the ctx has no bootstrap key to share");
+    if (hipSetDevice(src->device) != hipSuccess) return fail(src, SGFHE_ERR_NO_DEVICE, "ctx_clone: hipSetDevice failed");
+    sgfhe_ctx *c = new (std::nothrow) sgfhe_ctx();
+    if (!c) return fail(src, SGFHE_ERR_OOM, "out of host memory");
+    *out = c;  // returned even on failure so that the caller can read the error string (and destroys it)
+    // what a bootstrap only reads: parameter set, bases with their device constants and key forms, tables
+    c->par = src->par;
+    c->device = src->device;
+    c->logm = src->logm;
+    c->M = src->M;
+    c->n = src->n;
+    c->Q = src->Q;
+    c->B = src->B;
+    c->create_flags = src->create_flags;
+    c->shared = src->shared;
+    for (int b = 0; b < 2; b++) c->basis[b] = src->basis[b];
+    c->nb = src->nb;
+    c->npr_max = src->npr_max;
+    c->tw_done = src->tw_done;
+    c->d_tw = src->d_tw;
+    c->d_twq = src->d_twq;
+    c->d_pow = src->d_pow;
+    memcpy(c->tw_head, src->tw_head, sizeof c->tw_head);
+    c->rnd_ok = src->rnd_ok;
+    c->have_rns2 = src->have_rns2;
+    c->rns2 = src->rns2;
+    c->have_key = true;
+    // the scheduling knobs as they stand (sgfhe_set_chunk / _lanes / _small_batch_max and the environment)
+    c->chunk = src->chunk;
+    c->lanes = src->lanes;
+    c->small_max = src->small_max;
+    c->small_lanes = src->small_lanes;
+    c->small_lanes_max = src->small_lanes_max;
+    c->small_padded = src->small_padded;
+    c->crt1_max = src->crt1_max;
+    c->split_max = src->split_max;
+    c->fused_min = src->fused_min;
+    c->iter_all = src->iter_all;
+    c->use_lean = src->use_lean;
+    c->use_pin = src->use_pin;
+    // its own: flatten mode (deterministic, call counter 0), lanes' work buffers, streams, events, staging,
+    // timing, the error string and the lock
+    activate(c, 0);
+    int32_t rc = create_streams(c);
+    if (rc) return rc;
+    HIPCHK(c, hipMalloc(&c->d_bad, sizeof(uint32_t)));
+    HIPCHK(c, hipMemset(c->d_bad, 0, sizeof(uint32_t)));
+    return SGFHE_OK;
 }
 
 int32_t sgfhe_ctx_destroy(sgfhe_ctx *c) {
@@ -1645,20 +1813,12 @@ int32_t sgfhe_ctx_destroy(sgfhe_ctx *c) {
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
-    for (auto &S : c->basis) {
-        if (S.d_primes) (void)hipFree(S.d_primes);
-        if (S.d_crt) (void)hipFree(S.d_crt);
-        if (S.d_lean) (void)hipFree(S.d_lean);
-        if (S.d_key) (void)hipFree(S.d_key);
-    }
+    c->shared.reset();   // constants, tables and key: freed with the last ctx that shares them
     if (c->io_in) (void)hipFree(c->io_in);
     if (c->io_out) (void)hipFree(c->io_out);
     if (c->pin_in) (void)hipHostFree(c->pin_in);
     if (c->pin_out) (void)hipHostFree(c->pin_out);
     if (c->d_bad) (void)hipFree(c->d_bad);
-    if (c->d_tw) (void)hipFree(c->d_tw);
-    if (c->d_twq) (void)hipFree(c->d_twq);
-    if (c->d_pow) (void)hipFree(c->d_pow);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return SGFHE_OK;
@@ -1740,6 +1900,7 @@ static int32_t sgfhe_bkey_upload_impl(sgfhe_ctx *c, const uint64_t *canonical, s
     int32_t rc = key_alloc(c);
     if (rc) return rc;
     HIPCHK(c, hipMemset(c->d_bad, 0, sizeof(uint32_t)));
+    key_dirty(c);
     rc = key_transform_host(c, canonical, c->n * 8, c->d_key);
     if (rc) return rc;
     uint32_t bad = 0;
@@ -1755,7 +1916,8 @@ static int32_t sgfhe_bkey_upload_impl(sgfhe_ctx *c, const uint64_t *canonical, s
 int32_t sgfhe_bkey_upload(sgfhe_ctx *c, const uint64_t *canonical, size_t n_words) {
     if (!c) return SGFHE_ERR_INVALID_ARG;
     SGFHE_LOCK(c);
-    key_begin(c);   // on the larger basis; the other basis's key is derived from it
+    const int32_t rb = key_begin(c);   // on the larger basis; the other basis's key is derived from it
+    if (rb) return rb;
     return key_finish(c, sgfhe_bkey_upload_impl(c, canonical, n_words));
 }
 
@@ -1777,6 +1939,7 @@ static int32_t sgfhe_bkey_generate_impl(sgfhe_ctx *c, const uint64_t *sk, size_t
     SGFHE_QUIESCE(c);
     int32_t rc = key_alloc(c);
     if (rc) return rc;
+    key_dirty(c);
     const uint32_t M = c->M, rows = c->n * 4;
     uint32_t R = 64;  // rows per batch (16 key slices)
     if (R > rows) R = rows;
@@ -1827,7 +1990,8 @@ int32_t sgfhe_bkey_generate(sgfhe_ctx *c, const uint64_t *sk, size_t n_sk, const
                             uint32_t noise) {
     if (!c) return SGFHE_ERR_INVALID_ARG;
     SGFHE_LOCK(c);
-    key_begin(c);   // on the larger basis; the other basis's key is derived from it
+    const int32_t rb = key_begin(c);   // on the larger basis; the other basis's key is derived from it
+    if (rb) return rb;
     return key_finish(c, sgfhe_bkey_generate_impl(c, sk, n_sk, seed32, noise));
 }
 
@@ -1869,6 +2033,7 @@ static int32_t sgfhe_bkey_upload_rns2_impl(sgfhe_ctx *c, const uint64_t *pairs, 
     rc = key_alloc(c);
     if (rc) return rc;
     HIPCHK(c, hipMemset(c->d_bad, 0, sizeof(uint32_t)));
+    key_dirty(c);
     rc = key_transform_host(c, pairs, c->n * 8, c->d_key, &c->rns2);
     if (rc) return rc;
     uint32_t bad = 0;
@@ -1885,7 +2050,8 @@ int32_t sgfhe_bkey_upload_rns2(sgfhe_ctx *c, const uint64_t *pairs, size_t n_wor
                                uint64_t m2) {
     if (!c) return SGFHE_ERR_INVALID_ARG;
     SGFHE_LOCK(c);
-    key_begin(c);   // on the larger basis; the other basis's key is derived from it
+    const int32_t rb = key_begin(c);   // on the larger basis; the other basis's key is derived from it
+    if (rb) return rb;
     return key_finish(c, sgfhe_bkey_upload_rns2_impl(c, pairs, n_words, m1, m2));
 }
 
@@ -1951,7 +2117,7 @@ static int32_t sgfhe_bkey_export_device_form_impl(sgfhe_ctx *c, void *dst) {
 int32_t sgfhe_bkey_export_device_form(sgfhe_ctx *c, void *dst) {
     if (!c) return SGFHE_ERR_INVALID_ARG;
     SGFHE_LOCK(c);
-    key_begin(c);   // the blob is the key of the larger basis
+    activate(c, c->nb - 1);   // the blob is the key of the larger basis
     const int32_t rc = sgfhe_bkey_export_device_form_impl(c, dst);
     activate(c, mode_basis(c));
     return rc;
@@ -1974,6 +2140,7 @@ static int32_t sgfhe_bkey_import_device_form_impl(sgfhe_ctx *c, const void *src)
                     "bkey_import: the blob belongs to another parameter set (n, m, Q, B or RNS primes differ)");
     int32_t rc = key_alloc(c);
     if (rc) return rc;
+    key_dirty(c);
     HIPCHK(c, hipMemcpyAsync(c->d_key, static_cast<const char *>(src) + sizeof got, c->key_bytes,
                              hipMemcpyDeviceToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1984,7 +2151,8 @@ static int32_t sgfhe_bkey_import_device_form_impl(sgfhe_ctx *c, const void *src)
 int32_t sgfhe_bkey_import_device_form(sgfhe_ctx *c, const void *src) {
     if (!c) return SGFHE_ERR_INVALID_ARG;
     SGFHE_LOCK(c);
-    key_begin(c);   // on the larger basis; the other basis's key is derived from it
+    const int32_t rb = key_begin(c);   // on the larger basis; the other basis's key is derived from it
+    if (rb) return rb;
     return key_finish(c, sgfhe_bkey_import_device_form_impl(c, src));
 }
 
@@ -2048,8 +2216,8 @@ static int32_t bootstrap_host(sgfhe_ctx *c, const uint64_t *a1, const uint64_t *
     // and kept, and the copies pipelined chunk by chunk beside the kernels (HostPipe).  A failed
     // allocation, a buffer above PIN_MAX_BYTES, SGFHE_HOST_PIN=0 and the debug hooks take direct copies
     // of the caller's arrays.
-    bool pipe = c->use_pin && out && !acc && !digs && in_words * 8 <= PIN_MAX_BYTES &&
-                out_words * 8 <= PIN_MAX_BYTES;
+    const size_t pin_max = pin_max_bytes();
+    bool pipe = c->use_pin && out && !acc && !digs && in_words * 8 <= pin_max && out_words * 8 <= pin_max;
     if (pipe && in_words > c->pin_in_words) {
         if (c->pin_in) (void)hipHostFree(c->pin_in);
         c->pin_in = nullptr;
@@ -2116,13 +2284,126 @@ static int32_t bootstrap_host(sgfhe_ctx *c, const uint64_t *a1, const uint64_t *
     return rc;
 }
 
+// One request through the coalescer of the ctxs that share this key (struct Coalescer).
+static int32_t coalesced_call(sgfhe_ctx *c, const uint64_t *a1, const uint64_t *b1, const uint64_t *a2,
+                              const uint64_t *b2, size_t batch, uint64_t *out, uint32_t flags) {
+    Coalescer &co = c->shared->co;
+    Coalescer::Req me;
+    me.a1 = a1; me.b1 = b1; me.a2 = a2; me.b2 = b2;
+    me.batch = batch; me.out = out; me.flags = flags;
+    std::vector<Coalescer::Req *> take;
+    size_t gates = 0;
+    {
+        std::unique_lock<std::mutex> lk(co.mu);
+        co.pending.push_back(&me);
+        co.cv.notify_all();                         // a leader gathering its round sees the arrival
+        for (;;) {
+            if (me.done) {                          // a leader ran it
+                if (me.rc) c->err = me.err;
+                return me.rc;
+            }
+            if (!co.running && co.pending.front() == &me) break;   // nobody is running: the oldest request leads
+            co.cv.wait(lk);
+        }
+        co.running = true;
+        // The callers of the previous round are about to come back (they got their results microseconds ago):
+        // wait for as many requests as that round had, a few hundred microseconds at most.  A caller on its own
+        // (previous round: one request) never waits.
+        if (co.last_reqs > 1 && co.window_us) {
+            const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(co.window_us);
+            while (co.pending.size() < co.last_reqs && co.cv.wait_until(lk, deadline) != std::cv_status::timeout) {}
+        }
+        for (auto it = co.pending.begin(); it != co.pending.end();) {
+            if ((*it)->flags == me.flags && (take.empty() || gates + (*it)->batch <= co.gates_max)) {
+                take.push_back(*it);
+                gates += (*it)->batch;
+                it = co.pending.erase(it);
+            } else {
+                ++it;
+            }
+        }
+    }
+    // the combined call, on this ctx (the caller holds its lock)
+    int32_t rc;
+    const size_t n = c->n;
+    const size_t row = 3 * (n + 1) * ((flags & SGFHE_FLAG_RAW_MODQ) ? 2 : 1);
+    if (take.size() == 1) {
+        rc = bootstrap_host(c, a1, b1, a2, b2, batch, out, flags, c->n, nullptr);
+    } else {
+        try {
+            std::vector<uint64_t> &g = c->co_buf;                          // [a1 | a2 | b1 | b2 | out] of all requests
+            g.resize(gates * (2 * n + 2 + row));
+            uint64_t *ga1 = g.data(), *ga2 = ga1 + gates * n, *gb1 = ga2 + gates * n, *gb2 = gb1 + gates, *gout = gb2 + gates;
+            size_t r0 = 0;
+            for (const Coalescer::Req *q : take) {
+                memcpy(ga1 + r0 * n, q->a1, q->batch * n * 8);
+                memcpy(ga2 + r0 * n, q->a2, q->batch * n * 8);
+                memcpy(gb1 + r0, q->b1, q->batch * 8);
+                memcpy(gb2 + r0, q->b2, q->batch * 8);
+                r0 += q->batch;
+            }
+            rc = bootstrap_host(c, ga1, gb1, ga2, gb2, gates, gout, flags, c->n, nullptr);
+            r0 = 0;
+            if (rc == SGFHE_OK)
+                for (const Coalescer::Req *q : take) {
+                    memcpy(q->out, gout + r0 * row, q->batch * row * 8);
+                    r0 += q->batch;
+                }
+        } catch (...) {
+            rc = fail(c, SGFHE_ERR_OOM, "out of host memory");
+        }
+    }
+    {
+        std::lock_guard<std::mutex> lk(co.mu);
+        for (Coalescer::Req *q : take) {
+            q->rc = rc;
+            if (rc) q->err = c->err;
+            q->done = true;
+        }
+        co.n_calls++;
+        co.n_reqs += take.size();
+        co.n_gates += gates;
+        if (take.size() > co.max_reqs) co.max_reqs = take.size();
+        co.last_reqs = take.size();
+        co.running = false;
+        co.cv.notify_all();
+    }
+    return rc;
+}
+
 int32_t sgfhe_bootstrap_batch(sgfhe_ctx *c, const uint64_t *a1, const uint64_t *b1,
                               const uint64_t *a2, const uint64_t *b2, size_t batch, uint64_t *out,
                               uint32_t flags) {
     if (!c || !a1 || !b1 || !a2 || !b2 || !out) return SGFHE_ERR_INVALID_ARG;
     SGFHE_LOCK(c);
     if (batch == 0) return SGFHE_OK;
+    // small calls on a key that other ctxs share: gathered with whatever the other callers bring (Coalescer)
+    const Coalescer &co = c->shared->co;
+    if (c->shared.use_count() > 1 && co.enabled && !c->rnd && c->have_key && batch <= co.req_max)
+        return coalesced_call(c, a1, b1, a2, b2, batch, out, flags);
     return bootstrap_host(c, a1, b1, a2, b2, batch, out, flags, c->n, nullptr);
+}
+
+int32_t sgfhe_set_coalesce(sgfhe_ctx *c, int enable, uint32_t req_max, uint32_t gates_max, uint32_t window_us) {
+    if (!c) return SGFHE_ERR_INVALID_ARG;
+    SGFHE_LOCK(c);
+    if (enable && (req_max == 0 || gates_max < req_max || gates_max > 4096 || window_us > 100000))
+        return fail(c, SGFHE_ERR_INVALID_ARG, "set_coalesce: 1 <= req_max <= gates_max <= 4096, window at most 100 ms");
+    Coalescer &co = c->shared->co;
+    std::lock_guard<std::mutex> lk(co.mu);
+    co.enabled = enable != 0;
+    if (enable) { co.req_max = req_max; co.gates_max = gates_max; co.window_us = window_us; }
+    return SGFHE_OK;
+}
+
+int32_t sgfhe_coalesce_stats(sgfhe_ctx *c, uint64_t *stats, int reset) {
+    if (!c || !stats) return SGFHE_ERR_INVALID_ARG;
+    SGFHE_LOCK(c);
+    Coalescer &co = c->shared->co;
+    std::lock_guard<std::mutex> lk(co.mu);
+    stats[0] = co.n_calls; stats[1] = co.n_reqs; stats[2] = co.n_gates; stats[3] = co.max_reqs;
+    if (reset) co.n_calls = co.n_reqs = co.n_gates = co.max_reqs = 0;
+    return SGFHE_OK;
 }
 
 int32_t sgfhe_debug_accumulators(sgfhe_ctx *c, const uint64_t *a1, const uint64_t *b1,

@@ -14,6 +14,8 @@
 //              the accumulator, flatten again (divide by B).
 #pragma once
 
+#include <type_traits>
+
 #include "ntt.h"
 
 namespace sgfhe {
@@ -309,6 +311,19 @@ __device__ __forceinline__ int32_t digit_reduce(uint64_t e, const Mod &md, int32
 #ifndef SGFHE_EXT_WAVES
 #define SGFHE_EXT_WAVES 4
 #endif
+// Digit loads of a phase in groups (round 5, profiles/r05_exp_wide.txt).  The WIDE instantiations have three loads
+// per digit -- 48 values in flight beside the 32 accumulator registers -- and hipcc spilled five accumulator pairs
+// around the phase loop (44-52 bytes of scratch per lane, rounds 3-4): Params(2048) with the randomised flatten ran
+// at 297 bootstraps/s with the spills and runs at 345 without them (+16 %, same call).  The digits of a phase are
+// requested in SPLIT groups, each reduced before the next is requested (a scheduling barrier between the groups
+// bounds the values in flight): 2 groups remove the scratch at m = 8192 / 16384, 4 at m = 4096 too; the 32-bit
+// accumulator instead (-DSGFHE_WIDE_ACC32: 106-125 VGPRs, no scratch either) measured 339.
+#ifndef SGFHE_WIDE_SPLIT
+#define SGFHE_WIDE_SPLIT(LOGM) ((LOGM) >= 13 ? 2 : 4)
+#endif
+#ifndef SGFHE_DET_SPLIT     // the same for the two-plane kernels (A/B builds: -DSGFHE_DET_SPLIT=2)
+#define SGFHE_DET_SPLIT 0
+#endif
 // LE: points per thread (2^LE); 16 wherever that leaves a full wavefront, 8 for m <= 512
 // WIDE: the digit planes carry a third plane (bits 48..55; MODE_WIDE): a separate instantiation, so
 // that the deterministic kernel is textually what it was.
@@ -345,11 +360,17 @@ k_extprod(const uint64_t *__restrict__ dig, const int32_t *__restrict__ keyk,
 #endif
 
     const int32_t sRd = (mode & MODE_RANDOM) ? P.sRr : P.sR;  // digit offset of the flatten mode
+    constexpr int SPLIT = E == 16 ? (WIDE ? SGFHE_WIDE_SPLIT(LOGM) : SGFHE_DET_SPLIT) : 0;
 #ifdef SGFHE_ACC0_32
-    int32_t acc0[E];  // column 0 summed like column 1, Montgomery-reduced per phase (< 2.9 * 2^29)
+    constexpr bool ACC32 = true;
+#elif defined(SGFHE_WIDE_ACC32)   // A/B build of round 5: the 32-bit accumulator in the WIDE instantiations only
+    constexpr bool ACC32 = WIDE && E == 16;
 #else
-    int64_t acc0[E];  // 64-bit NTT-domain sum of column 0 over the four phases (|.| < 1.98 * 2^60)
+    constexpr bool ACC32 = false;
 #endif
+    // ACC32: column 0 summed like column 1, Montgomery-reduced per phase (< 2.9 * 2^29); else the 64-bit
+    // NTT-domain sum of column 0 over the four phases (|.| < 1.98 * 2^60)
+    typename std::conditional<ACC32, int32_t, int64_t>::type acc0[E];
 #pragma unroll
     for (int e = 0; e < E; e++) { acc0[e] = 0; z1[e * T] = 0; }
     // A real loop (not unrolled): one copy of the forward NTT in the instruction stream, and the
@@ -386,6 +407,8 @@ k_extprod(const uint64_t *__restrict__ dig, const int32_t *__restrict__ keyk,
                                 srec + 12u * (uint32_t)M + (uint32_t)(ph & 1) * (uint32_t)M + ((uint32_t)(T * e) & ~4095u)) << 16;
             x[0][e] = digit_reduce(lo | ((uint64_t)hi << 32), md, sRd);
 #endif
+            if constexpr (SPLIT > 1)    // next group of digit loads only after this group's reductions
+                if ((e + 1) % (E / SPLIT) == 0 && e + 1 < E) __builtin_amdgcn_sched_barrier(0);
         }
         // the exchange buffer is reused: every wave must have finished the previous phase's loads
         SGFHE_SYNC();
@@ -438,11 +461,8 @@ k_extprod(const uint64_t *__restrict__ dig, const int32_t *__restrict__ keyk,
             for (int t = 0; t < 4; t++) {
                 const int e = 4 * h + t;
                 const int32_t u = x[0][e];
-#ifdef SGFHE_ACC0_32
-                acc0[e] += smont(u, ka[t], mdp);
-#else
-                acc0[e] += (int64_t)u * ka[t];
-#endif
+                if constexpr (ACC32) acc0[e] += smont(u, ka[t], mdp);
+                else acc0[e] += (int64_t)u * ka[t];
                 int32_t *zp = reinterpret_cast<int32_t *>(lds) + M + e * T + tid;
                 *zp += smont(u, kb[t], mdp);
             }
@@ -466,16 +486,16 @@ k_extprod(const uint64_t *__restrict__ dig, const int32_t *__restrict__ keyk,
 #endif
 #pragma unroll
     for (int e = 0; e < E; e++) {
-#ifdef SGFHE_ACC0_32
-        z[0][e] = sred(acc0[e], md);
-#else
-        const int32_t r0 = sredc(acc0[e], md);   // |REDC| < 1.49 * 2^29
-        z[0][e] = WIDE0 ? r0 : sred(r0, md);
-#endif
+        if constexpr (ACC32) {
+            z[0][e] = sred((int32_t)acc0[e], md);
+        } else {
+            const int32_t r0 = sredc(acc0[e], md);   // |REDC| < 1.49 * 2^29
+            z[0][e] = WIDE0 ? r0 : sred(r0, md);
+        }
         z[1][e] = sred(z1[e * T], md);           // four phases: < 2.99 * 2^29
     }
     SGFHE_SYNC();  // every thread has taken its z_1 out of the buffer the exchanges now reuse
-    ntt_inverse<LOGM, 2, LE, WIDE0>(z, lds, P.twi, tid, md);  // |z| < 1.4 * 2^29
+    ntt_inverse<LOGM, 2, LE, (WIDE0 && !ACC32)>(z, lds, P.twi, tid, md);  // |z| < 1.4 * 2^29
 
     // Output addressing as for the digit loads: scalar offsets per column and coefficient, one
     // 32-bit lane offset.

@@ -65,6 +65,37 @@ class Engine:
                 self._h = None
             raise SgfheError(rc, msg)
 
+    def clone(self):
+        """A second engine on the same device, parameter set and key for an independent caller
+        (sgfhe_ctx_clone): shares the device key and constants, owns its work buffers and streams, so
+        calls on the clone overlap on the device with calls on this engine (one clone per thread).
+        While clones exist the shared key is read-only."""
+        h = ctypes.c_void_p()
+        with self.lock:
+            rc = self._L.sgfhe_ctx_clone(self._h, ctypes.byref(h))
+            if rc != 0:
+                msg = self._L.sgfhe_last_error_string(h if h else self._h).decode()
+                if h:
+                    self._L.sgfhe_ctx_destroy(h)
+                raise SgfheError(rc, msg)
+        other = Engine.__new__(Engine)
+        other.params = self.params
+        other.device = self.device
+        other.lock = threading.RLock()
+        other._L = self._L
+        other._h = h
+        return other
+
+    def set_coalesce(self, enable=True, req_max=32, gates_max=256, window_us=300):
+        """Gathering of small bootstrap_batch calls across the engines that share this key (sgfhe_set_coalesce):
+        on by default once clones exist; the setting belongs to the shared key."""
+        self._call("sgfhe_set_coalesce", int(bool(enable)), req_max, gates_max, window_us)
+
+    def coalesce_stats(self, reset=False):
+        st = (ctypes.c_uint64 * 4)()
+        self._call("sgfhe_coalesce_stats", st, int(reset))
+        return dict(calls=int(st[0]), requests=int(st[1]), gates=int(st[2]), max_requests=int(st[3]))
+
     def close(self):
         if getattr(self, "_h", None):
             self._L.sgfhe_ctx_destroy(self._h)

@@ -21,7 +21,7 @@ const libsgfhe_hip = get(ENV, "SGFHE_HIP_LIB", "libsgfhe_hip.so")
 
 # Revision of include/sgfhe_hip.h these ccalls were written for (SGFHE_ABI_VERSION): a library
 # built from another revision is refused when the module loads.
-const ABI_VERSION = UInt32(6)
+const ABI_VERSION = UInt32(7)
 
 function __init__()
     got = ccall((:sgfhe_abi_version, libsgfhe_hip), UInt32, ())
@@ -67,20 +67,35 @@ function create_ctx(p::Params, device::Integer, random_flatten::Bool, determinis
     ctx
 end
 
-mutable struct HipBootstrapKey
-    params::Params
+# One caller's share of a key: a ctx of its own (the key's first ctx, or a clone of it: same device key and
+# constants, own work buffers and streams -- sgfhe_ctx_clone, ABI revision 7) and its result buffer.
+mutable struct Slot
     ctx::Ptr{Cvoid}
     # result words of the last batched call, kept and regrown on demand: releasing a
     # multi-megabyte array between calls can stall the next call's kernels (include/sgfhe_hip.h)
     scratch::Vector{UInt64}
-    lock::ReentrantLock          # tasks sharing a key take turns from the ccall to the last read of `scratch`
+end
+
+# The reference call is pure (src/fhe.jl:608-621): tasks may run bootstrap(bkey, ...) on one key side by
+# side.  Calls on one ctx are serialised, so the key hands every call a slot of its own: the first slot
+# is the ctx that holds the key, further ones are clones made on demand, up to `max_slots` (tasks beyond
+# that wait for a slot).  A call keeps its slot from the choice of the flatten mode to the last read of
+# its result words.  Tasks on different Julia threads (Threads.@spawn) then overlap on the device; a
+# ccall blocks its thread, so tasks of ONE thread still take turns.
+mutable struct HipBootstrapKey
+    params::Params
+    ctx::Ptr{Cvoid}              # the ctx the key was uploaded to (slot 1)
+    slots::Vector{Slot}          # every slot made so far
+    free::Channel{Slot}          # the ones not in use
+    max_slots::Int
+    lock::ReentrantLock          # guards `slots` (slot creation)
 
     # Both `rng = nothing` and `rng::AbstractRNG` calls work with every key (ABI revision 6: at
     # Params(1024) the engine keeps a basis per flatten mode).  `random_flatten` is kept for callers
     # written against revision 5 and has no effect; `deterministic_only = true` asks for the smaller
     # basis only (SGFHE_CTX_DETERMINISTIC_ONLY: rng calls are then refused at Params(1024)).
     function HipBootstrapKey(bkey::BootstrapKey; device::Integer=0, random_flatten::Bool=false,
-                             deterministic_only::Bool=false)
+                             deterministic_only::Bool=false, max_slots::Integer=max(1, Threads.nthreads()))
         p = bkey.params
         ctx = create_ctx(p, device, random_flatten, deterministic_only)
         # value.(p.coeffs) of every polynomial, order [k][row][col][coef], 2 x UInt64 each
@@ -97,13 +112,51 @@ mutable struct HipBootstrapKey
         rc = ccall((:sgfhe_bkey_upload, libsgfhe_hip), Int32,
                    (Ptr{Cvoid}, Ptr{UInt64}, Csize_t), ctx[], canon, length(canon))
         check(ctx[], rc)
-        key = new(p, ctx[], UInt64[], ReentrantLock())
-        finalizer(k -> ccall((:sgfhe_ctx_destroy, libsgfhe_hip), Int32, (Ptr{Cvoid},), k.ctx), key)
-        key
+        with_slots(new(p, ctx[], Slot[], Channel{Slot}(Int(max_slots)), Int(max_slots), ReentrantLock()))
     end
 
     # raw constructor used by the generate-on-device method below
-    HipBootstrapKey(params::Params, ctx::Ptr{Cvoid}, ::Nothing) = new(params, ctx, UInt64[], ReentrantLock())
+    HipBootstrapKey(params::Params, ctx::Ptr{Cvoid}, max_slots::Integer) =
+        with_slots(new(params, ctx, Slot[], Channel{Slot}(Int(max_slots)), Int(max_slots), ReentrantLock()))
+end
+
+# first slot = the key's own ctx; the finalizer destroys every ctx (clones and owner in any order:
+# the shared device memory goes with the last of them)
+function with_slots(key::HipBootstrapKey)
+    s = Slot(key.ctx, UInt64[])
+    push!(key.slots, s)
+    put!(key.free, s)
+    finalizer(key) do k
+        for sl in k.slots
+            ccall((:sgfhe_ctx_destroy, libsgfhe_hip), Int32, (Ptr{Cvoid},), sl.ctx)
+        end
+    end
+    key
+end
+
+# A slot for the duration of `f`: a free one, else a new clone while fewer than max_slots exist, else wait.
+function with_slot(f, key::HipBootstrapKey)
+    lock(key.lock) do
+        if !isready(key.free) && length(key.slots) < key.max_slots
+            c = Ref{Ptr{Cvoid}}(C_NULL)
+            rc = ccall((:sgfhe_ctx_clone, libsgfhe_hip), Int32, (Ptr{Cvoid}, Ref{Ptr{Cvoid}}), key.ctx, c)
+            if rc != 0
+                msg = unsafe_string(ccall((:sgfhe_last_error_string, libsgfhe_hip), Cstring, (Ptr{Cvoid},),
+                                          c[] == C_NULL ? key.ctx : c[]))
+                c[] == C_NULL || ccall((:sgfhe_ctx_destroy, libsgfhe_hip), Int32, (Ptr{Cvoid},), c[])
+                error("sgfhe_hip error $rc: $msg")
+            end
+            fresh = Slot(c[], UInt64[])
+            push!(key.slots, fresh)
+            put!(key.free, fresh)
+        end
+    end
+    s = take!(key.free)
+    try
+        f(s)
+    finally
+        put!(key.free, s)
+    end
 end
 
 # Vector{ModUInt{UInt64, r}} is an isbits array: reinterpret is a zero-copy n x UInt64 view
@@ -115,10 +168,10 @@ lwe_words(bits::AbstractVector{EncryptedBit}, n) =
 # rng = nothing: deterministic flatten (src/utils.jl:155-189), bit-exact with the CPU path.
 # rng::AbstractRNG: randomised flatten (src/utils.jl:198-241) from a device ChaCha8 counter stream
 # keyed with 32 bytes of `rng` -- same distribution, not the same stream as the CPU path.
-function set_flatten_mode(hkey, rng)
+function set_flatten_mode(ctx::Ptr{Cvoid}, rng)
     key = rng === nothing ? zeros(UInt8, 32) : rand(rng, UInt8, 32)
-    check(hkey.ctx, ccall((:sgfhe_set_random_flatten_key, libsgfhe_hip), Int32,
-                          (Ptr{Cvoid}, Cint, Ptr{UInt8}), hkey.ctx, rng === nothing ? 0 : 1, key))
+    check(ctx, ccall((:sgfhe_set_random_flatten_key, libsgfhe_hip), Int32,
+                     (Ptr{Cvoid}, Cint, Ptr{UInt8}), ctx, rng === nothing ? 0 : 1, key))
 end
 
 """
@@ -139,15 +192,16 @@ function SGFHE.bootstrap(hkey::HipBootstrapKey, rng::Union{AbstractRNG,Nothing},
     # new_repr = ModUInt, new_base_type = UInt64, new_modulus = params.r (src/utils.jl:116, src/fhe.jl:616-618)
     mk(x::UInt64) = ModUInt(x, p.r, _verbatim)
     res = Vector{NTuple{3,EncryptedBit}}(undef, batch)
-    lock(hkey.lock) do
-        set_flatten_mode(hkey, rng)               # mode and call stay together under the lock
-        length(hkey.scratch) < batch * 3 * (n + 1) && resize!(hkey.scratch, batch * 3 * (n + 1))
-        out = hkey.scratch
+    # (the rng is read before the slot is taken: the caller's rng need not be task-safe beyond its own use)
+    with_slot(hkey) do slot
+        set_flatten_mode(slot.ctx, rng)           # mode and call stay together on the slot's own ctx
+        length(slot.scratch) < batch * 3 * (n + 1) && resize!(slot.scratch, batch * 3 * (n + 1))
+        out = slot.scratch
         rc = ccall((:sgfhe_bootstrap_batch, libsgfhe_hip), Int32,
                    (Ptr{Cvoid}, Ptr{UInt64}, Ptr{UInt64}, Ptr{UInt64}, Ptr{UInt64}, Csize_t,
                     Ptr{UInt64}, UInt32),
-                   hkey.ctx, a1, b1, a2, b2, batch, out, 0)
-        check(hkey.ctx, rc)
+                   slot.ctx, a1, b1, a2, b2, batch, out, 0)
+        check(slot.ctx, rc)
         for t in 1:batch
             base = (t - 1) * 3 * (n + 1)
             res[t] = ntuple(3) do g
@@ -166,16 +220,15 @@ Generates the bootstrap key on the GPU (BootstrapKey(rng, sk), src/fhe.jl:181-20
 32-byte seed (ChaCha20 streams on the device): `rand(RandomDevice(), UInt8, 32)` for real keys.
 """
 function HipBootstrapKey(params::Params, sk::SGFHE.PrivateKey, seed::Vector{UInt8};
-                         device::Integer=0, random_flatten::Bool=false)
+                         device::Integer=0, random_flatten::Bool=false,
+                         max_slots::Integer=max(1, Threads.nthreads()))
     @assert length(seed) == 32
     ctx = create_ctx(params, device, random_flatten)
     bits = UInt64[UInt64(value(c)) for c in sk.key.coeffs]
     check(ctx[], ccall((:sgfhe_bkey_generate, libsgfhe_hip), Int32,
                        (Ptr{Cvoid}, Ptr{UInt64}, Csize_t, Ptr{UInt8}, UInt32),
                        ctx[], bits, length(bits), seed, UInt32(params.n)))
-    key = HipBootstrapKey(params, ctx[], nothing)
-    finalizer(k -> ccall((:sgfhe_ctx_destroy, libsgfhe_hip), Int32, (Ptr{Cvoid},), k.ctx), key)
-    key
+    HipBootstrapKey(params, ctx[], max_slots)
 end
 
 """
@@ -191,12 +244,12 @@ function SGFHE.pack_encrypted_bits(hkey::HipBootstrapKey, rng::Union{AbstractRNG
     a, b = lwe_words(enc_bits, p.n)
     w = Vector{UInt64}(undef, p.m)
     v = Vector{UInt64}(undef, p.m)
-    lock(hkey.lock) do
-        set_flatten_mode(hkey, rng)
+    with_slot(hkey) do slot
+        set_flatten_mode(slot.ctx, rng)
         rc = ccall((:sgfhe_pack_encrypted_bits, libsgfhe_hip), Int32,
                    (Ptr{Cvoid}, Ptr{UInt64}, Ptr{UInt64}, Csize_t, Ptr{UInt64}, Ptr{UInt64}),
-                   hkey.ctx, a, b, 1, w, v)
-        check(hkey.ctx, rc)
+                   slot.ctx, a, b, 1, w, v)
+        check(slot.ctx, rc)
     end
     mk(x::UInt64) = ModUInt(x, p.r, _verbatim)     # as at src/utils.jl:116 (reduce_modulus of src/fhe.jl:692-693)
     SGFHE.Ciphertext(p, SGFHE.RLWE(Polynomial(mk.(w), negacyclic_modulus),

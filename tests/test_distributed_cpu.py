@@ -100,6 +100,14 @@ def test_bench_self_launch_dry_run(gpus):
     d = json.loads(lines[0])
     assert d["n_gpus"] == gpus and d["steps"] == 3 and d["warmup"] == 1
     assert d["max_over_ranks"] == float(gpus)           # MAX over ranks of (1 + rank)
+    # the proof that N ranks talked: all-reduce(SUM) of 1 over the process group, asserted
+    # equal to --gpus before the line is printed; the real line carries it as config.rccl_ranks over RCCL
+    c = d["config"]
+    if gpus > 1:
+        assert c["group_ranks"] == gpus and c["collective_backend"] == "gloo"
+    else:
+        assert c["group_ranks"] is None
+    assert c["rccl_ranks"] is None and c["key_broadcast_gbs"] is None      # (gloo rehearsal: no RCCL figure)
 
 
 def test_bench_refuses_mismatched_world():

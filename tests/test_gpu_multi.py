@@ -219,6 +219,9 @@ def test_bench_two_gpus_self_launch():
     assert r.returncode == 0, r.stderr[-2000:]
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert d["n_gpus"] == 2 and d["config"]["key_broadcast_s"] > 0 and d["value"] > 0
+    # the ranks proved they talked over RCCL, and the broadcast has a rate
+    assert d["config"]["rccl_ranks"] == 2 and d["config"]["collective_backend"] == "nccl"
+    assert d["config"]["key_broadcast_gbs"] > 0
 
 
 @pytest.mark.parametrize("ranks", [2, 4])
@@ -242,6 +245,10 @@ def test_bench_ranks_rehearsal_on_one_gpu(ranks):
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d["n_gpus"] == ranks and d["config"]["key_broadcast_s"] > 0 and "rehearsal" in d["config"]
+    # all-reduce(SUM) of 1 over the group == --gpus, asserted by bench.py before it prints; a rehearsal over
+    # gloo claims no RCCL figure
+    assert d["config"]["group_ranks"] == ranks and d["config"]["collective_backend"] == "gloo"
+    assert d["config"]["rccl_ranks"] is None and d["config"]["key_broadcast_gbs"] > 0
     assert d["value"] > 0 and abs(d["value"] - ranks * 512 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
     assert d["host_io"]["equals_device_resident_output"] is True and "cpu_baseline" not in d
 
@@ -284,4 +291,6 @@ def test_bench_under_torchrun_with_rccl_one_rank():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and d["value"] > 0 and "rehearsal" not in d["config"]
     assert d["config"]["key_broadcast_s"] > 0          # the broadcast went through RCCL
+    assert d["config"]["rccl_ranks"] == 1 and d["config"]["collective_backend"] == "nccl"   # all-reduce(SUM) of 1 on RCCL
+    assert d["config"]["key_broadcast_gbs"] is None    # (no peer: nothing moved)
     assert d["host_io"]["equals_device_resident_output"] is True

@@ -83,10 +83,10 @@ def test_external_product(S, oc, use_gadget):
 FORMS = ["small-batch form", "throughput form"]
 
 
-def _engine(S, params, form):
+def _engine(S, exp, params, form):
     """Engine whose small chunks take the small-batch kernels (k_fwd_phase / k_inv_column, default
     threshold 24) or, threshold 0, the throughput kernel k_extprod<LOGM> like a large batch."""
-    eng = S.Engine(params)
+    eng = exp.engine(S, params)
     if form == "throughput form":
         eng.set_small_batch_max(0)
     return eng
@@ -94,7 +94,7 @@ def _engine(S, params, form):
 
 @pytest.mark.parametrize("form", FORMS)
 @pytest.mark.parametrize("n", [8, 16, 32, 128, 256])
-def test_small_synthetic_bootstrap(S, oc, n, form):
+def test_small_synthetic_bootstrap(S, oc, exp, n, form):
     """Synthetic rings (m = 64 ... 2048: every pass structure below the full-size rings) vs the
     oracle: accumulators after every iteration count, raw LWEs mod Q, and ModRed words."""
     Q, B = _synthetic(n)
@@ -102,18 +102,18 @@ def test_small_synthetic_bootstrap(S, oc, n, form):
     o = oc.Oracle.from_params(params)
     sk = o.private_key(100 + n)
     bkey = o.bootstrap_key(sk, 200 + n, noise=2)
-    eng = _engine(S, params, form)
+    eng = _engine(S, exp, params, form)
     eng.upload_key(bkey)
     batch = 5
     bits, a1, b1, a2, b2 = _inputs(o, sk, batch, 300 + n)
+    tag = "parity.synth%d" % n
     for it in (1, 2, n):
-        _, acc_ref = o.bootstrap_batch(bkey, a1, b1, a2, b2, n_iters=it, want_acc=True)
-        acc = eng.debug_accumulators(a1, b1, a2, b2, it)
-        assert np.array_equal(acc, acc_ref), "accumulators differ after %d iterations" % it
-    assert np.array_equal(eng.bootstrap_batch(a1, b1, a2, b2, raw=True),
-                          o.bootstrap_batch(bkey, a1, b1, a2, b2, raw=True))
-    assert np.array_equal(eng.bootstrap_batch(a1, b1, a2, b2),
-                          o.bootstrap_batch(bkey, a1, b1, a2, b2))
+        exp.check(tag + ".acc%d" % it, eng.debug_accumulators(a1, b1, a2, b2, it),
+                  lambda: o.bootstrap_batch(bkey, a1, b1, a2, b2, n_iters=it, want_acc=True)[1],
+                  "accumulators differ after %d iterations" % it)
+    exp.check(tag + ".raw", eng.bootstrap_batch(a1, b1, a2, b2, raw=True),
+              lambda: o.bootstrap_batch(bkey, a1, b1, a2, b2, raw=True))
+    exp.check(tag + ".out", eng.bootstrap_batch(a1, b1, a2, b2), lambda: o.bootstrap_batch(bkey, a1, b1, a2, b2))
     eng.close()
 
 
@@ -160,24 +160,29 @@ def test_params64_bootstrap_truth_table(S, oc):
 
 # ---- BASELINE.json configurations at full ring size --------------------------------------------
 
-def _big_case(S, oc, params, batch, key_seed, in_seed, valid_key, iters_checked, form=FORMS[0]):
+def _big_case(S, oc, exp, tag, params, batch, key_seed, in_seed, valid_key, iters_checked, form=FORMS[0]):
+    """The oracle here is the REFERENCE-SHAPED loop (24 NTT products per iteration, canonical key): its
+    answers are recorded expectations (tests/expect.py); both kernel forms are held to the same digests."""
     o = oc.Oracle.from_params(params)
     sk = o.private_key(key_seed)
+    eng = _engine(S, exp, params, form)
     if valid_key:
-        bkey = o.bootstrap_key(sk, key_seed + 1)
+        bkey = exp.lazy(lambda: o.bootstrap_key(sk, key_seed + 1))
+        if params.n >= 1024:
+            eng.generate_key(sk, key_seed + 1)          # byte-identical to the oracle's (test_gpu_golden.py)
+        elif exp.live:
+            eng.upload_key(bkey())
     else:
         import bench
-        bkey = bench.random_key(params, key_seed)
-    eng = _engine(S, params, form)
-    eng.upload_key(bkey)
+        rk = bench.random_key(params, key_seed)
+        bkey = exp.lazy(lambda: rk)
+        eng.upload_key(rk)
     bits, a1, b1, a2, b2 = _inputs(o, sk, batch, in_seed)
     for it in iters_checked:
-        _, acc_ref = o.bootstrap_batch(bkey, a1[:1], b1[:1], a2[:1], b2[:1], n_iters=it, want_acc=True)
-        acc = eng.debug_accumulators(a1[:1], b1[:1], a2[:1], b2[:1], it)
-        assert np.array_equal(acc, acc_ref), "accumulators differ after %d iterations" % it
-    out = eng.bootstrap_batch(a1, b1, a2, b2)
-    ref = o.bootstrap_batch(bkey, a1, b1, a2, b2)
-    assert np.array_equal(out, ref)
+        exp.check(tag + ".acc%d" % it, eng.debug_accumulators(a1[:1], b1[:1], a2[:1], b2[:1], it),
+                  lambda: o.bootstrap_batch(bkey(), a1[:1], b1[:1], a2[:1], b2[:1], n_iters=it, want_acc=True)[1],
+                  "accumulators differ after %d iterations" % it)
+    out = exp.check(tag + ".out", eng.bootstrap_batch(a1, b1, a2, b2), lambda: o.bootstrap_batch(bkey(), a1, b1, a2, b2))
     if valid_key:
         y1, y2 = bits[0::2], bits[1::2]
         for g, fn in enumerate((np.bitwise_and, np.bitwise_or, np.bitwise_xor)):
@@ -189,48 +194,46 @@ def _big_case(S, oc, params, batch, key_seed, in_seed, valid_key, iters_checked,
 
 @pytest.mark.parametrize("form", FORMS)
 @pytest.mark.parametrize("n", [128, 256])
-def test_params128_256_vs_oracle(S, oc, n, form):
+def test_params128_256_vs_oracle(S, oc, exp, n, form):
     """The reference's parameter sets between Params(64) and Params(512) (Q 68.25 / 74.25 bits,
     m = 1024 / 2048: the pass structures with a 2- and a 3-stage partial pass): complete
     bootstraps, bit-exact and decrypting."""
-    _big_case(S, oc, S.Params(n), batch=6, key_seed=40 + n, in_seed=50 + n, valid_key=True,
+    _big_case(S, oc, exp, "parity.p%d" % n, S.Params(n), batch=6, key_seed=40 + n, in_seed=50 + n, valid_key=True,
               iters_checked=(1, n), form=form)
 
 
 @pytest.mark.parametrize("form", FORMS)
-def test_params512_vs_oracle(S, oc, form):
+def test_params512_vs_oracle(S, oc, exp, form):
     """BASELINE.json config 2 ring (Params(512), Q 80.25 bits): bit-exact vs the oracle, decrypts."""
-    _big_case(S, oc, S.Params(512), batch=8, key_seed=11, in_seed=12, valid_key=True,
+    _big_case(S, oc, exp, "parity.p512", S.Params(512), batch=8, key_seed=11, in_seed=12, valid_key=True,
               iters_checked=(1, 2), form=form)
 
 
-def test_params512_full_batch_1024(S, oc):
+def test_params512_full_batch_1024(S, oc, exp):
     """BASELINE.json config 2 at its full batch: 1024 bootstraps in one call (one 1024-chunk).
     The oracle covers 8 distinct input pairs; the batch tiles them 128 times in a shuffled order,
     so every one of the 1024 x 3 x 513 output words is pinned to an oracle word."""
     params = S.Params(512)
     o = oc.Oracle.from_params(params)
     sk = o.private_key(11)
-    bkey = o.bootstrap_key(sk, 12)
-    eng = S.Engine(params)
-    eng.upload_key(bkey)
+    eng = exp.engine(S, params)
+    eng.generate_key(sk, 12)
     bits, a1, b1, a2, b2 = _inputs(o, sk, 8, 13)
-    ref = o.bootstrap_batch(bkey, a1, b1, a2, b2)
     idx = np.random.default_rng(14).permutation(np.repeat(np.arange(8), 128))
-    out = eng.bootstrap_batch(a1[idx], b1[idx], a2[idx], b2[idx])
+    out = exp.check("parity.p512.full1024", eng.bootstrap_batch(a1[idx], b1[idx], a2[idx], b2[idx]),
+                    lambda: o.bootstrap_batch(o.bootstrap_key(sk, 12), a1, b1, a2, b2)[idx])
     assert out.shape == (1024, 3, params.n + 1)
-    assert np.array_equal(out, ref[idx])
     eng.close()
 
 
 @pytest.mark.parametrize("form", FORMS)
-def test_params1024_vs_oracle(S, oc, form):
+def test_params1024_vs_oracle(S, oc, exp, form):
     """BASELINE.json config 4' (the reference's own Params(1024), Q 86.25 bits)."""
-    _big_case(S, oc, S.Params(1024), batch=4, key_seed=21, in_seed=22, valid_key=True,
+    _big_case(S, oc, exp, "parity.p1024", S.Params(1024), batch=4, key_seed=21, in_seed=22, valid_key=True,
               iters_checked=(1, 2), form=form)
 
 
-def test_params1024_full_batch_4096(S, oc):
+def test_params1024_full_batch_4096(S, oc, exp):
     """The bench workload at full size (Params(1024), batch 4096 = 8 chunks of 512): 4 input pairs
     verified by the oracle, tiled 1024 times in a shuffled order; every output word is pinned to
     an oracle word, across all chunks and batch positions.  The key comes from the device
@@ -238,14 +241,13 @@ def test_params1024_full_batch_4096(S, oc):
     params = S.Params(1024)
     o = oc.Oracle.from_params(params)
     sk = o.private_key(21)
-    bkey = o.bootstrap_key(sk, 22)
-    eng = S.Engine(params)
+    eng = exp.engine(S, params)
     eng.generate_key(sk, 22)
     bits, a1, b1, a2, b2 = _inputs(o, sk, 4, 23)
-    ref = o.bootstrap_batch(bkey, a1, b1, a2, b2)
+    ref4 = exp.lazy(lambda: o.bootstrap_batch(o.bootstrap_key(sk, 22), a1, b1, a2, b2))   # reference-shaped loop
+    exp.check("parity.p1024.in23.out4", eng.bootstrap_batch(a1, b1, a2, b2), ref4)
     idx = np.random.default_rng(24).permutation(np.repeat(np.arange(4), 1024))
-    out = eng.bootstrap_batch(a1[idx], b1[idx], a2[idx], b2[idx])
-    assert np.array_equal(out, ref[idx])
+    out = exp.check("parity.p1024.full4096", eng.bootstrap_batch(a1[idx], b1[idx], a2[idx], b2[idx]), lambda: ref4()[idx])
     y1, y2 = bits[0::2], bits[1::2]
     dec = o.lwe_decrypt_bits(sk, out[:4096:512, 2, :params.n], out[:4096:512, 2, params.n])
     assert np.array_equal(dec, (y1 ^ y2)[idx[:4096:512]])
@@ -253,7 +255,7 @@ def test_params1024_full_batch_4096(S, oc):
 
 
 @pytest.mark.parametrize("form", FORMS)
-def test_params2048_largest_reference_ring(S, oc, form):
+def test_params2048_largest_reference_ring(S, oc, exp, form):
     """Params(2048): the largest parameter set the reference can build (Q 92.25 bits < 2^128,
     src/fhe.jl:74-77): m = 16384, six RNS primes, B just above 2^46.  The first two k-loop
     iterations against the oracle (only key slices 0 and 1 are filled), then complete gate
@@ -262,7 +264,10 @@ def test_params2048_largest_reference_ring(S, oc, form):
     import bench
     params = S.Params(2048)
     o = oc.Oracle.from_params(params)
-    eng = _engine(S, params, form)
+    if not exp.live:
+        pytest.skip("two live oracle iterations and decryption checks: nothing to record "
+                    "(complete Params(2048) bootstraps against recorded bytes: tests/test_gpu_round5.py)")
+    eng = _engine(S, exp, params, form)
     assert len(eng.primes()) == 6                          # 5 m B Q needs six 29-bit primes
     key = np.zeros((params.n, 4, 2, params.m, 2), dtype=np.uint64)
     key[:2] = bench.random_key(params, 41)[:2]
@@ -300,16 +305,16 @@ def test_params2048_largest_reference_ring(S, oc, form):
 
 
 @pytest.mark.parametrize("form", FORMS)
-def test_synthetic_single_limb_1024(S, oc, form):
+def test_synthetic_single_limb_1024(S, oc, exp, form):
     """BASELINE.json config 3: n = 1024, single-limb 64-bit prime Q', B' = 2^32 (synthetic: the
     parity target is the oracle at the same parameters, not decryption)."""
     import bench
     params = bench.make_params(S, "synth64")
-    _big_case(S, oc, params, batch=2, key_seed=31, in_seed=32, valid_key=False, iters_checked=(1, 3),
-              form=form)
+    _big_case(S, oc, exp, "parity.synth64", params, batch=2, key_seed=31, in_seed=32, valid_key=False,
+              iters_checked=(1, 3), form=form)
 
 
-def test_synthetic_single_limb_full_batch_4096(S, oc):
+def test_synthetic_single_limb_full_batch_4096(S, oc, exp):
     """BASELINE.json config 3 at its full batch: n = 1024 over a single-limb 64-bit prime, batch
     4096 (8 chunks of 512 on the four-prime grid at m = 8192).  Four random LWE input pairs are
     verified by the oracle on the synthetic key of the bench (`bench.random_key`), tiled 1024
@@ -320,24 +325,23 @@ def test_synthetic_single_limb_full_batch_4096(S, oc):
     params = bench.make_params(S, "synth64")
     o = oc.Oracle.from_params(params)
     key = bench.random_key(params, 31)
-    eng = S.Engine(params)
-    assert len(eng.primes()) == 4
+    eng = exp.engine(S, params)
+    if exp.live:
+        assert len(eng.primes()) == 4
     eng.upload_key(key)
     rng = np.random.default_rng(33)
     a1 = rng.integers(0, params.r, size=(4, params.n), dtype=np.uint64)
     a2 = rng.integers(0, params.r, size=(4, params.n), dtype=np.uint64)
     b1 = rng.integers(0, params.r, size=4, dtype=np.uint64)
     b2 = rng.integers(0, params.r, size=4, dtype=np.uint64)
-    ref = o.bootstrap_batch(key, a1, b1, a2, b2, threads=4)
-    del key
     idx = np.random.default_rng(34).permutation(np.repeat(np.arange(4), 1024))
-    out = eng.bootstrap_batch(a1[idx], b1[idx], a2[idx], b2[idx])
+    out = exp.check("parity.synth64.full4096", eng.bootstrap_batch(a1[idx], b1[idx], a2[idx], b2[idx]),
+                    lambda: o.bootstrap_batch(key, a1, b1, a2, b2, threads=4)[idx])
     assert out.shape == (4096, 3, params.n + 1)
-    assert np.array_equal(out, ref[idx])
     eng.close()
 
 
-def test_config5_per_gpu_shards_of_65536(S, oc):
+def test_config5_per_gpu_shards_of_65536(S, oc, exp):
     """BASELINE.json config 5 on the one GPU a box has: Params(1024), a logical batch of 65536
     bootstraps cut into the 8 contiguous shards `shard_range(65536, g, 8)` that 8 ranks would
     take (8192 each = 16 chunks of 512).  Every shard runs through Engine.bootstrap_batch as a
@@ -348,12 +352,15 @@ def test_config5_per_gpu_shards_of_65536(S, oc):
     params = S.Params(1024)
     o = oc.Oracle.from_params(params)
     sk = o.private_key(21)
-    bkey = o.bootstrap_key(sk, 22)
-    eng = S.Engine(params)
+    eng = exp.engine(S, params)
     eng.generate_key(sk, 22)
     bits, a1, b1, a2, b2 = _inputs(o, sk, 4, 23)
-    ref = o.bootstrap_batch(bkey, a1, b1, a2, b2, threads=4)
-    del bkey
+    # the four oracle rows every one of the 65536 is a copy of (the key and inputs of
+    # test_params1024_full_batch_4096: the same recorded expectation)
+    ref = exp.check("parity.p1024.in23.out4", eng.bootstrap_batch(a1, b1, a2, b2),
+                    lambda: o.bootstrap_batch(o.bootstrap_key(sk, 22), a1, b1, a2, b2, threads=4))
+    if not exp.live:
+        return
     total, world = 65536, 8
     idx = np.random.default_rng(25).permutation(np.repeat(np.arange(4), total // 4))
     shards = []
@@ -377,7 +384,7 @@ def test_config5_per_gpu_shards_of_65536(S, oc):
     eng.close()
 
 
-def test_params64_soak_4096_random_bootstraps(S, oc):
+def test_params64_soak_4096_random_bootstraps(S, oc, exp):
     """4096 independent gate bootstraps at Params(64) with a device-generated key, every output
     word against the oracle (random LWE inputs and valid encryptions mixed), all three gates
     decrypting where the inputs are encryptions: a wide net for rare range / carry cases of the
@@ -385,8 +392,7 @@ def test_params64_soak_4096_random_bootstraps(S, oc):
     params = S.Params(64)
     o = oc.Oracle.from_params(params)
     sk = o.private_key(71)
-    bkey = o.bootstrap_key(sk, 72)
-    eng = S.Engine(params)
+    eng = exp.engine(S, params)
     eng.generate_key(sk, 72)
     rng = np.random.default_rng(73)
     bits = rng.integers(0, 2, size=2 * 2048).astype(np.uint8)
@@ -395,9 +401,8 @@ def test_params64_soak_4096_random_bootstraps(S, oc):
     a2 = np.concatenate([a[1::2], rng.integers(0, params.r, size=(2048, params.n), dtype=np.uint64)])
     b1 = np.concatenate([b[0::2], rng.integers(0, params.r, size=2048, dtype=np.uint64)])
     b2 = np.concatenate([b[1::2], rng.integers(0, params.r, size=2048, dtype=np.uint64)])
-    out = eng.bootstrap_batch(a1, b1, a2, b2)
-    ref = o.bootstrap_batch(bkey, a1, b1, a2, b2, threads=16)
-    assert np.array_equal(out, ref)
+    out = exp.check("parity.p64.soak4096", eng.bootstrap_batch(a1, b1, a2, b2),
+                    lambda: o.bootstrap_batch(o.bootstrap_key(sk, 72), a1, b1, a2, b2, threads=16))
     y1, y2 = bits[0::2], bits[1::2]
     for g, fn in enumerate((np.bitwise_and, np.bitwise_or, np.bitwise_xor)):
         dec = o.lwe_decrypt_bits(sk, out[:2048, g, :params.n], out[:2048, g, params.n])

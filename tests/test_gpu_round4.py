@@ -9,7 +9,11 @@
    (the reference call is pure, src/fhe.jl:608-621);
  * the randomised flatten on parameter sets with a two-limb modulus and a base far above sqrt(Q).
 
-Run on the GPU box with `pytest -m gpu`.  Everything goes through the C ABI."""
+Run on the GPU box with `pytest -m gpu`.  Everything goes through the C ABI.
+
+Round 5: the oracle halves of the fixed-seed comparisons are recorded digests (tests/expect.py,
+tests/golden/gpu_expect.json, made by the oracle alone in the build container); the live oracle runs on the
+GPU box only where a digest is missing or differs."""
 
 import hashlib
 import json
@@ -27,14 +31,7 @@ G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 FKEY = bytes(range(11, 43))
 
 
-def _threads():
-    try:
-        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
-        if q != "max":
-            return max(1, int(q) // int(per))
-    except OSError:
-        pass
-    return min(32, os.cpu_count() or 1)
+from conftest import oracle_threads as _threads  # noqa: E402
 
 
 def h_ints(vals, nbytes=16):
@@ -65,17 +62,17 @@ def _mixed_inputs(o, sk, p, count, seed):
 
 
 @pytest.fixture(scope="module")
-def p1024six(S, oc):
+def p1024six(S, oc, exp):
     """Params(1024) on a default ctx (a basis per flatten mode) with the key of
-    tests/golden/p1024*.json; the oracle's key in the NTT domain."""
+    tests/golden/p1024*.json; the oracle's key in the NTT domain, made on first use (on the GPU box: only
+    when a recorded expectation is missing or differs)."""
     params = S.Params(1024)
     o = oc.Oracle.from_params(params)
     sk = o.private_key(21)
-    bkey = o.bootstrap_key(sk, 22)
-    khat = o.key_transform(bkey, threads=_threads())
-    del bkey
-    eng = S.Engine(params)
-    assert len(eng.primes()) == 5
+    khat = exp.lazy(lambda: o.key_transform(o.bootstrap_key(sk, 22, threads=_threads()), threads=_threads()))
+    eng = exp.engine(S, params)
+    if exp.live:
+        assert len(eng.primes()) == 5
     eng.generate_key(sk, 22)                    # byte-identical to the oracle's key (test_gpu_golden.py)
     yield params, o, sk, khat, eng
     eng.close()
@@ -83,8 +80,11 @@ def p1024six(S, oc):
 
 # ---- 1. the dual-basis Params(1024) ctx, deterministic mode (derived five-prime key) ----------------
 
-@pytest.mark.parametrize("form", ["small-batch form", "throughput form"])
-def test_dual_basis_ctx_deterministic_mode_vs_oracle(S, oc, p1024six, form):
+FORMS4 = ["small-batch form", "throughput form"]
+
+
+@pytest.mark.parametrize("form", FORMS4)
+def test_dual_basis_ctx_deterministic_mode_vs_oracle(S, oc, exp, p1024six, form):
     """The deterministic mode of a ctx that also holds the randomised mode's six-prime basis: five
     primes, the key form derived on the device (k_key_derive) -- accumulators after k = 1, 2 and n
     iterations, raw LWEs mod Q and ModRed words of 4 bootstraps against the C restatement; the
@@ -93,25 +93,29 @@ def test_dual_basis_ctx_deterministic_mode_vs_oracle(S, oc, p1024six, form):
     eng.set_random_flatten(False)
     eng.set_small_batch_max(0 if form == "throughput form" else 24)
     eng.set_random_flatten(True, FKEY)          # there and back: the basis switch leaves nothing behind
-    assert len(eng.primes()) == 6
+    if exp.live:
+        assert len(eng.primes()) == 6
     eng.set_random_flatten(False)
-    assert eng.kernel_names() == ("k_extprod<13, 4, false>", "k_crt_lean<5, 3>") and len(eng.primes()) == 5
+    if exp.live:
+        assert eng.kernel_names() == ("k_extprod<13, 4, false>", "k_crt_lean<5, 3>") and len(eng.primes()) == 5
     bits, a1, b1, a2, b2 = _mixed_inputs(o, sk, params, 4, 61)
     T = _threads()
+    # (both kernel forms must give the oracle's bytes: one tag serves both parametrisations)
     for it in (1, 2, params.n):
-        _, ref = o.bootstrap_batch(khat, a1, b1, a2, b2, n_iters=it, want_acc=True, opt=True, threads=T)
-        assert np.array_equal(eng.debug_accumulators(a1, b1, a2, b2, it), ref), "accumulators after %d" % it
-    assert np.array_equal(eng.bootstrap_batch(a1, b1, a2, b2, raw=True),
-                          o.bootstrap_batch(khat, a1, b1, a2, b2, raw=True, opt=True, threads=T))
-    out = eng.bootstrap_batch(a1, b1, a2, b2)
-    assert np.array_equal(out, o.bootstrap_batch(khat, a1, b1, a2, b2, opt=True, threads=T))
+        exp.check("r4.dual.det.acc%d" % it, eng.debug_accumulators(a1, b1, a2, b2, it),
+                  lambda: o.bootstrap_batch(khat(), a1, b1, a2, b2, n_iters=it, want_acc=True, opt=True, threads=T)[1],
+                  "accumulators after %d" % it)
+    exp.check("r4.dual.det.raw", eng.bootstrap_batch(a1, b1, a2, b2, raw=True),
+              lambda: o.bootstrap_batch(khat(), a1, b1, a2, b2, raw=True, opt=True, threads=T))
+    out = exp.check("r4.dual.det.out", eng.bootstrap_batch(a1, b1, a2, b2),
+                    lambda: o.bootstrap_batch(khat(), a1, b1, a2, b2, opt=True, threads=T))
     y1, y2 = bits[0::2], bits[1::2]
     for g, fn in enumerate((np.bitwise_and, np.bitwise_or, np.bitwise_xor)):
         assert np.array_equal(o.lwe_decrypt_bits(sk, out[:, g, :params.n], out[:, g, params.n]), fn(y1, y2))
     eng.set_small_batch_max(24)
 
 
-def test_dual_basis_ctx_deterministic_full_batch_4096(S, oc, p1024six):
+def test_dual_basis_ctx_deterministic_full_batch_4096(S, oc, exp, p1024six):
     """The dual-basis ctx in its deterministic mode at the full batch: 8 distinct oracle-verified
     input pairs tiled over 4096 rows in a shuffled order, every output word pinned; equal to the
     bytes of a ctx created with SGFHE_CTX_DETERMINISTIC_ONLY, whose five-prime key form comes
@@ -119,21 +123,21 @@ def test_dual_basis_ctx_deterministic_full_batch_4096(S, oc, p1024six):
     params, o, sk, khat, eng = p1024six
     eng.set_random_flatten(False)
     bits, a1, b1, a2, b2 = _mixed_inputs(o, sk, params, 8, 62)
-    ref = o.bootstrap_batch(khat, a1, b1, a2, b2, opt=True, threads=_threads())
     idx = np.random.default_rng(63).permutation(np.repeat(np.arange(8), 512))
-    out = eng.bootstrap_batch(a1[idx], b1[idx], a2[idx], b2[idx])
-    assert np.array_equal(out, ref[idx])
-    five = S.Engine(params, deterministic_only=True)
-    assert len(five.primes()) == 5
-    five.generate_key(sk, 22)
-    assert five.bootstrap_batch(a1[idx[:64]], b1[idx[:64]], a2[idx[:64]], b2[idx[:64]]).tobytes() == \
-        out[:64].tobytes()
-    five.close()
+    out = exp.check("r4.dual.det.full4096", eng.bootstrap_batch(a1[idx], b1[idx], a2[idx], b2[idx]),
+                    lambda: o.bootstrap_batch(khat(), a1, b1, a2, b2, opt=True, threads=_threads())[idx])
+    if exp.live:
+        five = S.Engine(params, deterministic_only=True)
+        assert len(five.primes()) == 5
+        five.generate_key(sk, 22)
+        assert five.bootstrap_batch(a1[idx[:64]], b1[idx[:64]], a2[idx[:64]], b2[idx[:64]]).tobytes() == \
+            out[:64].tobytes()
+        five.close()
 
 
 # ---- 1. the dual-basis Params(1024) ctx, randomised mode (six primes) ---------------------------------
 
-def test_dual_basis_ctx_random_mode_accumulators_vs_oracle(S, oc, p1024six):
+def test_dual_basis_ctx_random_mode_accumulators_vs_oracle(S, oc, exp, p1024six):
     """bootstrap(bkey, rng, ...) at the reference's own Params(1024): accumulators after k = 1, 2 and
     n iterations, raw LWEs and ModRed words of 4 bootstraps bit for bit against the C restatement of
     utils.jl:198-241 on the same ChaCha8 stream (small-batch and throughput kernels)."""
@@ -143,19 +147,19 @@ def test_dual_basis_ctx_random_mode_accumulators_vs_oracle(S, oc, p1024six):
     for form in (24, 0):
         eng.set_small_batch_max(form)
         eng.set_random_flatten(True, FKEY)                      # call number back to 0
-        assert eng.kernel_names()[1] == "k_crt_lean_rnd<6, 3, false>" and len(eng.primes()) == 6
+        if exp.live:
+            assert eng.kernel_names()[1] == "k_crt_lean_rnd<6, 3, false>" and len(eng.primes()) == 6
         call = 0
-        for it in (1, 2, params.n):
-            _, ref = o.bootstrap_batch(khat, a1, b1, a2, b2, n_iters=it, want_acc=True, opt=True, threads=T,
-                                       rnd=(FKEY, call))
-            assert np.array_equal(eng.debug_accumulators(a1, b1, a2, b2, it), ref), (form, it)
+        for it in (1, 2, params.n):     # (both kernel forms against the same recorded oracle bytes)
+            exp.check("r4.dual.rnd.acc%d" % it, eng.debug_accumulators(a1, b1, a2, b2, it),
+                      lambda: o.bootstrap_batch(khat(), a1, b1, a2, b2, n_iters=it, want_acc=True, opt=True,
+                                                threads=T, rnd=(FKEY, call))[1], repr((form, it)))
             call += 1
-        raw = eng.bootstrap_batch(a1, b1, a2, b2, raw=True)
-        assert np.array_equal(raw, o.bootstrap_batch(khat, a1, b1, a2, b2, raw=True, opt=True, threads=T,
-                                                     rnd=(FKEY, call)))
+        exp.check("r4.dual.rnd.raw", eng.bootstrap_batch(a1, b1, a2, b2, raw=True),
+                  lambda: o.bootstrap_batch(khat(), a1, b1, a2, b2, raw=True, opt=True, threads=T, rnd=(FKEY, call)))
         call += 1
-        out = eng.bootstrap_batch(a1, b1, a2, b2)
-        assert np.array_equal(out, o.bootstrap_batch(khat, a1, b1, a2, b2, opt=True, threads=T, rnd=(FKEY, call)))
+        out = exp.check("r4.dual.rnd.out", eng.bootstrap_batch(a1, b1, a2, b2),
+                        lambda: o.bootstrap_batch(khat(), a1, b1, a2, b2, opt=True, threads=T, rnd=(FKEY, call)))
         y1, y2 = bits[0::2], bits[1::2]
         for g, fn in enumerate((np.bitwise_and, np.bitwise_or, np.bitwise_xor)):
             assert np.array_equal(o.lwe_decrypt_bits(sk, out[:, g, :params.n], out[:, g, params.n]), fn(y1, y2))
@@ -163,7 +167,7 @@ def test_dual_basis_ctx_random_mode_accumulators_vs_oracle(S, oc, p1024six):
     eng.set_random_flatten(False)
 
 
-def test_dual_basis_ctx_random_mode_full_batch_4096(S, oc, p1024six):
+def test_dual_basis_ctx_random_mode_full_batch_4096(S, oc, exp, p1024six):
     """The workload of `bench.py --flatten random` at its ring and batch.  In the randomised mode
     every row of a call has its own draws (counter word = its index in the call), so tiling inputs
     does not tile outputs: 8 distinct input pairs are tiled over the 4096 rows, and 96 rows -- the
@@ -181,9 +185,12 @@ def test_dual_basis_ctx_random_mode_full_batch_4096(S, oc, p1024six):
                       [int(v) for v in np.random.default_rng(67).choice(4096, size=64, replace=False)]))
     rows = np.array(rows)
     src = idx[rows]
-    ref = o.bootstrap_batch(khat, a1[src], b1[src], a2[src], b2[src], opt=True, threads=_threads(),
-                            rnd=(FKEY, 1, rows.astype(np.uint32)))
-    assert np.array_equal(out[rows], ref)
+    pinned = exp.check("r4.dual.rnd.full4096.rows", out[rows] if exp.live else None,
+                       lambda: o.bootstrap_batch(khat(), a1[src], b1[src], a2[src], b2[src], opt=True,
+                                                 threads=_threads(), rnd=(FKEY, 1, rows.astype(np.uint32))))
+    if not exp.live:
+        return          # (recording: the decryption of all 4096 rows needs the engine's array)
+    assert pinned.shape[0] == len(rows)
     # the same inputs at two different rows give different words (their draws differ) ...
     same = np.flatnonzero(idx == idx[0])
     assert not np.array_equal(out[same[0]], out[same[1]])
@@ -195,13 +202,15 @@ def test_dual_basis_ctx_random_mode_full_batch_4096(S, oc, p1024six):
     eng.set_random_flatten(False)
 
 
-def test_dual_basis_ctx_matches_big_integer_golden(S, oc, p1024six):
+def test_dual_basis_ctx_matches_big_integer_golden(S, oc, exp, p1024six):
     """tests/golden/p1024rnd.json, made by the literal big-integer restatement: accumulator hashes
     after 1, 2, 512 and 1024 iterations, raw and ModRed output hashes of the randomised bootstrap at
     Params(1024), as bootstrap 0 of call 0 and as bootstrap 5 of call 2 of the stream."""
     path = os.path.join(G, "p1024rnd.json")
     if not os.path.exists(path):
         pytest.skip("golden/p1024rnd.json not generated")
+    if not exp.live:
+        pytest.skip("engine against a committed fixture: nothing to record")
     d = json.load(open(path))
     params, o, sk, khat, eng = p1024six
     assert str(params.Q) == d["params"]["Q"] and d["key_seed"] == 22 and d["sk_seed"] == 21
@@ -237,7 +246,7 @@ def test_dual_basis_ctx_matches_big_integer_golden(S, oc, p1024six):
 # ---- 2. soak on distinct inputs, every full-size configuration ----------------------------------------
 
 @pytest.mark.parametrize("name,count", [("params1024", 64), ("params512", 256), ("synth64", 32), ("rns2", 16)])
-def test_soak_distinct_inputs_vs_oracle(S, oc, name, count):
+def test_soak_distinct_inputs_vs_oracle(S, oc, exp, name, count):
     """test/api.test.jl:45-83 widened: `count` DISTINCT bootstraps (uniformly random LWE words, so
     every rotation amount occurs, plus encryptions of all four bit pairs) tiled to a full batch so
     that the default schedule (two lanes of full chunks) runs; every output word of every copy
@@ -255,28 +264,30 @@ def test_soak_distinct_inputs_vs_oracle(S, oc, name, count):
         o = oc.Oracle.from_params(p)
     sk = o.private_key(31)
     valid = name in ("params1024", "params512", "rns2")      # synth64 has no noise budget
-    eng = S.Engine(p)
+    eng = exp.engine(S, p)
     if valid:
-        bkey = o.bootstrap_key(sk, 32, threads=T)
         eng.generate_key(sk, 32)
+        bkey = exp.lazy(lambda: o.bootstrap_key(sk, 32, threads=T))
     else:
-        bkey = bench.random_key(p, 32)
-        eng.upload_key(bkey)
+        rk = bench.random_key(p, 32)
+        eng.upload_key(rk)
+        bkey = exp.lazy(lambda: rk)
     bits, a1, b1, a2, b2 = _mixed_inputs(o, sk, p, count, 33)
     assert o.uses_ntt or o.uses_rns2
-    khat = o.key_transform(bkey, threads=T)       # NTT-domain loop (for rns2: limb-wise, CRT per column;
-    del bkey                                      # bit-identical to the reference-shaped loops: test_oracle_properties.py)
-    ref = o.bootstrap_batch(khat, a1, b1, a2, b2, threads=T, opt=True)
+    # NTT-domain loop (for rns2: limb-wise, CRT per column; bit-identical to the reference-shaped loops:
+    # test_oracle_properties.py)
+    khat = exp.lazy(lambda: o.key_transform(bkey(), threads=T))
     full = 4096 if name != "params512" else 1024             # BASELINE.json's batch of each configuration
     idx = np.random.default_rng(35).permutation(np.resize(np.arange(count), full))
-    out = eng.bootstrap_batch(a1[idx], b1[idx], a2[idx], b2[idx])
+    out = exp.check("r4.soak.%s.det" % name, eng.bootstrap_batch(a1[idx], b1[idx], a2[idx], b2[idx]),
+                    lambda: o.bootstrap_batch(khat(), a1, b1, a2, b2, threads=T, opt=True)[idx])
     assert out.shape == (full, 3, p.n + 1)
-    assert np.array_equal(out, ref[idx])
     if valid:
         k = len(bits) // 2
         y1, y2 = bits[0::2], bits[1::2]
+        first = np.array([int(np.flatnonzero(idx == t)[0]) for t in range(k)])     # a copy of each encryption pair
         for g, fn in enumerate((np.bitwise_and, np.bitwise_or, np.bitwise_xor)):
-            assert np.array_equal(o.lwe_decrypt_bits(sk, ref[:k, g, :p.n], ref[:k, g, p.n]), fn(y1, y2))
+            assert np.array_equal(o.lwe_decrypt_bits(sk, out[first, g, :p.n], out[first, g, p.n]), fn(y1, y2))
     # the randomised flatten on the same ring, key and batch (Params(1024) has its own tests above): every
     # row draws at its own index in the call, so 32 rows spread over the chunks of both lanes are pinned
     # word for word to the C restatement run at those stream indices
@@ -286,12 +297,13 @@ def test_soak_distinct_inputs_vs_oracle(S, oc, name, count):
         rows = np.unique(np.concatenate([[0, full - 1], np.random.default_rng(36).choice(full, size=14 if name == "rns2" else 30,
                                                                                       replace=False)]))
         src = idx[rows]
-        ref_r = o.bootstrap_batch(khat, a1[src], b1[src], a2[src], b2[src], threads=T, opt=True,
-                                  rnd=(FKEY, 0, rows.astype(np.uint32)))
-        assert np.array_equal(out_r[rows], ref_r)
-        assert not np.array_equal(out_r[rows], out[rows])
+        pinned = exp.check("r4.soak.%s.rnd.rows" % name, out_r[rows] if exp.live else None,
+                           lambda: o.bootstrap_batch(khat(), a1[src], b1[src], a2[src], b2[src], threads=T, opt=True,
+                                                     rnd=(FKEY, 0, rows.astype(np.uint32))))
+        assert not np.array_equal(pinned, out[rows])
         eng.set_random_flatten(False)
-        assert np.array_equal(eng.bootstrap_batch(a1[idx[:8]], b1[idx[:8]], a2[idx[:8]], b2[idx[:8]]), ref[idx[:8]])
+        if exp.live:
+            assert np.array_equal(eng.bootstrap_batch(a1[idx[:8]], b1[idx[:8]], a2[idx[:8]], b2[idx[:8]]), out[:8])
     eng.close()
 
 
@@ -471,7 +483,7 @@ def test_host_staging_can_be_released(S, oc):
 # ---- the latency form at its true sizes (round 4: no padding to 8 gates, one coefficient per CRT thread) ----
 
 @pytest.mark.parametrize("ring", ["params64", "synthetic m = 256", "params512", "params1024"])
-def test_latency_form_calls_of_one_to_nine_gates(S, oc, ring):
+def test_latency_form_calls_of_one_to_nine_gates(S, oc, exp, ring):
     """A call of g gates launches g gates' workgroups (up to round 3 the small-batch grids were padded
     to a multiple of 8, so the literal drop-in call -- one gate -- did eight gates' work); up to 8
     gates the CRT kernel takes one coefficient per thread (k_crt_lean1); and for m >= 4096 calls of up
@@ -491,43 +503,56 @@ def test_latency_form_calls_of_one_to_nine_gates(S, oc, ring):
         params, noise = S.Params.custom(n, BO.find_modulus(16 * n, 1 << 50), 1 << 26), 2
     o = oc.Oracle.from_params(params)
     sk = o.private_key(7)
-    bkey = o.bootstrap_key(sk, 8, noise=noise)
-    khat = o.key_transform(bkey, threads=_threads())
-    eng = S.Engine(params)
-    eng.upload_key(bkey)
-    del bkey
-    bits, a1, b1, a2, b2 = _mixed_inputs(o, sk, params, 9, 9)
+    T = _threads()
+    # Params(1024) keeps the UPLOAD of a reference-shaped key (what julia/SGFHEHip.jl's HipBootstrapKey(bkey)
+    # does) in the suite; the other full-size ring is keyed on the device from the same seed (byte-identical)
+    big = ring in ("params512", "params1024")
+    bkey = exp.lazy(lambda: o.bootstrap_key(sk, 8, noise=noise, threads=T))
+    khat = exp.lazy(lambda: o.key_transform(bkey(), threads=T))
+    eng = exp.engine(S, params)
+    if ring == "params512":
+        eng.generate_key(sk, 8)
+    elif exp.live:
+        eng.upload_key(bkey())
+    tag = "r4.latency.%s." % ring.replace(" ", "")
     sizes = {"params512": (1, 3, 4, 5, 7, 8, 13), "params1024": (1, 7, 8)}.get(ring, (1, 2, 3, 4, 5, 8, 9))
+    bits, a1, b1, a2, b2 = _mixed_inputs(o, sk, params, max(sizes), 9)   # (round 4 made 9 rows: its "13" ran 9 gates)
+    # (an oracle row depends on its own inputs only: one run over all rows serves every size)
+    all_out = exp.lazy(lambda: o.bootstrap_batch(khat(), a1, b1, a2, b2, opt=True, threads=T))
     for g in sizes:
         sl = slice(0, g)
-        ref = o.bootstrap_batch(khat, a1[sl], b1[sl], a2[sl], b2[sl], opt=True, threads=_threads())
-        assert np.array_equal(eng.bootstrap_batch(a1[sl], b1[sl], a2[sl], b2[sl]), ref), g
-        if ring not in ("params512", "params1024") or g == 7:
-            assert np.array_equal(eng.bootstrap_batch(a1[sl], b1[sl], a2[sl], b2[sl], raw=True),
-                                  o.bootstrap_batch(khat, a1[sl], b1[sl], a2[sl], b2[sl], raw=True, opt=True)), g
+        exp.check(tag + "out%d" % g, eng.bootstrap_batch(a1[sl], b1[sl], a2[sl], b2[sl]), lambda: all_out()[sl], repr(g))
+        if not big or g == 7:
+            exp.check(tag + "raw%d" % g, eng.bootstrap_batch(a1[sl], b1[sl], a2[sl], b2[sl], raw=True),
+                      lambda: o.bootstrap_batch(khat(), a1[sl], b1[sl], a2[sl], b2[sl], raw=True, opt=True, threads=T),
+                      repr(g))
             for it in (1, 2):
-                _, acc = o.bootstrap_batch(khat, a1[sl], b1[sl], a2[sl], b2[sl], n_iters=it, want_acc=True, opt=True)
-                assert np.array_equal(eng.debug_accumulators(a1[sl], b1[sl], a2[sl], b2[sl], it), acc), (g, it)
+                exp.check(tag + "acc%d.%d" % (g, it), eng.debug_accumulators(a1[sl], b1[sl], a2[sl], b2[sl], it),
+                          lambda: o.bootstrap_batch(khat(), a1[sl], b1[sl], a2[sl], b2[sl], n_iters=it, want_acc=True,
+                                                    opt=True, threads=T)[1], repr((g, it)))
     # the randomised flatten through the same forms (the quarter form serves both modes)
     eng.set_random_flatten(True, FKEY)
     for call, g in enumerate((1, 3, 7, 9) if ring != "params1024" else (1, 7)):
         sl = slice(0, g)
-        ref = o.bootstrap_batch(khat, a1[sl], b1[sl], a2[sl], b2[sl], opt=True, threads=_threads(), rnd=(FKEY, call))
-        assert np.array_equal(eng.bootstrap_batch(a1[sl], b1[sl], a2[sl], b2[sl]), ref), ("random", g)
+        exp.check(tag + "rnd%d" % g, eng.bootstrap_batch(a1[sl], b1[sl], a2[sl], b2[sl]),
+                  lambda: o.bootstrap_batch(khat(), a1[sl], b1[sl], a2[sl], b2[sl], opt=True, threads=T,
+                                            rnd=(FKEY, call)), repr(("random", g)))
     eng.close()
-    ref = o.bootstrap_batch(khat, a1[:3], b1[:3], a2[:3], b2[:3], opt=True, threads=_threads())
     for knob in ("SGFHE_SMALL_PADDED", "SGFHE_SMALL_SPLIT", "SGFHE_SMALL_FUSED"):
         os.environ[knob] = "0" if knob == "SGFHE_SMALL_SPLIT" else "1"
         try:
-            old = S.Engine(params)
+            old = exp.engine(S, params)
         finally:
             del os.environ[knob]
-        old.generate_key(sk, 8, noise=noise) if noise is None else old.upload_key(o.bootstrap_key(sk, 8, noise=noise))
-        assert np.array_equal(old.bootstrap_batch(a1[:3], b1[:3], a2[:3], b2[:3]), ref), knob
+        if noise is None:
+            old.generate_key(sk, 8)
+        elif exp.live:
+            old.upload_key(bkey())
+        exp.check(tag + "out3", old.bootstrap_batch(a1[:3], b1[:3], a2[:3], b2[:3]), lambda: all_out()[:3], knob)
         old.close()
 
 
-def test_latency_form_boundaries_at_params512(S, oc):
+def test_latency_form_boundaries_at_params512(S, oc, exp):
     """The call sizes at which the engine changes its form of the k-loop, Params(512) (m = 4096: every latency
     form exists), both flatten modes, every output word against the C restatement: 6 gates (the last size of
     the two-launch quarter form), 12 (the largest single chain of k_ext_quarter launches on five primes), 14
@@ -537,23 +562,23 @@ def test_latency_form_boundaries_at_params512(S, oc):
     params = S.Params(512)
     o = oc.Oracle.from_params(params)
     sk = o.private_key(31)
-    bkey = o.bootstrap_key(sk, 32)
-    khat = o.key_transform(bkey, threads=_threads())
-    eng = S.Engine(params)
-    eng.upload_key(bkey)
-    del bkey
+    T = _threads()
+    khat = exp.lazy(lambda: o.key_transform(o.bootstrap_key(sk, 32, threads=T), threads=T))
+    eng = exp.engine(S, params)
+    eng.generate_key(sk, 32)
     bits, a1, b1, a2, b2 = _mixed_inputs(o, sk, params, 25, 33)
+    all_out = exp.lazy(lambda: o.bootstrap_batch(khat(), a1, b1, a2, b2, opt=True, threads=T))
     for g in (6, 12, 14, 24, 25):
         sl = slice(25 - g, 25)                       # the tail: other rows than the sizes before
-        ref = o.bootstrap_batch(khat, a1[sl], b1[sl], a2[sl], b2[sl], opt=True, threads=_threads())
-        assert np.array_equal(eng.bootstrap_batch(a1[sl], b1[sl], a2[sl], b2[sl]), ref), g
+        out = exp.check("r4.bound512.out%d" % g, eng.bootstrap_batch(a1[sl], b1[sl], a2[sl], b2[sl]),
+                        lambda: all_out()[sl], repr(g))
     y1, y2 = bits[0::2], bits[1::2]
-    out = eng.bootstrap_batch(a1, b1, a2, b2)
-    dec = o.lwe_decrypt_bits(sk, out[:len(y1), 2, :params.n], out[:len(y1), 2, params.n])
+    dec = o.lwe_decrypt_bits(sk, out[:len(y1), 2, :params.n], out[:len(y1), 2, params.n])     # g = 25: all rows
     assert np.array_equal(dec, y1 ^ y2)
     eng.set_random_flatten(True, FKEY)
     for call, g in enumerate((10, 11, 13, 24, 25)):
         sl = slice(0, g)
-        ref = o.bootstrap_batch(khat, a1[sl], b1[sl], a2[sl], b2[sl], opt=True, threads=_threads(), rnd=(FKEY, call))
-        assert np.array_equal(eng.bootstrap_batch(a1[sl], b1[sl], a2[sl], b2[sl]), ref), ("random", g)
+        exp.check("r4.bound512.rnd%d" % g, eng.bootstrap_batch(a1[sl], b1[sl], a2[sl], b2[sl]),
+                  lambda: o.bootstrap_batch(khat(), a1[sl], b1[sl], a2[sl], b2[sl], opt=True, threads=T,
+                                            rnd=(FKEY, call)), repr(("random", g)))
     eng.close()

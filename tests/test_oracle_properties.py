@@ -414,6 +414,38 @@ def test_pack_small_ring_c_equals_bigint(oc):
     assert BO.decrypt_ciphertext(p, skl, pw, pv) == [int(x) for x in bits]
 
 
+def test_pack_c_randomised_and_ntt_domain_equal_bigint(oc):
+    """Round 5: the C restatement's pack_encrypted_bits(bkey, rng, ...) (src/fhe.jl:660-696 with the
+    randomised flatten of src/utils.jl:198-241 in the n bootstraps, fhe.jl:673, and in the flatten of every
+    as_i, fhe.jl:683-684) on the engine's ChaCha8 stream equals the big-integer restatement for two
+    ciphertext positions of a call; and its NTT-domain form (khat) gives the bytes of the reference-shaped
+    one in both modes.  This is what makes full-size packing fixtures affordable (tests/golden/pack512.json)."""
+    n, m = 8, 64
+    Q = BO.find_modulus(2 * m, 1 << 50)
+    p = BO.Params.custom(n, Q, 1 << 26)
+    o = oc.Oracle.from_params(p)
+    sk = o.private_key(7)
+    bkey = o.bootstrap_key(sk, 8, noise=2)
+    khat = o.key_transform(bkey)
+    bits = np.array([1, 0, 0, 1, 1, 1, 0, 1], dtype=np.uint8)
+    a, b = o.lwe_encrypt_bits(sk, bits, 9)
+    vals = oc.u128_to_ints(bkey)
+    bk = [[[vals[((k * 4 + r) * 2 + c) * m:((k * 4 + r) * 2 + c + 1) * m] for c in range(2)]
+           for r in range(4)] for k in range(n)]
+    lwes = [([int(x) for x in a[i]], int(b[i])) for i in range(n)]
+    det = o.pack_encrypted_bits(bkey, a, b)
+    det_opt = o.pack_encrypted_bits(bkey, a, b, khat=khat)
+    assert np.array_equal(det[0], det_opt[0]) and np.array_equal(det[1], det_opt[1])
+    key32 = bytes(range(3, 35))
+    for ct, call in ((0, 0), (2, 5)):
+        pw, pv = BO.pack_encrypted_bits(p, bk, lwes, seed=key32, ct=ct, call=call)
+        for kh in (None, khat):
+            w, v = o.pack_encrypted_bits(bkey, a, b, khat=kh, rnd=(key32, ct, call))
+            assert [int(x) for x in w] == pw and [int(x) for x in v] == pv
+        assert not np.array_equal(w, det[0])
+        assert BO.decrypt_ciphertext(p, [int(x) for x in sk], pw, pv) == [int(x) for x in bits]
+
+
 # ---- the C restatement of the randomised flatten (round 4) against the big-integer one --------------
 
 @pytest.mark.parametrize("B", [4, 5, 6, 7])
