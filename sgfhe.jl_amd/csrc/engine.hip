@@ -15,6 +15,7 @@
 #include <mutex>
 #include <string>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 
 #include "kernels.h"
@@ -86,6 +87,7 @@ double u128_dbl(u128 x) { return (double)(uint64_t)(x >> 64) * 18446744073709551
 // bootstrap; tests/test_gpu_golden.py batch-position test), so every caller gets the bytes of its call made alone.
 struct Coalescer {
     struct Req {
+        const void *owner;       // the ctx the request came in on
         const uint64_t *a1, *b1, *a2, *b2;
         size_t batch;
         uint64_t *out;
@@ -98,7 +100,12 @@ struct Coalescer {
     std::condition_variable cv;
     std::deque<Req *> pending;
     bool running = false;        // a leader is running a combined call
-    size_t last_reqs = 0;        // requests in the previous combined call: how many callers to expect back
+    // which ctxs had a request served in which round: the callers of the last two rounds are the ones a leader
+    // expects back (with eight callers, half of them are still on their way back from the previous round when the
+    // other half -- who waited through it -- could already start: two alternating rounds of four, at 3.5 x one
+    // caller's rate, where one round of eight gives 5.8 x)
+    uint64_t round = 0;
+    std::unordered_map<const void *, uint64_t> seen;
     // knobs (sgfhe_set_coalesce): on / off, largest request that is gathered, gates per combined call, how long a
     // leader waits for the callers of the previous round to come back
     bool enabled = true;
@@ -1813,6 +1820,10 @@ int32_t sgfhe_ctx_destroy(sgfhe_ctx *c) {
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
+    if (c->shared) {     // the coalescer no longer expects this caller back
+        std::lock_guard<std::mutex> lk(c->shared->co.mu);
+        c->shared->co.seen.erase(c);
+    }
     c->shared.reset();   // constants, tables and key: freed with the last ctx that shares them
     if (c->io_in) (void)hipFree(c->io_in);
     if (c->io_out) (void)hipFree(c->io_out);
@@ -2289,6 +2300,7 @@ static int32_t coalesced_call(sgfhe_ctx *c, const uint64_t *a1, const uint64_t *
                               const uint64_t *b2, size_t batch, uint64_t *out, uint32_t flags) {
     Coalescer &co = c->shared->co;
     Coalescer::Req me;
+    me.owner = c;
     me.a1 = a1; me.b1 = b1; me.a2 = a2; me.b2 = b2;
     me.batch = batch; me.out = out; me.flags = flags;
     std::vector<Coalescer::Req *> take;
@@ -2306,12 +2318,17 @@ static int32_t coalesced_call(sgfhe_ctx *c, const uint64_t *a1, const uint64_t *
             co.cv.wait(lk);
         }
         co.running = true;
-        // The callers of the previous round are about to come back (they got their results microseconds ago):
-        // wait for as many requests as that round had, a few hundred microseconds at most.  A caller on its own
-        // (previous round: one request) never waits.
-        if (co.last_reqs > 1 && co.window_us) {
+        // The callers of the last two rounds are about to come back (they got their results microseconds ago):
+        // wait until as many requests are here as there were callers, a few hundred microseconds at most.  A
+        // caller on its own never waits.
+        if (co.window_us) {
+            size_t expect = 1;                                     // the leader itself
+            for (auto it = co.seen.begin(); it != co.seen.end();) {
+                if (it->first != c && it->second + 2 > co.round) expect++;
+                if (it->second + 64 <= co.round) it = co.seen.erase(it); else ++it;     // long gone
+            }
             const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(co.window_us);
-            while (co.pending.size() < co.last_reqs && co.cv.wait_until(lk, deadline) != std::cv_status::timeout) {}
+            while (co.pending.size() < expect && co.cv.wait_until(lk, deadline) != std::cv_status::timeout) {}
         }
         for (auto it = co.pending.begin(); it != co.pending.end();) {
             if ((*it)->flags == me.flags && (take.empty() || gates + (*it)->batch <= co.gates_max)) {
@@ -2359,12 +2376,13 @@ static int32_t coalesced_call(sgfhe_ctx *c, const uint64_t *a1, const uint64_t *
             q->rc = rc;
             if (rc) q->err = c->err;
             q->done = true;
+            co.seen[q->owner] = co.round;
         }
+        co.round++;
         co.n_calls++;
         co.n_reqs += take.size();
         co.n_gates += gates;
         if (take.size() > co.max_reqs) co.max_reqs = take.size();
-        co.last_reqs = take.size();
         co.running = false;
         co.cv.notify_all();
     }

@@ -216,7 +216,7 @@ def _julia_case(oc, d, key):
     return o
 
 
-@pytest.mark.parametrize("n", [64, 512])
+@pytest.mark.parametrize("n", [64, 512, 1024])
 def test_julia_reference_fixture(oc, n):
     """tests/golden/julia_p<n>.json + its key file, written by sgfhe.jl_amd/julia/make_fixtures.jl under
     Julia with the reference installed: bootstrap(bkey, nothing, ...) and _bootstrap_internal outputs of
@@ -253,3 +253,59 @@ def test_julia_fixture_reader_on_a_self_made_file(oc, tmp_path):
     with pytest.raises(AssertionError):
         _julia_case(oc, d, key)
     assert JF.load(str(tmp_path), 512) is None
+
+
+# ---- round 5: the full-size fixtures made by the C restatement (tests/golden/make_golden_c.py) --------------------
+
+@pytest.mark.parametrize("name", ["p128rnd", "p256rnd"])
+def test_round5_bootstrap_fixtures_reproduce(oc, name):
+    """tests/golden/p128rnd.json / p256rnd.json (complete bootstraps in both flatten modes, committed as digests):
+    the C restatement gives them again from the seeds, through BOTH of its loops (the reference-shaped one, 24 NTT
+    products per iteration, and the NTT-domain one that made the file).  The Params(2048) and packing fixtures of
+    the same generator take minutes to an hour and are reproduced in the build container only."""
+    import sys
+    sys.path.insert(0, G)
+    import make_golden_c as MG
+    path = os.path.join(G, name + ".json")
+    if not os.path.exists(path):
+        pytest.skip("not generated")
+    d = json.load(open(path))
+    n, rows = d["n"], d["rows"]
+    o = oc.Oracle.make(n)
+    sk = o.private_key(d["sk_seed"])
+    bkey = o.bootstrap_key(sk, d["key_seed"])
+    khat = o.key_transform(bkey)
+    a1, b1, a2, b2, bits = MG.mixed_inputs(o, sk, n, rows, d["in_seed"])
+    assert [int(x) for x in bits] == d["bits"]
+    fkey = bytes.fromhex(d["flatten_key_hex"])
+    for mode, rnd in (("det", None), ("rnd", (fkey, d["call"]))):
+        for key, opt in ((bkey, False), (khat, True)):
+            out = o.bootstrap_batch(key, a1, b1, a2, b2, opt=opt, rnd=rnd)
+            assert [MG.sha_words(out[t]) for t in range(rows)] == d[mode]["out_sha256"], (mode, opt)
+            assert [MG.head(out[t]) for t in range(rows)] == d[mode]["out_head"]
+        raw = o.bootstrap_batch(khat, a1, b1, a2, b2, raw=True, opt=True, rnd=rnd)
+        assert [MG.sha_words(raw[t]) for t in range(rows)] == d[mode]["raw_sha256"]
+        for it, want in d[mode]["acc_sha256_after"].items():
+            _, acc = o.bootstrap_batch(khat, a1, b1, a2, b2, n_iters=int(it), want_acc=True, opt=True, rnd=rnd)
+            assert [MG.sha_words(acc[t]) for t in range(rows)] == want
+
+
+def test_round5_fixture_files_are_well_formed():
+    """pack512 / pack1024 / p2048: seeds, the flatten key and SHA-256 digests of the right shape; the deterministic
+    and randomised results differ, and so do the two ciphertexts of the randomised call."""
+    for name in ("pack512", "pack1024"):
+        path = os.path.join(G, name + ".json")
+        if not os.path.exists(path):
+            continue
+        d = json.load(open(path))
+        assert d["n"] == int(name[4:]) and len(bytes.fromhex(d["flatten_key_hex"])) == 32 and d["call"] == 0
+        digs = [d["det"]] + d["rnd"]
+        assert len(d["rnd"]) == 2 and all(len(x["w_sha256"]) == 64 and len(x["v_sha256"]) == 64 and len(x["w_head"]) == 8 for x in digs)
+        assert len({x["w_sha256"] for x in digs}) == 3 and len({x["v_sha256"] for x in digs}) == 3
+    path = os.path.join(G, "p2048.json")
+    if os.path.exists(path):
+        d = json.load(open(path))
+        assert d["n"] == 2048 and d["rows"] == 6 and set(d["det"]["acc_sha256_after"]) == {"1", "2"}
+        for mode in ("det", "rnd"):
+            assert len(d[mode]["out_sha256"]) == 6 and len(set(d[mode]["out_sha256"])) == 6
+        assert d["det"]["raw_sha256"] != d["rnd"]["raw_sha256"]

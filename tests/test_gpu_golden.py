@@ -594,7 +594,7 @@ def _engine_julia_case(S, oc, d, key):
         eng.close()
 
 
-@pytest.mark.parametrize("n", [64, 512])
+@pytest.mark.parametrize("n", [64, 512, 1024])
 def test_engine_matches_julia_reference_fixture(S, oc, n):
     """The HIP engine against bootstrap(bkey, nothing, ...) / _bootstrap_internal of the Julia
     reference itself, on the reference's own key (tests/golden/julia_p<n>.json, written by
