@@ -137,10 +137,12 @@ int32_t sgfhe_ctx_clone(sgfhe_ctx *ctx, sgfhe_ctx **out);
  * each driven by its own host thread -- are run as ONE call: the caller that finds no combined call in flight takes
  * every request waiting (up to `gates_max` gates, default 256), runs them as one batch on its own ctx and hands each
  * caller its rows; callers arriving meanwhile form the next round, whose leader waits up to `window_us` (default 300)
- * for as many callers as the previous round had.  A caller on its own never waits, and a ctx without clones is not
- * affected at all.  Deterministic flatten only (every clone has its own draw stream): a row of the result does not
- * depend on the rows beside it, so every caller gets the bytes its call gives alone.  The asynchronous entry point
- * (sgfhe_bootstrap_batch_device) is never gathered.
+ * for as many callers as the last two rounds had.  A caller on its own never waits, and a ctx without clones is not
+ * affected at all.  A row of the result does not depend on the rows beside it, so every caller gets the bytes its
+ * call gives alone -- with the randomised flatten too: every row of a gathered call draws from the stream of the ctx
+ * it came in on (that ctx's key, the number of its call, the row's index in its call), and deterministic and
+ * randomised requests form separate rounds.  The asynchronous entry point (sgfhe_bootstrap_batch_device) and
+ * sgfhe_pack_encrypted_bits are never gathered.
  * The setting belongs to the shared key: it applies to every ctx that shares it.  enable = 0 switches gathering off
  * (SGFHE_COALESCE=0 in the environment does the same at ctx creation); the other arguments are then ignored.
  * sgfhe_coalesce_stats: stats[4] = {combined calls run, requests served, gates, most requests in one call}.

@@ -83,8 +83,11 @@ double u128_dbl(u128 x) { return (double)(uint64_t)(x >> 64) * 18446744073709551
 // calls that arrive together on ctxs sharing a key (sgfhe_ctx_clone) are run as one call: the caller that finds no
 // combined call in flight leads -- it takes every request waiting, runs them as one batch on ITS OWN ctx (its lock,
 // lanes and streams) and hands each caller its rows -- and callers that arrive meanwhile wait for the next round.
-// Deterministic flatten only: a row's result does not depend on the rows beside it (src/fhe.jl:579-582 is per
-// bootstrap; tests/test_gpu_golden.py batch-position test), so every caller gets the bytes of its call made alone.
+// A row's result does not depend on the rows beside it (src/fhe.jl:579-582 is per bootstrap; tests/test_gpu_golden.py
+// batch-position test), so every caller gets the bytes of its call made alone -- in the randomised flatten too:
+// there every row of the combined call draws from the stream of the ctx it came in on (that ctx's key, the number
+// of its call, the row's index in its call: kernels.h RndRow), and deterministic and randomised requests form
+// separate rounds.
 struct Coalescer {
     struct Req {
         const void *owner;       // the ctx the request came in on
@@ -92,6 +95,9 @@ struct Coalescer {
         size_t batch;
         uint64_t *out;
         uint32_t flags;
+        bool rnd = false;        // randomised flatten: the request's own draw stream (key, number of the call)
+        ChaChaKey key;
+        uint32_t call = 0;
         int32_t rc = 0;
         bool done = false;
         std::string err;
@@ -216,6 +222,11 @@ struct sgfhe_ctx {
     bool rnd = false, rnd_ok = false;
     ChaChaKey rnd_key = {};   // 32-byte key of the draw stream (sgfhe_set_random_flatten[_key])
     uint32_t rnd_call = 0, last_call = 0;
+    int64_t call_fixed = -1;              // the number of the next call, when the coalescer has already assigned it
+    const RndRow *gather_rows = nullptr;  // set around a gathered randomised call this ctx leads: d_rows
+    RndRow *d_rows = nullptr;             // per-row draw streams of such a call (device), for up to rows_cap rows
+    size_t rows_cap = 0;
+    std::vector<RndRow> h_rows;
     uint32_t create_flags = 0;
     // RNS2Number form of Z_Q (src/rns.jl): set by sgfhe_bkey_upload_rns2 / sgfhe_rns2_convert
     bool have_rns2 = false;
@@ -635,21 +646,26 @@ void launch_crt_lean_t(sgfhe_ctx *c, const uint32_t *yres, uint64_t *dig, uint32
 template <int NP, bool WIDE>
 void launch_crt_lean_rnd_t(sgfhe_ctx *c, const uint32_t *yres, uint64_t *dig, uint32_t total, hipStream_t st,
                            RndArgs ra, uint32_t iter) {
+    // ROWS: a gathered call, every row on the draw stream of the ctx it came in on (kernels.h RndRow)
+#define SGFHE_RND1(NL, ROWS) hipLaunchKernelGGL((k_crt_lean_rnd1<NP, NL, false, ROWS>), grid1, block1, 0, st, yres, dig, c->d_lean, total, (uint32_t)c->logm, ra, iter, (const PrimeK *)nullptr)
+#define SGFHE_RND4(NL, ROWS) hipLaunchKernelGGL((k_crt_lean_rnd<NP, NL, WIDE, ROWS>), grid, block, 0, st, yres, dig, c->d_lean, total / 4, (uint32_t)c->logm, ra, iter)
     if (!WIDE && total <= c->crt1_max) {   // the latency form: one coefficient per thread
         const dim3 grid1((total + 255) / 256), block1(256);
         switch (c->h_lean.nl) {
-        case 2: hipLaunchKernelGGL((k_crt_lean_rnd1<NP, 2, false>), grid1, block1, 0, st, yres, dig, c->d_lean, total, (uint32_t)c->logm, ra, iter, (const PrimeK *)nullptr); break;
-        case 3: hipLaunchKernelGGL((k_crt_lean_rnd1<NP, 3, false>), grid1, block1, 0, st, yres, dig, c->d_lean, total, (uint32_t)c->logm, ra, iter, (const PrimeK *)nullptr); break;
-        default: hipLaunchKernelGGL((k_crt_lean_rnd1<NP, 4, false>), grid1, block1, 0, st, yres, dig, c->d_lean, total, (uint32_t)c->logm, ra, iter, (const PrimeK *)nullptr); break;
+        case 2: if (ra.rows) SGFHE_RND1(2, true); else SGFHE_RND1(2, false); break;
+        case 3: if (ra.rows) SGFHE_RND1(3, true); else SGFHE_RND1(3, false); break;
+        default: if (ra.rows) SGFHE_RND1(4, true); else SGFHE_RND1(4, false); break;
         }
         return;
     }
     const dim3 grid((total / 4 + 255) / 256), block(256);
     switch (c->h_lean.nl) {
-    case 2: hipLaunchKernelGGL((k_crt_lean_rnd<NP, 2, WIDE>), grid, block, 0, st, yres, dig, c->d_lean, total / 4, (uint32_t)c->logm, ra, iter); break;
-    case 3: hipLaunchKernelGGL((k_crt_lean_rnd<NP, 3, WIDE>), grid, block, 0, st, yres, dig, c->d_lean, total / 4, (uint32_t)c->logm, ra, iter); break;
-    default: hipLaunchKernelGGL((k_crt_lean_rnd<NP, 4, WIDE>), grid, block, 0, st, yres, dig, c->d_lean, total / 4, (uint32_t)c->logm, ra, iter); break;
+    case 2: if (ra.rows) SGFHE_RND4(2, true); else SGFHE_RND4(2, false); break;
+    case 3: if (ra.rows) SGFHE_RND4(3, true); else SGFHE_RND4(3, false); break;
+    default: if (ra.rows) SGFHE_RND4(4, true); else SGFHE_RND4(4, false); break;
     }
+#undef SGFHE_RND1
+#undef SGFHE_RND4
 }
 int32_t launch_crt_raw(sgfhe_ctx *c, const uint32_t *yres, uint64_t *dig, uint32_t total,
                        uint32_t mode, hipStream_t st, RndArgs ra, uint32_t iter) {
@@ -671,8 +687,11 @@ int32_t launch_crt_raw(sgfhe_ctx *c, const uint32_t *yres, uint64_t *dig, uint32
         else if (mode == 0u) /* two coefficients per thread */                                   \
             hipLaunchKernelGGL(k_crt_acc2<NP>, dim3((total / 2 + 255) / 256), dim3(256), 0, st,   \
                                yres, dig, c->d_crt, total / 2, (uint32_t)c->logm);                \
+        else if (ra.rows)                                                                         \
+            hipLaunchKernelGGL((k_crt_acc<NP, true>), dim3((total + 255) / 256), dim3(256), 0, st, yres, \
+                               dig, c->d_crt, total, (uint32_t)c->logm, mode, ra, iter);          \
         else                                                                                      \
-            hipLaunchKernelGGL(k_crt_acc<NP>, dim3((total + 255) / 256), dim3(256), 0, st, yres,  \
+            hipLaunchKernelGGL((k_crt_acc<NP, false>), dim3((total + 255) / 256), dim3(256), 0, st, yres, \
                                dig, c->d_crt, total, (uint32_t)c->logm, mode, ra, iter);          \
         break;
         SGFHE_FOR_NPR(X)
@@ -694,19 +713,21 @@ int32_t launch_crt_quarter(sgfhe_ctx *c, const sgfhe_ctx::Lane &L, uint32_t cnt,
     const dim3 grid((total + 255) / 256), block(256);
     const int32_t *yp = reinterpret_cast<const int32_t *>(L.yres);
     if (mode & MODE_RANDOM) {   // the randomised flatten: one coefficient per thread here too (k_crt_lean_rnd1)
+#define SGFHE_RNDQ(NPQ, NL, ROWS) hipLaunchKernelGGL((k_crt_lean_rnd1<NPQ, NL, true, ROWS>), grid, block, 0, st, L.yres, L.dig, c->d_lean, total, (uint32_t)c->logm, ra, iter, c->d_primes)
         switch (c->npr) {
 #define X(NP)                                                                                                     \
         case NP:                                                                                                  \
             switch (c->h_lean.nl) {                                                                               \
-            case 2: hipLaunchKernelGGL((k_crt_lean_rnd1<NP, 2, true>), grid, block, 0, st, L.yres, L.dig, c->d_lean, total, (uint32_t)c->logm, ra, iter, c->d_primes); break; \
-            case 3: hipLaunchKernelGGL((k_crt_lean_rnd1<NP, 3, true>), grid, block, 0, st, L.yres, L.dig, c->d_lean, total, (uint32_t)c->logm, ra, iter, c->d_primes); break; \
-            default: hipLaunchKernelGGL((k_crt_lean_rnd1<NP, 4, true>), grid, block, 0, st, L.yres, L.dig, c->d_lean, total, (uint32_t)c->logm, ra, iter, c->d_primes); break; \
+            case 2: if (ra.rows) SGFHE_RNDQ(NP, 2, true); else SGFHE_RNDQ(NP, 2, false); break;                          \
+            case 3: if (ra.rows) SGFHE_RNDQ(NP, 3, true); else SGFHE_RNDQ(NP, 3, false); break;                          \
+            default: if (ra.rows) SGFHE_RNDQ(NP, 4, true); else SGFHE_RNDQ(NP, 4, false); break;                         \
             }                                                                                                     \
             break;
             SGFHE_FOR_NPR(X)
 #undef X
         default: return fail(c, SGFHE_ERR_UNSUPPORTED, "unsupported number of RNS primes");
         }
+#undef SGFHE_RNDQ
         HIPCHK(c, hipGetLastError());
         return SGFHE_OK;
     }
@@ -957,7 +978,14 @@ int32_t bootstrap_device(sgfhe_ctx *c, const uint64_t *a1, const uint64_t *b1, c
             return fail(c, SGFHE_ERR_INVALID_ARG, "SGFHE_FLAG_RAW_RNS2: no RNS2 moduli (upload the key with sgfhe_bkey_upload_rns2)");
     }
     const bool two_lanes = c->lanes == 2 && batch > chunk;
-    const uint32_t call = c->rnd ? c->rnd_call++ : 0u;
+    // (the call number of the draw stream: this ctx's counter -- unless the call was numbered when it was handed
+    //  to the coalescer, or is a gathered call, whose rows carry their own numbers: kernels.h RndRow)
+    uint32_t call = 0u;
+    if (c->rnd) {
+        if (c->gather_rows) call = 0u;
+        else if (c->call_fixed >= 0) { call = (uint32_t)c->call_fixed; c->call_fixed = -1; }
+        else call = c->rnd_call++;
+    }
     c->last_call = call;
     {   // work buffers for the largest chunk of this call, before anything of it is queued
         const uint32_t first = (uint32_t)(batch < chunk ? batch : chunk);
@@ -1067,7 +1095,7 @@ int32_t bootstrap_device(sgfhe_ctx *c, const uint64_t *a1, const uint64_t *b1, c
             J.cb = (uint32_t)((batch - c0 < chunk) ? batch - c0 : chunk);
             J.cpad = round_up8(J.cb);
             J.c0 = c0;
-            J.ra = RndArgs{c->rnd_key, call, (uint32_t)c0};
+            J.ra = RndArgs{c->rnd_key, call, (uint32_t)c0, c->gather_rows};
             J.sampled = li == 0 && J.cpad == c->last_chunk;
             const uint64_t *ja1 = a1 + c0 * n, *jb1 = b1 + c0, *ja2 = a2 + c0 * n, *jb2 = b2 + c0;
             if (hp_single) {   // whole-call layout [a1 | a2 | b1 | b2], uploaded above
@@ -1093,8 +1121,12 @@ int32_t bootstrap_device(sgfhe_ctx *c, const uint64_t *a1, const uint64_t *b1, c
                 ja1 = di; ja2 = di + cb * n; jb1 = di + 2 * cb * n; jb2 = jb1 + cb;
             }
             const uint32_t tot = J.cpad * M;
-            hipLaunchKernelGGL(k_init, dim3((tot + 255) / 256), dim3(256), 0, J.st, ja1, jb1, ja2, jb2,
-                               J.L->dig, J.L->ua, c->d_crt, J.cb, J.cpad, n, (uint32_t)c->logm, mode, J.ra);
+            if (J.ra.rows)
+                hipLaunchKernelGGL(k_init<true>, dim3((tot + 255) / 256), dim3(256), 0, J.st, ja1, jb1, ja2, jb2,
+                                   J.L->dig, J.L->ua, c->d_crt, J.cb, J.cpad, n, (uint32_t)c->logm, mode, J.ra);
+            else
+                hipLaunchKernelGGL(k_init<false>, dim3((tot + 255) / 256), dim3(256), 0, J.st, ja1, jb1, ja2, jb2,
+                                   J.L->dig, J.L->ua, c->d_crt, J.cb, J.cpad, n, (uint32_t)c->logm, mode, J.ra);
             HIPCHK(c, hipGetLastError());
         }
         if (dbg_io && g0 == 0) tw_first = wall();
@@ -1830,6 +1862,7 @@ int32_t sgfhe_ctx_destroy(sgfhe_ctx *c) {
     if (c->pin_in) (void)hipHostFree(c->pin_in);
     if (c->pin_out) (void)hipHostFree(c->pin_out);
     if (c->d_bad) (void)hipFree(c->d_bad);
+    if (c->d_rows) (void)hipFree(c->d_rows);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return SGFHE_OK;
@@ -2303,6 +2336,12 @@ static int32_t coalesced_call(sgfhe_ctx *c, const uint64_t *a1, const uint64_t *
     me.owner = c;
     me.a1 = a1; me.b1 = b1; me.a2 = a2; me.b2 = b2;
     me.batch = batch; me.out = out; me.flags = flags;
+    if (c->rnd) {               // its draw stream: this ctx's key, and the number this call has on this ctx
+        me.rnd = true;
+        me.key = c->rnd_key;
+        me.call = c->rnd_call++;
+        c->last_call = me.call;
+    }
     std::vector<Coalescer::Req *> take;
     size_t gates = 0;
     {
@@ -2331,7 +2370,7 @@ static int32_t coalesced_call(sgfhe_ctx *c, const uint64_t *a1, const uint64_t *
             while (co.pending.size() < expect && co.cv.wait_until(lk, deadline) != std::cv_status::timeout) {}
         }
         for (auto it = co.pending.begin(); it != co.pending.end();) {
-            if ((*it)->flags == me.flags && (take.empty() || gates + (*it)->batch <= co.gates_max)) {
+            if ((*it)->flags == me.flags && (*it)->rnd == me.rnd && (take.empty() || gates + (*it)->batch <= co.gates_max)) {
                 take.push_back(*it);
                 gates += (*it)->batch;
                 it = co.pending.erase(it);
@@ -2345,9 +2384,33 @@ static int32_t coalesced_call(sgfhe_ctx *c, const uint64_t *a1, const uint64_t *
     const size_t n = c->n;
     const size_t row = 3 * (n + 1) * ((flags & SGFHE_FLAG_RAW_MODQ) ? 2 : 1);
     if (take.size() == 1) {
+        if (me.rnd) c->call_fixed = me.call;            // (numbered above)
         rc = bootstrap_host(c, a1, b1, a2, b2, batch, out, flags, c->n, nullptr);
+        c->call_fixed = -1;
     } else {
         try {
+            if (me.rnd) {   // the draw stream of every row of the combined call, on the device before its first kernel
+                (void)hipSetDevice(c->device);
+                rc = drain(c);
+                if (rc == SGFHE_OK && gates > c->rows_cap) {
+                    if (c->d_rows) (void)hipFree(c->d_rows);
+                    c->d_rows = nullptr;
+                    c->rows_cap = 0;
+                    if (hipMalloc(&c->d_rows, co.gates_max * sizeof(RndRow)) != hipSuccess)
+                        rc = fail(c, SGFHE_ERR_OOM, "hipMalloc of the gathered call's draw-stream table failed");
+                    else
+                        c->rows_cap = co.gates_max;
+                }
+                if (rc == SGFHE_OK) {
+                    c->h_rows.clear();
+                    for (const Coalescer::Req *q : take)
+                        for (size_t t = 0; t < q->batch; t++) c->h_rows.push_back(RndRow{q->key, q->call, (uint32_t)t});
+                    if (hipMemcpy(c->d_rows, c->h_rows.data(), gates * sizeof(RndRow), hipMemcpyHostToDevice) != hipSuccess)
+                        rc = fail(c, SGFHE_ERR_HIP, "copy of the gathered call's draw-stream table failed");
+                }
+                if (rc) throw rc;
+                c->gather_rows = c->d_rows;
+            }
             std::vector<uint64_t> &g = c->co_buf;                          // [a1 | a2 | b1 | b2 | out] of all requests
             g.resize(gates * (2 * n + 2 + row));
             uint64_t *ga1 = g.data(), *ga2 = ga1 + gates * n, *gb1 = ga2 + gates * n, *gb2 = gb1 + gates, *gout = gb2 + gates;
@@ -2360,15 +2423,19 @@ static int32_t coalesced_call(sgfhe_ctx *c, const uint64_t *a1, const uint64_t *
                 r0 += q->batch;
             }
             rc = bootstrap_host(c, ga1, gb1, ga2, gb2, gates, gout, flags, c->n, nullptr);
+            c->gather_rows = nullptr;
             r0 = 0;
             if (rc == SGFHE_OK)
                 for (const Coalescer::Req *q : take) {
                     memcpy(q->out, gout + r0 * row, q->batch * row * 8);
                     r0 += q->batch;
                 }
+        } catch (int32_t e) {
+            rc = e;                                     // (message already on the ctx)
         } catch (...) {
             rc = fail(c, SGFHE_ERR_OOM, "out of host memory");
         }
+        c->gather_rows = nullptr;
     }
     {
         std::lock_guard<std::mutex> lk(co.mu);
@@ -2397,7 +2464,7 @@ int32_t sgfhe_bootstrap_batch(sgfhe_ctx *c, const uint64_t *a1, const uint64_t *
     if (batch == 0) return SGFHE_OK;
     // small calls on a key that other ctxs share: gathered with whatever the other callers bring (Coalescer)
     const Coalescer &co = c->shared->co;
-    if (c->shared.use_count() > 1 && co.enabled && !c->rnd && c->have_key && batch <= co.req_max)
+    if (c->shared.use_count() > 1 && co.enabled && c->have_key && batch <= co.req_max)
         return coalesced_call(c, a1, b1, a2, b2, batch, out, flags);
     return bootstrap_host(c, a1, b1, a2, b2, batch, out, flags, c->n, nullptr);
 }
@@ -2598,7 +2665,7 @@ int32_t sgfhe_pack_encrypted_bits(sgfhe_ctx *c, const uint64_t *a, const uint64_
         rc = bootstrap_device(c, d_a1, d_b1, d_a2, d_b2, nb, (uint64_t *)d_raw, SGFHE_FLAG_RAW_MODQ,
                               c->n, nullptr, c->stream);
         if (rc) break;
-        const RndArgs ra = {c->rnd_key, c->last_call, 0u};
+        const RndArgs ra = {c->rnd_key, c->last_call, 0u, nullptr};
         const size_t tf = count * n * len;
         hipLaunchKernelGGL(k_pack_flatten, dim3((unsigned)((tf + 255) / 256)), dim3(256), 0, c->stream,
                            d_raw, d_pdig, c->d_crt, (uint32_t)count, (uint32_t)n, (uint32_t)c->logm,

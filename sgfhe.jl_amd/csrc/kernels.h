@@ -253,14 +253,33 @@ __device__ __forceinline__ void chacha_block(const ChaChaKey &key, uint32_t c12,
 #pragma unroll
     for (int i = 0; i < 16; i++) out[i] = x[i] + s[i];
 }
+// A call gathered from several callers (engine.hip Coalescer, round 5): every row of the batch draws from the
+// stream of the ctx it came in on -- that ctx's key, call number and the row's index in ITS call -- so that each
+// caller gets the bytes its call gives alone.  One record per row of the combined call, in device memory.
+struct RndRow {
+    ChaChaKey key;
+    uint32_t call, boot;
+};
 struct RndArgs {
     ChaChaKey key;         // 32-byte key of the draw stream
     uint32_t call, chunk;  // per-call counter, index of the chunk's first bootstrap in the call
+    const RndRow *rows;    // gathered call: the stream of every row of the call (kernels instantiated with ROWS); else null
 };
+// The stream of bootstrap `row` of the chunk: key, its index in its call (counter word z), its call number (w).
+// ROWS = false leaves the key in the kernel arguments (scalar registers), as before the table existed.
+template <bool ROWS>
+__device__ __forceinline__ void rnd_stream(const RndArgs &ra, uint32_t row, ChaChaKey &key, uint32_t &cz, uint32_t &cw) {
+    if constexpr (ROWS) {
+        const RndRow r = ra.rows[ra.chunk + row];
+        key = r.key; cz = r.boot; cw = r.call;
+    } else {
+        key = ra.key; cz = ra.chunk + row; cw = ra.call;
+    }
+}
 // the 128 bits of one coefficient (ctr.x = its index): a quarter of its quad's block
-__device__ __forceinline__ uint4 rnd128(const RndArgs &ra, uint4 ctr) {
+__device__ __forceinline__ uint4 rnd128(const ChaChaKey &key, uint4 ctr) {
     uint32_t w[16];
-    chacha_block<SGFHE_RND_ROUNDS>(ra.key, ctr.x >> 2, ctr.y, ctr.z, ctr.w, w);
+    chacha_block<SGFHE_RND_ROUNDS>(key, ctr.x >> 2, ctr.y, ctr.z, ctr.w, w);
     const uint32_t q = ctr.x & 3u;
     return make_uint4(q == 0 ? w[0] : q == 1 ? w[4] : q == 2 ? w[8] : w[12],
                       q == 0 ? w[1] : q == 1 ? w[5] : q == 2 ? w[9] : w[13],
@@ -270,9 +289,9 @@ __device__ __forceinline__ uint4 rnd128(const RndArgs &ra, uint4 ctr) {
 // Digits of the randomised flatten of acc, given xn = (acc + (s + xmax)(1 + B)) mod Q:
 //   r_i = v_i + xmax uniform in [0, 2 xmax];  x2 = (xn - r_0 - r_1 B) mod Q = a' of utils.jl:179
 //   for the shifted value;  (lo, hi) = divmod(x2, B);  e_i = (lo, hi) + r_i  ( = u_i + s + xmax ).
-__device__ __forceinline__ ulonglong2 random_digits(u128 xn, const CrtConst *CC, const RndArgs &ra,
+__device__ __forceinline__ ulonglong2 random_digits(u128 xn, const CrtConst *CC, const ChaChaKey &key,
                                                     uint4 ctr) {
-    const uint4 rv = rnd128(ra, ctr);
+    const uint4 rv = rnd128(key, ctr);
     const uint64_t span = 2 * CC->xmax + 1;
     const uint64_t r0 = (uint64_t)(((u128)(((uint64_t)rv.y << 32) | rv.x) * span) >> 64);
     const uint64_t r1 = (uint64_t)(((u128)(((uint64_t)rv.w << 32) | rv.z) * span) >> 64);
@@ -682,7 +701,7 @@ __device__ __forceinline__ U96 crt_reduce(const uint32_t (&y)[NP], const CrtCons
     return a;
 }
 
-template <int NP>
+template <int NP, bool ROWS = false>
 __global__ void __launch_bounds__(256)
 k_crt_acc(const uint32_t *__restrict__ yres, uint64_t *__restrict__ dig,
           const CrtConst *__restrict__ CC, uint32_t total, uint32_t logm, uint32_t mode,
@@ -719,8 +738,11 @@ k_crt_acc(const uint32_t *__restrict__ yres, uint64_t *__restrict__ dig,
         return;
     }
     if (mode & MODE_RANDOM) {
-        const uint4 ctr = make_uint4(((bc & 1u) << logm) + i, iter, ra.chunk + (bc >> 1), ra.call);
-        const ulonglong2 e = random_digits(((u128)a.w2 << 64) | xlo, CC, ra, ctr);
+        ChaChaKey key;
+        uint32_t cz, cw;
+        rnd_stream<ROWS>(ra, bc >> 1, key, cz, cw);
+        const uint4 ctr = make_uint4(((bc & 1u) << logm) + i, iter, cz, cw);
+        const ulonglong2 e = random_digits(((u128)a.w2 << 64) | xlo, CC, key, ctr);
         store_digits(dig, bc, i, M, e.x, e.y, wide);
         return;
     }
@@ -998,7 +1020,7 @@ k_crt_lean1(const uint32_t *__restrict__ yres, uint64_t *__restrict__ dig,
 // x2 directly -- no reduction of r_1 B + r_0, no second quotient.  New stored digits: those of x2
 // plus r_i.  Same stream addressing as k_crt_acc (random_digits), bit-identical output (tests: the oracle; the
 // register widths: tests/rns_model.py CrtLean.digits_random).
-template <int NP, int NL, bool WIDE>
+template <int NP, int NL, bool WIDE, bool ROWS = false>
 __global__ void __launch_bounds__(256)
 k_crt_lean_rnd(const uint32_t *__restrict__ yres, uint64_t *__restrict__ dig,
                const CrtLean *__restrict__ K, uint32_t quads, uint32_t logm, RndArgs ra, uint32_t iter) {
@@ -1026,9 +1048,12 @@ k_crt_lean_rnd(const uint32_t *__restrict__ yres, uint64_t *__restrict__ dig,
     const uint32_t h0w[4] = {h0.x & 0xFFFFu, h0.x >> 16, h0.y & 0xFFFFu, h0.y >> 16};
     const uint32_t h1w[4] = {h1.x & 0xFFFFu, h1.x >> 16, h1.y & 0xFFFFu, h1.y >> 16};
     const uint64_t xm2 = ((uint64_t)K->xm2hi << 32) | K->xm2lo, span = xm2 + 1;
-    const uint32_t cx = ((bc & 1u) << logm) + i, cz = ra.chunk + (bc >> 1);
+    const uint32_t cx = ((bc & 1u) << logm) + i;
+    ChaChaKey key;
+    uint32_t cz, cw;
+    rnd_stream<ROWS>(ra, bc >> 1, key, cz, cw);
     uint32_t rw[16];   // the draws of the thread's four coefficients: one block of the stream
-    chacha_block<SGFHE_RND_ROUNDS>(ra.key, cx >> 2, iter, cz, ra.call, rw);
+    chacha_block<SGFHE_RND_ROUNDS>(key, cx >> 2, iter, cz, cw, rw);
     uint64_t nlo[4], nhi[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
@@ -1072,7 +1097,7 @@ k_crt_lean_rnd(const uint32_t *__restrict__ yres, uint64_t *__restrict__ dig,
 // instruction stream is one block and one CRT instead of one block and four.  Same stream addressing, same
 // digits as k_crt_lean_rnd.  QUARTER: residues from the partial values of the quarter kernels.  Not for the
 // three-plane digit records (B >= 2^46).
-template <int NP, int NL, bool QUARTER>
+template <int NP, int NL, bool QUARTER, bool ROWS = false>
 __global__ void __launch_bounds__(256)
 k_crt_lean_rnd1(const uint32_t *__restrict__ yres, uint64_t *__restrict__ dig,
                 const CrtLean *__restrict__ K, uint32_t total, uint32_t logm, RndArgs ra, uint32_t iter,
@@ -1108,9 +1133,12 @@ k_crt_lean_rnd1(const uint32_t *__restrict__ yres, uint64_t *__restrict__ dig,
     }
     const ulonglong2 d = load_digits(dig, bc, i, M);
     const uint64_t xm2 = ((uint64_t)K->xm2hi << 32) | K->xm2lo, span = xm2 + 1;
-    const uint32_t cx = ((bc & 1u) << logm) + i, cz = ra.chunk + (bc >> 1);
+    const uint32_t cx = ((bc & 1u) << logm) + i;
+    ChaChaKey key;
+    uint32_t cz, cw;
+    rnd_stream<ROWS>(ra, bc >> 1, key, cz, cw);
     uint32_t rw[16];
-    chacha_block<SGFHE_RND_ROUNDS>(ra.key, cx >> 2, iter, cz, ra.call, rw);
+    chacha_block<SGFHE_RND_ROUNDS>(key, cx >> 2, iter, cz, cw, rw);
     const uint32_t sel = cx & 3u;   // this coefficient's four words of the block
     const uint32_t w0 = sel == 0 ? rw[0] : sel == 1 ? rw[4] : sel == 2 ? rw[8] : rw[12];
     const uint32_t w1 = sel == 0 ? rw[1] : sel == 1 ? rw[5] : sel == 2 ? rw[9] : rw[13];
@@ -1653,6 +1681,7 @@ k_crt_lean1q(const int32_t *__restrict__ ypart, uint64_t *__restrict__ dig, Prim
 // t = initial_poly (fhe.jl:535-548): +1 on [0, Dr), 0 at Dr, -1 on (Dr, m).  Every coefficient of
 // b is 0, +DQ_tilde or -DQ_tilde, so the three possible digit pairs are precomputed.
 // One thread per (bootstrap of the padded chunk, coefficient).
+template <bool ROWS = false>
 __global__ void __launch_bounds__(256)
 k_init(const uint64_t *__restrict__ a1, const uint64_t *__restrict__ b1,
        const uint64_t *__restrict__ a2, const uint64_t *__restrict__ b2,
@@ -1681,8 +1710,11 @@ k_init(const uint64_t *__restrict__ a1, const uint64_t *__restrict__ b1,
         const u128 offr = CC->offneg_rnd ? Q - CC->offneg_rnd : 0;
         u128 xb = offr + (tv > 0 ? CC->DQ : (tv < 0 ? Q - CC->DQ : 0));
         if (xb >= Q) xb -= Q;
-        const ulonglong2 ea = random_digits(offr, CC, ra, make_uint4(i, 0u, ra.chunk + b, ra.call));
-        const ulonglong2 eb = random_digits(xb, CC, ra, make_uint4(M + i, 0u, ra.chunk + b, ra.call));
+        ChaChaKey key;
+        uint32_t cz, cw;
+        rnd_stream<ROWS>(ra, b, key, cz, cw);
+        const ulonglong2 ea = random_digits(offr, CC, key, make_uint4(i, 0u, cz, cw));
+        const ulonglong2 eb = random_digits(xb, CC, key, make_uint4(M + i, 0u, cz, cw));
         store_digits(dig, (size_t)b * 2 + 0, i, M, ea.x, ea.y, (mode & MODE_WIDE) != 0);
         store_digits(dig, (size_t)b * 2 + 1, i, M, eb.x, eb.y, (mode & MODE_WIDE) != 0);
         return;
@@ -1826,7 +1858,7 @@ k_pack_flatten(const ulonglong2 *__restrict__ raw, uint64_t *__restrict__ pdig,
     if (mode & MODE_RANDOM) {
         x += CC->offneg_rnd ? Q - CC->offneg_rnd : 0;   // + (s + xmax)(1 + B)
         if (x >= Q) x -= Q;
-        const ulonglong2 e = random_digits(x, CC, ra, make_uint4(j, 0x80000000u | i, ci, ra.call));
+        const ulonglong2 e = random_digits(x, CC, ra.key, make_uint4(j, 0x80000000u | i, ci, ra.call));
         d[0] = e.x;
         d[len] = e.y;
         return;

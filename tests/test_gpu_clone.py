@@ -79,6 +79,48 @@ def test_eight_threads_single_gate_calls_on_eight_clones(S, gpu_keys, n):
             e.close()
 
 
+@pytest.mark.parametrize("n", [64, 512])
+def test_gathered_randomised_calls_keep_every_callers_own_draw_stream(S, oc, gpu_keys, n):
+    """bootstrap(hkey, rng, ...) from eight tasks at once (the reference's documented call, README.md:24): every
+    clone has its own flatten key and call counter, and a gathered call draws for every row from the stream of the
+    ctx the row came in on (kernels.h RndRow) -- so each caller gets the bytes of the same calls made alone, call
+    after call, whatever was gathered with them; one caller's first call is also held against the C restatement of
+    src/utils.jl:198-241 on that caller's stream.  Calls of 1, 3 and 2 gates per caller; Params(64) (m = 512: a
+    wave of the CRT kernel spans several rows) and Params(512)."""
+    params, o, sk, eng = gpu_keys.engine(n)
+    eng.set_random_flatten(False)
+    sizes = (1, 3, 2, 1)
+    work = [[_inputs(params, g, 7300 + 16 * t + i) for i, g in enumerate(sizes)] for t in range(8)]
+    keys = [bytes((13 * t + i) & 0xFF for i in range(32)) for t in range(8)]
+    alone = eng.clone()
+    eng.set_coalesce(False)                       # the reference streams: nothing gathered
+    ref = []
+    for t in range(8):
+        alone.set_random_flatten(True, keys[t])   # call counter 0
+        ref.append([alone.bootstrap_batch(*w) for w in work[t]])          # calls 0, 1, 2, 3 of stream t
+    alone.close()
+    khat = gpu_keys.khat(n)
+    assert np.array_equal(ref[5][1], o.bootstrap_batch(khat, *work[5][1], opt=True, rnd=(keys[5], 1)))
+    clones = [eng.clone() for _ in range(8)]
+    try:
+        eng.set_coalesce(True)
+        eng.coalesce_stats(reset=True)
+
+        def job(t):
+            clones[t].set_random_flatten(True, keys[t])
+            return [clones[t].bootstrap_batch(*w) for w in work[t]]
+        got = _run_threads([lambda t=t: job(t) for t in range(8)])
+        for t in range(8):
+            for a, b in zip(got[t], ref[t]):
+                assert a.tobytes() == b.tobytes(), t
+        st = eng.coalesce_stats()
+        assert st["requests"] == 8 * len(sizes) and st["max_requests"] >= 2
+        assert ref[0][0].tobytes() != ref[1][0].tobytes()
+    finally:
+        for e in clones:
+            e.close()
+
+
 def test_clones_keep_their_own_mode_buffers_and_knobs(S, oc, gpu_keys):
     """Clones beside the parent, all busy at once with different call sizes (latency form, two chains,
     throughput form), one of them in the randomised flatten mode on its own ChaCha key: each stream of

@@ -7,7 +7,9 @@
 // compared with the same call made alone.
 //   g++ -O2 -std=c++17 -pthread -Iinclude -o tools/abl/callers tools/callers.cpp -Lsgfhe.jl_amd/csrc -lsgfhe_hip \
 //       -Wl,-rpath,'$ORIGIN/../../sgfhe.jl_amd/csrc'
-//   tools/abl/callers [n = 1024] [gates = 1] [seconds = 3] [gather = 1] [window_us = 300]
+//   tools/abl/callers [n = 1024] [gates = 1] [seconds = 3] [gather = 1] [window_us = 300] [random = 0]
+// random = 1: bootstrap(hkey, rng, ...) -- every caller sets a flatten key of its own before every call, as
+// julia/SGFHEHip.jl does with 32 bytes of the caller's rng (so every call is call 0 of its stream).
 #include <atomic>
 #include <chrono>
 #include <cstdint>
@@ -44,6 +46,7 @@ int main(int argc, char **argv) {
     const double seconds = argc > 3 ? atof(argv[3]) : 3.0;
     const int gather = argc > 4 ? atoi(argv[4]) : 1;
     const uint32_t window = argc > 5 ? (uint32_t)atoi(argv[5]) : 300;
+    const int rnd = argc > 6 ? atoi(argv[6]) : 0;
     sgfhe_params p;
     if (!params_of(n, &p)) { printf("n must be 64, 512 or 1024\n"); return 2; }
     sgfhe_ctx *ctx = nullptr;
@@ -58,16 +61,21 @@ int main(int argc, char **argv) {
     const size_t row = 3 * (n + 1);
     struct Work { std::vector<uint64_t> a1, b1, a2, b2, ref; };
     std::vector<Work> work(tmax);
-    for (auto &w : work) {
+    auto fkey = [](int t, uint8_t *k) { for (int i = 0; i < 32; i++) k[i] = (uint8_t)(17 * t + i); };
+    for (int t = 0; t < tmax; t++) {
+        Work &w = work[t];
         w.a1.resize(gates * n); w.a2.resize(gates * n); w.b1.resize(gates); w.b2.resize(gates); w.ref.resize(gates * row);
         for (auto *v : {&w.a1, &w.a2, &w.b1, &w.b2}) for (auto &x : *v) x = rng() % p.r;
+        if (rnd) { uint8_t k[32]; fkey(t, k); OK(sgfhe_set_random_flatten_key(ctx, 1, k)); }
         OK(sgfhe_bootstrap_batch(ctx, w.a1.data(), w.b1.data(), w.a2.data(), w.b2.data(), gates, w.ref.data(), 0));   // alone
     }
+    OK(sgfhe_set_random_flatten(ctx, 0, 0));
     std::vector<sgfhe_ctx *> clones(tmax);
     for (auto &c : clones) OK(sgfhe_ctx_clone(ctx, &c));
     OK(sgfhe_set_coalesce(ctx, gather, 32, 256, window));
-    printf("Params(%llu), calls of %zu gate(s) through sgfhe_bootstrap_batch, %.1f s per point, gathering %s (window %u us), %s\n",
-           (unsigned long long)n, gates, seconds, gather ? "on" : "off", window, sgfhe_build_id());
+    printf("Params(%llu), calls of %zu gate(s) through sgfhe_bootstrap_batch, %s flatten, %.1f s per point, gathering %s (window %u us), %s\n",
+           (unsigned long long)n, gates, rnd ? "randomised (a key per caller and call)" : "deterministic", seconds,
+           gather ? "on" : "off", window, sgfhe_build_id());
     double base = 0;
     for (int T : counts) {
         std::atomic<bool> go{false}, stop{false}, bad{false};
@@ -79,9 +87,13 @@ int main(int argc, char **argv) {
             th.emplace_back([&, t] {
                 const Work &w = work[t];
                 std::vector<uint64_t> out(gates * row);
+                uint8_t k[32];
+                fkey(t, k);
+                if (rnd) sgfhe_set_random_flatten_key(clones[t], 1, k);
                 sgfhe_bootstrap_batch(clones[t], w.a1.data(), w.b1.data(), w.a2.data(), w.b2.data(), gates, out.data(), 0);   // warm
                 while (!go.load()) std::this_thread::yield();
                 while (!stop.load()) {
+                    if (rnd) sgfhe_set_random_flatten_key(clones[t], 1, k);     // call 0 of this caller's stream again
                     if (sgfhe_bootstrap_batch(clones[t], w.a1.data(), w.b1.data(), w.a2.data(), w.b2.data(), gates, out.data(), 0) ||
                         ((calls[t]++ & 7) == 0 && memcmp(out.data(), w.ref.data(), out.size() * 8))) { bad = true; return; }
                 }
