@@ -20,6 +20,7 @@
 
 #include "kernels.h"
 #include "host_plumbing.h"
+#include "coalescer.h"
 
 using namespace sgfhe;
 
@@ -76,50 +77,7 @@ double u128_dbl(u128 x) { return (double)(uint64_t)(x >> 64) * 18446744073709551
 // CRT / flatten constants of every basis, the twiddle tables, and the key in every form -- everything a
 // bootstrap only reads.  Each allocation is registered here when it is made and freed when the last ctx
 // that holds the block goes, so a clone may outlive the ctx it was taken from.
-// Independent callers on one key, gathered (round 5).  The device runs about two dependent launch chains side by
-// side, whatever streams and hardware queues they are given (tools/ubench_streams.hip, profiles/r05_concurrent.txt:
-// 2 / 4 / 8 threads with a stream each reach 1.9 / 1.9 / 2.5 x one thread), but ONE chain of g gates costs little
-// more than a chain of one (15.1 ms for 1 gate, 20.8 for 8, 26.5 for 16 at Params(1024)).  So small host-pointer
-// calls that arrive together on ctxs sharing a key (sgfhe_ctx_clone) are run as one call: the caller that finds no
-// combined call in flight leads -- it takes every request waiting, runs them as one batch on ITS OWN ctx (its lock,
-// lanes and streams) and hands each caller its rows -- and callers that arrive meanwhile wait for the next round.
-// A row's result does not depend on the rows beside it (src/fhe.jl:579-582 is per bootstrap; tests/test_gpu_golden.py
-// batch-position test), so every caller gets the bytes of its call made alone -- in the randomised flatten too:
-// there every row of the combined call draws from the stream of the ctx it came in on (that ctx's key, the number
-// of its call, the row's index in its call: kernels.h RndRow), and deterministic and randomised requests form
-// separate rounds.
-struct Coalescer {
-    struct Req {
-        const void *owner;       // the ctx the request came in on
-        const uint64_t *a1, *b1, *a2, *b2;
-        size_t batch;
-        uint64_t *out;
-        uint32_t flags;
-        bool rnd = false;        // randomised flatten: the request's own draw stream (key, number of the call)
-        ChaChaKey key;
-        uint32_t call = 0;
-        int32_t rc = 0;
-        bool done = false;
-        std::string err;
-    };
-    std::mutex mu;
-    std::condition_variable cv;
-    std::deque<Req *> pending;
-    bool running = false;        // a leader is running a combined call
-    // which ctxs had a request served in which round: the callers of the last two rounds are the ones a leader
-    // expects back (with eight callers, half of them are still on their way back from the previous round when the
-    // other half -- who waited through it -- could already start: two alternating rounds of four, at 3.5 x one
-    // caller's rate, where one round of eight gives 5.8 x)
-    uint64_t round = 0;
-    std::unordered_map<const void *, uint64_t> seen;
-    // knobs (sgfhe_set_coalesce): on / off, largest request that is gathered, gates per combined call, how long a
-    // leader waits for the callers of the previous round to come back
-    bool enabled = true;
-    uint32_t req_max = 32, gates_max = 256, window_us = 300;
-    // statistics (sgfhe_coalesce_stats)
-    uint64_t n_calls = 0, n_reqs = 0, n_gates = 0, max_reqs = 0;
-};
-
+// (struct Coalescer -- the gathering of small calls across the ctxs that share a key -- is csrc/coalescer.h)
 struct SharedDev {
     int device = 0;
     std::mutex mu;
@@ -1852,10 +1810,7 @@ int32_t sgfhe_ctx_destroy(sgfhe_ctx *c) {
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
-    if (c->shared) {     // the coalescer no longer expects this caller back
-        std::lock_guard<std::mutex> lk(c->shared->co.mu);
-        c->shared->co.seen.erase(c);
-    }
+    if (c->shared) c->shared->co.forget(c);
     c->shared.reset();   // constants, tables and key: freed with the last ctx that shares them
     if (c->io_in) (void)hipFree(c->io_in);
     if (c->io_out) (void)hipFree(c->io_out);
@@ -2328,7 +2283,7 @@ static int32_t bootstrap_host(sgfhe_ctx *c, const uint64_t *a1, const uint64_t *
     return rc;
 }
 
-// One request through the coalescer of the ctxs that share this key (struct Coalescer).
+// One request through the coalescer of the ctxs that share this key (csrc/coalescer.h).
 static int32_t coalesced_call(sgfhe_ctx *c, const uint64_t *a1, const uint64_t *b1, const uint64_t *a2,
                               const uint64_t *b2, size_t batch, uint64_t *out, uint32_t flags) {
     Coalescer &co = c->shared->co;
@@ -2338,46 +2293,15 @@ static int32_t coalesced_call(sgfhe_ctx *c, const uint64_t *a1, const uint64_t *
     me.batch = batch; me.out = out; me.flags = flags;
     if (c->rnd) {               // its draw stream: this ctx's key, and the number this call has on this ctx
         me.rnd = true;
-        me.key = c->rnd_key;
+        memcpy(me.key, c->rnd_key.k, sizeof me.key);
         me.call = c->rnd_call++;
         c->last_call = me.call;
     }
     std::vector<Coalescer::Req *> take;
     size_t gates = 0;
-    {
-        std::unique_lock<std::mutex> lk(co.mu);
-        co.pending.push_back(&me);
-        co.cv.notify_all();                         // a leader gathering its round sees the arrival
-        for (;;) {
-            if (me.done) {                          // a leader ran it
-                if (me.rc) c->err = me.err;
-                return me.rc;
-            }
-            if (!co.running && co.pending.front() == &me) break;   // nobody is running: the oldest request leads
-            co.cv.wait(lk);
-        }
-        co.running = true;
-        // The callers of the last two rounds are about to come back (they got their results microseconds ago):
-        // wait until as many requests are here as there were callers, a few hundred microseconds at most.  A
-        // caller on its own never waits.
-        if (co.window_us) {
-            size_t expect = 1;                                     // the leader itself
-            for (auto it = co.seen.begin(); it != co.seen.end();) {
-                if (it->first != c && it->second + 2 > co.round) expect++;
-                if (it->second + 64 <= co.round) it = co.seen.erase(it); else ++it;     // long gone
-            }
-            const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(co.window_us);
-            while (co.pending.size() < expect && co.cv.wait_until(lk, deadline) != std::cv_status::timeout) {}
-        }
-        for (auto it = co.pending.begin(); it != co.pending.end();) {
-            if ((*it)->flags == me.flags && (*it)->rnd == me.rnd && (take.empty() || gates + (*it)->batch <= co.gates_max)) {
-                take.push_back(*it);
-                gates += (*it)->batch;
-                it = co.pending.erase(it);
-            } else {
-                ++it;
-            }
-        }
+    if (!co.arrive(me, take, gates)) {              // a leader ran it
+        if (me.rc) c->err = me.err;
+        return me.rc;
     }
     // the combined call, on this ctx (the caller holds its lock)
     int32_t rc;
@@ -2396,15 +2320,22 @@ static int32_t coalesced_call(sgfhe_ctx *c, const uint64_t *a1, const uint64_t *
                     if (c->d_rows) (void)hipFree(c->d_rows);
                     c->d_rows = nullptr;
                     c->rows_cap = 0;
-                    if (hipMalloc(&c->d_rows, co.gates_max * sizeof(RndRow)) != hipSuccess)
+                    const size_t cap = gates > co.gates_max ? gates : co.gates_max;
+                    if (hipMalloc(&c->d_rows, cap * sizeof(RndRow)) != hipSuccess)
                         rc = fail(c, SGFHE_ERR_OOM, "hipMalloc of the gathered call's draw-stream table failed");
                     else
-                        c->rows_cap = co.gates_max;
+                        c->rows_cap = cap;
                 }
                 if (rc == SGFHE_OK) {
                     c->h_rows.clear();
                     for (const Coalescer::Req *q : take)
-                        for (size_t t = 0; t < q->batch; t++) c->h_rows.push_back(RndRow{q->key, q->call, (uint32_t)t});
+                        for (size_t t = 0; t < q->batch; t++) {
+                            RndRow r;
+                            memcpy(r.key.k, q->key, sizeof r.key.k);
+                            r.call = q->call;
+                            r.boot = (uint32_t)t;
+                            c->h_rows.push_back(r);
+                        }
                     if (hipMemcpy(c->d_rows, c->h_rows.data(), gates * sizeof(RndRow), hipMemcpyHostToDevice) != hipSuccess)
                         rc = fail(c, SGFHE_ERR_HIP, "copy of the gathered call's draw-stream table failed");
                 }
@@ -2437,22 +2368,7 @@ static int32_t coalesced_call(sgfhe_ctx *c, const uint64_t *a1, const uint64_t *
         }
         c->gather_rows = nullptr;
     }
-    {
-        std::lock_guard<std::mutex> lk(co.mu);
-        for (Coalescer::Req *q : take) {
-            q->rc = rc;
-            if (rc) q->err = c->err;
-            q->done = true;
-            co.seen[q->owner] = co.round;
-        }
-        co.round++;
-        co.n_calls++;
-        co.n_reqs += take.size();
-        co.n_gates += gates;
-        if (take.size() > co.max_reqs) co.max_reqs = take.size();
-        co.running = false;
-        co.cv.notify_all();
-    }
+    co.finish(take, gates, rc, c->err);
     return rc;
 }
 

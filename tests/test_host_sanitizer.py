@@ -65,3 +65,32 @@ def test_oracle_c_under_asan_and_ubsan(tmp_path):
                    check=True, timeout=600)
     r2 = subprocess.run([exe2], capture_output=True, text=True, timeout=900, env=env)
     assert r2.returncode == 0 and r2.stdout.strip() == r.stdout.strip()
+
+
+@pytest.mark.parametrize("san", ["thread", "address,undefined"])
+def test_coalescer_under_thread_and_address_sanitizers(tmp_path, san):
+    """csrc/coalescer.h -- the queueing half of the gathering of independent callers on one key (round 5,
+    sgfhe_set_coalesce) -- under ThreadSanitizer and under ASan / UBSan on the CPU, with a stand-in for the combined
+    call (tests/native/coalescer_tsan.cpp): twelve threads of mixed requests; every request gets its own rows, rounds
+    never overlap or mix modes, errors reach exactly their round, the statistics add up, a lone caller is not
+    delayed.  The requests live on their callers' stacks while another thread serves them: exactly what these tools
+    are for."""
+    gxx = shutil.which("g++")
+    if not gxx:
+        pytest.skip("no g++")
+    exe = str(tmp_path / "coalescer_san")
+    b = subprocess.run([gxx, "-std=c++17", "-O1", "-g", "-pthread", "-fsanitize=" + san, "-fno-sanitize-recover=all",
+                        "-fno-omit-frame-pointer", "-Wall", "-Wextra", "-Werror",
+                        "-I", os.path.join(ROOT, "sgfhe.jl_amd", "csrc"),
+                        os.path.join(ROOT, "tests", "native", "coalescer_tsan.cpp"), "-o", exe],
+                       capture_output=True, text=True, timeout=300)
+    if b.returncode != 0 and "sanitize" in b.stderr and "cannot find" in b.stderr:
+        pytest.skip("the sanitizer runtimes are not installed: " + b.stderr[-300:])
+    assert b.returncode == 0, b.stderr[-3000:]
+    env = dict(os.environ, TSAN_OPTIONS="halt_on_error=1:second_deadlock_stack=1",
+               ASAN_OPTIONS="detect_leaks=1:abort_on_error=1:detect_stack_use_after_return=1", UBSAN_OPTIONS="print_stacktrace=1")
+    env.pop("LD_PRELOAD", None)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    tag, n_calls, n_reqs = r.stdout.split()
+    assert tag == "ok" and int(n_reqs) == 12 * 60 + 200 and int(n_calls) < int(n_reqs)      # something was gathered
