@@ -60,18 +60,23 @@ struct Coalescer {
     // statistics (sgfhe_coalesce_stats)
     uint64_t n_calls = 0, n_reqs = 0, n_gates = 0, max_reqs = 0;
 
-    // A request arrives.  Returns false when another caller's combined call served it (me.rc / me.err hold its
-    // outcome).  Returns true when the caller LEADS a round: `take` holds the requests of the round, `me` among them
-    // -- same flags and flatten mode as `me`, at most gates_max gates (always at least `me`); the caller runs them
-    // and then calls finish().  Between the two calls no other round starts.
-    bool arrive(Req &me, std::vector<Req *> &take, size_t &gates) {
+    // A request arrives.  Returns 0 when another caller's combined call served it (me.rc / me.err hold its outcome);
+    // 1 when the caller LEADS a round: `take` holds the requests of the round, `me` among them -- same flags and
+    // flatten mode as `me`, at most gates_max gates (always at least `me`); the caller runs them and then calls
+    // finish(); between the two calls no other round starts.  -1 when the host is out of memory: the request is
+    // in no queue and nothing else has changed (the entry points of the C ABI must not throw).
+    int arrive(Req &me, std::vector<Req *> &take, size_t &gates) {
         take.clear();
         gates = 0;
         std::unique_lock<std::mutex> lk(mu);
-        pending.push_back(&me);
+        try {
+            pending.push_back(&me);
+        } catch (...) {
+            return -1;
+        }
         cv.notify_all();                            // a leader gathering its round sees the arrival
         for (;;) {
-            if (me.done) return false;              // a leader ran it
+            if (me.done) return 0;                  // a leader ran it
             if (!running && pending.front() == &me) break;     // nobody is running: the oldest request leads
             cv.wait(lk);
         }
@@ -88,6 +93,15 @@ struct Coalescer {
             const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(window_us);
             while (pending.size() < expect && cv.wait_until(lk, deadline) != std::cv_status::timeout) {}
         }
+        try {
+            take.reserve(pending.size());           // (the only allocation of the round: nothing below can throw)
+        } catch (...) {
+            for (auto it = pending.begin(); it != pending.end(); ++it)
+                if (*it == &me) { pending.erase(it); break; }
+            running = false;
+            cv.notify_all();                        // the next oldest request leads
+            return -1;
+        }
         for (auto it = pending.begin(); it != pending.end();) {
             if ((*it)->flags == me.flags && (*it)->rnd == me.rnd && (take.empty() || gates + (*it)->batch <= gates_max)) {
                 take.push_back(*it);
@@ -97,7 +111,7 @@ struct Coalescer {
                 ++it;
             }
         }
-        return true;
+        return 1;
     }
 
     // The leader's round is over: every request of it gets the outcome, the waiting callers are released, and the
@@ -108,7 +122,10 @@ struct Coalescer {
             q->rc = rc;
             if (rc) q->err = err;
             q->done = true;
-            seen[q->owner] = round;
+            try {
+                seen[q->owner] = round;             // (only the next leader's expectation depends on it)
+            } catch (...) {
+            }
         }
         round++;
         n_calls++;

@@ -2299,7 +2299,9 @@ static int32_t coalesced_call(sgfhe_ctx *c, const uint64_t *a1, const uint64_t *
     }
     std::vector<Coalescer::Req *> take;
     size_t gates = 0;
-    if (!co.arrive(me, take, gates)) {              // a leader ran it
+    const int lead = co.arrive(me, take, gates);
+    if (lead < 0) return fail(c, SGFHE_ERR_OOM, "out of host memory");
+    if (lead == 0) {                                // a leader ran it
         if (me.rc) c->err = me.err;
         return me.rc;
     }

@@ -64,6 +64,12 @@ def pytest_terminal_summary(terminalreporter, exitstatus, config):
         dt = time.time() - config._sgfhe_t0
         tr.write_line("GPU suite wall time %.0f s (budget %d s, driver limit 900 s)%s"
                       % (dt, GPU_SUITE_BUDGET_S, "" if dt <= GPU_SUITE_BUDGET_S else "  ** OVER BUDGET **"))
+        # the slowest items, whatever flags the runner was started with (the driver's command has no --durations):
+        # the next test that eats the budget shows up in the round's log
+        reps = [r for rs in tr.stats.values() for r in rs
+                if hasattr(r, "duration") and getattr(r, "when", None) in ("setup", "call")]
+        for r in sorted(reps, key=lambda r: -r.duration)[:15]:
+            tr.write_line("  %7.2f s %-5s %s" % (r.duration, r.when, r.nodeid))
 
 
 @pytest.fixture(scope="session")

@@ -48,7 +48,9 @@ static int32_t call(Coalescer &co, const void *owner, uint32_t key0, uint32_t ca
     me.rnd = rnd; me.key[0] = key0; me.call = callno;
     std::vector<Coalescer::Req *> take;
     size_t gates = 0;
-    if (!co.arrive(me, take, gates)) {
+    const int lead = co.arrive(me, take, gates);
+    if (lead < 0) return -6;
+    if (lead == 0) {
         err_out = me.err;
         return me.rc;
     }
