@@ -30,7 +30,8 @@ import os
 
 import numpy as np
 
-PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "gpu_expect.json")
+PATH = os.environ.get("SGFHE_EXPECT_PATH") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden",
+                                                            "gpu_expect.json")
 RECORD = os.environ.get("SGFHE_EXPECT_RECORD") == "1"
 
 
