@@ -1662,7 +1662,7 @@ int32_t create_streams(sgfhe_ctx *c) {
 
 extern "C" {
 
-const char *sgfhe_version(void) { return "sgfhe_hip 0.4.0 gfx950"; }
+const char *sgfhe_version(void) { return "sgfhe_hip 0.5.0 gfx950"; }
 
 uint32_t sgfhe_abi_version(void) { return SGFHE_ABI_VERSION; }
 
