@@ -8,6 +8,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <deque>
@@ -83,6 +84,7 @@ struct SharedDev {
     std::mutex mu;
     std::vector<void *> mem;
     Coalescer co;
+    std::atomic<unsigned> clones{0};     // clones made of this block so far (their streams are shifted by it)
     void own(void *p) {
         std::lock_guard<std::mutex> g(mu);
         mem.push_back(p);
@@ -1786,7 +1788,20 @@ int32_t sgfhe_ctx_clone(sgfhe_ctx *src, sgfhe_ctx **out) {
     // its own: flatten mode (deterministic, call counter 0), lanes' work buffers, streams, events, staging,
     // timing, the error string and the lock
     activate(c, 0);
+    // The runtime deals streams onto its hardware queues (GPU_MAX_HW_QUEUES = 4) in the order they are created, and
+    // packets of one hardware queue run in order: with four streams per ctx, the FIRST stream of every ctx -- the
+    // one its calls run on -- would sit on the same queue and calls on different clones could never overlap on the
+    // device (tools/ubench_streams.hip with UB_EXTRA_STREAMS=3: x1.00 at any number of threads,
+    // profiles/r05_concurrent.txt).  A clone therefore shifts its streams by its number among the sharers: a few
+    // throw-away streams first, destroyed once its own exist.  (What the gathering of small calls does not cover --
+    // calls above its size limit, the asynchronous entry point -- then overlaps as far as the device lets two
+    // chains overlap.)
+    hipStream_t skip[3] = {nullptr, nullptr, nullptr};
+    const unsigned shift = c->shared->clones.fetch_add(1) % 4u + 1u;       // 1, 2, 3, 0, 1, ... (the creator ctx has 0)
+    for (unsigned i = 0; i < shift % 4u; i++) (void)hipStreamCreateWithFlags(&skip[i], hipStreamNonBlocking);
     int32_t rc = create_streams(c);
+    for (hipStream_t x : skip)
+        if (x) (void)hipStreamDestroy(x);
     if (rc) return rc;
     HIPCHK(c, hipMalloc(&c->d_bad, sizeof(uint32_t)));
     HIPCHK(c, hipMemset(c->d_bad, 0, sizeof(uint32_t)));

@@ -7,6 +7,9 @@
 //   prio     hipStreamCreateWithPriority, priorities cycling low / normal / high (a queue pool per priority)
 //   cumask   hipExtStreamCreateWithCUMask with every CU enabled: a hardware queue of the stream's own
 // and two ways of queueing: launch by launch, or the chain captured once into a hipGraph per thread.
+// UB_EXTRA_STREAMS=k in the environment: every thread creates k more (unused) plain streams after its own, as an
+// engine ctx does (two lanes + two copy streams = 3 extra): if the runtime deals streams round-robin onto its
+// hardware queues, the streams in USE then all sit on one queue and nothing overlaps.  UB_KINDS=plain limits the run.
 // Prints aggregate chains per second and the ratio to one thread.
 //   hipcc --offload-arch=gfx950 -O3 -pthread -o tools/abl/ubench_streams tools/ubench_streams.hip
 #include <hip/hip_runtime.h>
@@ -51,11 +54,16 @@ int main(int argc, char **argv) {
     CHECK(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, 0));
     printf("chain = %d x 3 dependent launches, work %d, %d CUs, GPU_MAX_HW_QUEUES=%s\n", iters, work, ncu,
            getenv("GPU_MAX_HW_QUEUES") ? getenv("GPU_MAX_HW_QUEUES") : "(default)");
+    const int extra = getenv("UB_EXTRA_STREAMS") ? atoi(getenv("UB_EXTRA_STREAMS")) : 0;
+    const char *only = getenv("UB_KINDS");
+    if (extra) printf("every thread creates %d more plain streams after its own and leaves them unused\n", extra);
     for (const char *kind : {"plain", "prio", "cumask"}) {
+        if (only && strcmp(only, kind)) continue;
         for (int graph = 0; graph < 2; graph++) {
             double base = 0;
             for (int T : {1, 2, 4, 8, 16}) {
                 std::vector<Worker> w(T);
+                std::vector<hipStream_t> unused;
                 for (int t = 0; t < T; t++) {
                     if (!strcmp(kind, "plain")) {
                         CHECK(hipStreamCreateWithFlags(&w[t].st, hipStreamNonBlocking));
@@ -68,6 +76,11 @@ int main(int argc, char **argv) {
                         std::vector<uint32_t> mask((ncu + 31) / 32, 0xFFFFFFFFu);
                         if (ncu % 32) mask.back() = (1u << (ncu % 32)) - 1u;
                         CHECK(hipExtStreamCreateWithCUMask(&w[t].st, (uint32_t)mask.size(), mask.data()));
+                    }
+                    for (int x = 0; x < extra; x++) {
+                        hipStream_t u;
+                        CHECK(hipStreamCreateWithFlags(&u, hipStreamNonBlocking));
+                        unused.push_back(u);
                     }
                     CHECK(hipMalloc(&w[t].buf, 3 * 8192 * 4));
                     CHECK(hipMemset(w[t].buf, 0, 3 * 8192 * 4));
@@ -115,6 +128,7 @@ int main(int argc, char **argv) {
                 printf("%-6s %-6s threads %2d: %7.1f chains/s  x%.2f   one chain %.2f ms, of which the host queues for %.2f ms\n", kind,
                        graph ? "graph" : "launch", T, rate, rate / base, ms / reps, q);
                 fflush(stdout);
+                for (auto u : unused) CHECK(hipStreamDestroy(u));
                 for (auto &x : w) {
                     if (x.exec) CHECK(hipGraphExecDestroy(x.exec));
                     CHECK(hipStreamDestroy(x.st));
