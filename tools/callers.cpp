@@ -8,6 +8,7 @@
 //   g++ -O2 -std=c++17 -pthread -Iinclude -o tools/abl/callers tools/callers.cpp -Lsgfhe.jl_amd/csrc -lsgfhe_hip \
 //       -Wl,-rpath,'$ORIGIN/../../sgfhe.jl_amd/csrc'
 //   tools/abl/callers [n = 1024] [gates = 1] [seconds = 3] [gather = 1] [window_us = 300] [random = 0]
+//                     [req_max = 32] [gates_max = 256] [most callers = 32]      (sgfhe_set_coalesce's limits)
 // random = 1: bootstrap(hkey, rng, ...) -- every caller sets a flatten key of its own before every call, as
 // julia/SGFHEHip.jl does with 32 bytes of the caller's rng (so every call is call 0 of its stream).
 #include <atomic>
@@ -47,6 +48,9 @@ int main(int argc, char **argv) {
     const int gather = argc > 4 ? atoi(argv[4]) : 1;
     const uint32_t window = argc > 5 ? (uint32_t)atoi(argv[5]) : 300;
     const int rnd = argc > 6 ? atoi(argv[6]) : 0;
+    const uint32_t req_max = argc > 7 ? (uint32_t)atoi(argv[7]) : 32;        // the library's defaults
+    const uint32_t gates_max = argc > 8 ? (uint32_t)atoi(argv[8]) : 256;
+    const int most = argc > 9 ? atoi(argv[9]) : 32;
     sgfhe_params p;
     if (!params_of(n, &p)) { printf("n must be 64, 512 or 1024\n"); return 2; }
     sgfhe_ctx *ctx = nullptr;
@@ -56,7 +60,8 @@ int main(int argc, char **argv) {
     for (auto &x : sk) x = rng() & 1;
     uint8_t seed[32] = {2};
     OK(sgfhe_bkey_generate(ctx, sk.data(), n, seed, (uint32_t)n));
-    const std::vector<int> counts = {1, 2, 4, 8, 16, 32};
+    std::vector<int> counts;
+    for (int t = 1; t <= most; t *= 2) counts.push_back(t);
     const int tmax = counts.back();
     const size_t row = 3 * (n + 1);
     struct Work { std::vector<uint64_t> a1, b1, a2, b2, ref; };
@@ -72,10 +77,10 @@ int main(int argc, char **argv) {
     OK(sgfhe_set_random_flatten(ctx, 0, 0));
     std::vector<sgfhe_ctx *> clones(tmax);
     for (auto &c : clones) OK(sgfhe_ctx_clone(ctx, &c));
-    OK(sgfhe_set_coalesce(ctx, gather, 32, 256, window));
-    printf("Params(%llu), calls of %zu gate(s) through sgfhe_bootstrap_batch, %s flatten, %.1f s per point, gathering %s (window %u us), %s\n",
+    OK(sgfhe_set_coalesce(ctx, gather, req_max, gates_max, window));
+    printf("Params(%llu), calls of %zu gate(s) through sgfhe_bootstrap_batch, %s flatten, %.1f s per point, gathering %s (window %u us, requests up to %u gates, %u per chain), %s\n",
            (unsigned long long)n, gates, rnd ? "randomised (a key per caller and call)" : "deterministic", seconds,
-           gather ? "on" : "off", window, sgfhe_build_id());
+           gather ? "on" : "off", window, req_max, gates_max, sgfhe_build_id());
     double base = 0;
     for (int T : counts) {
         std::atomic<bool> go{false}, stop{false}, bad{false};
