@@ -130,11 +130,11 @@ int32_t sgfhe_ctx_create_ex(const sgfhe_params *p, int device, uint32_t flags, s
  */
 int32_t sgfhe_ctx_clone(sgfhe_ctx *ctx, sgfhe_ctx **out);
 /*
- * Gathering of small calls across the ctxs that share a key (ABI revision 7).  This device runs about two
- * dependent launch chains side by side however many streams feed it, while ONE chain of g gates costs little more
- * than a chain of one (Params(1024): 15 ms for 1 gate, 21 ms for 8, 27 ms for 16).  So sgfhe_bootstrap_batch calls
- * of at most `req_max` gates (default 32) made at the same time on ctxs that share a key -- a ctx and its clones,
- * each driven by its own host thread -- are run as ONE call: the caller that finds no combined call in flight takes
+ * Gathering of small calls across the ctxs that share a key (ABI revision 7).  Separate launch chains overlap only so
+ * far on this device (four hardware queues: 1.8 x one caller's rate at two callers, 3 x at four and beyond), while ONE
+ * chain of g gates costs little more than a chain of one (Params(1024): 15 ms for 1 gate, 21 ms for 8, 27 ms for 16).
+ * So sgfhe_bootstrap_batch calls of at most `req_max` gates (default 32) made at the same time on ctxs that share a
+ * key -- a ctx and its clones, each driven by its own host thread -- are run as ONE call: the caller that finds no combined call in flight takes
  * every request waiting (up to `gates_max` gates, default 256), runs them as one batch on its own ctx and hands each
  * caller its rows; callers arriving meanwhile form the next round, whose leader waits up to `window_us` (default 300)
  * for as many callers as the last two rounds had.  A caller on its own never waits, and a ctx without clones is not

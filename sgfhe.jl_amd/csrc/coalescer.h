@@ -2,11 +2,11 @@
 // ThreadSanitizer on the CPU (tests/native/coalescer_tsan.cpp, tests/test_host_sanitizer.py).  engine.hip supplies
 // the other half: what a leader does with the requests it took (one batch on its own ctx).
 //
-// The device runs about two dependent launch chains side by side, whatever streams and hardware queues they are
-// given (tools/ubench_streams.hip, profiles/r05_concurrent.txt: 2 / 4 / 8 threads with a stream each reach 1.9 / 1.9 /
-// 2.5 x one thread), but ONE chain of g gates costs little more than a chain of one (15.1 ms for 1 gate, 20.8 for 8,
-// 26.5 for 16 at Params(1024)).  So small host-pointer calls that arrive together on ctxs sharing a key
-// (sgfhe_ctx_clone) are run as one call: the caller that finds no combined call in flight leads -- it takes every
+// Separate launch chains overlap only so far on this device -- the runtime feeds four hardware queues, and more busy
+// queues than that are time-sliced: clones with a stream each reach 1.8 x one caller's rate at two callers and 3 x at
+// four and beyond (profiles/r05_concurrent.txt) -- but ONE chain of g gates costs little more than a chain of one
+// (15.1 ms for 1 gate, 20.8 for 8, 26.5 for 16 at Params(1024)).  So small host-pointer calls that arrive together
+// on ctxs sharing a key (sgfhe_ctx_clone) are run as one call: the caller that finds no combined call in flight leads -- it takes every
 // request waiting, runs them as one batch on ITS OWN ctx (its lock, lanes and streams) and hands each caller its rows
 // -- and callers that arrive meanwhile wait for the next round.
 // A row's result does not depend on the rows beside it (src/fhe.jl:579-582 is per bootstrap; tests/test_gpu_golden.py
@@ -59,6 +59,12 @@ struct Coalescer {
     uint32_t req_max = 32, gates_max = 256, window_us = 300;
     // statistics (sgfhe_coalesce_stats)
     uint64_t n_calls = 0, n_reqs = 0, n_gates = 0, max_reqs = 0;
+
+    // Is a call of `batch` gates one to gather?  (the knobs may change under a caller's feet: read under the lock)
+    bool wants(size_t batch) {
+        std::lock_guard<std::mutex> lk(mu);
+        return enabled && batch <= req_max;
+    }
 
     // A request arrives.  Returns 0 when another caller's combined call served it (me.rc / me.err hold its outcome);
     // 1 when the caller LEADS a round: `take` holds the requests of the round, `me` among them -- same flags and

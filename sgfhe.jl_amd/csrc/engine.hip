@@ -2396,8 +2396,7 @@ int32_t sgfhe_bootstrap_batch(sgfhe_ctx *c, const uint64_t *a1, const uint64_t *
     SGFHE_LOCK(c);
     if (batch == 0) return SGFHE_OK;
     // small calls on a key that other ctxs share: gathered with whatever the other callers bring (Coalescer)
-    const Coalescer &co = c->shared->co;
-    if (c->shared.use_count() > 1 && co.enabled && c->have_key && batch <= co.req_max)
+    if (c->shared.use_count() > 1 && c->have_key && c->shared->co.wants(batch))
         return coalesced_call(c, a1, b1, a2, b2, batch, out, flags);
     return bootstrap_host(c, a1, b1, a2, b2, batch, out, flags, c->n, nullptr);
 }
