@@ -171,10 +171,13 @@ lwe_words(bits::AbstractVector{EncryptedBit}, n) =
 # rng = nothing: deterministic flatten (src/utils.jl:155-189), bit-exact with the CPU path.
 # rng::AbstractRNG: randomised flatten (src/utils.jl:198-241) from a device ChaCha8 counter stream
 # keyed with 32 bytes of `rng` -- same distribution, not the same stream as the CPU path.
-function set_flatten_mode(ctx::Ptr{Cvoid}, rng)
-    key = rng === nothing ? zeros(UInt8, 32) : rand(rng, UInt8, 32)
+# The 32 bytes are drawn from the caller's rng BEFORE a slot is taken (flatten_key), so the rng is touched by
+# the calling task only and in the order of its calls.
+flatten_key(rng) = rng === nothing ? nothing : rand(rng, UInt8, 32)
+function set_flatten_mode(ctx::Ptr{Cvoid}, key::Union{Vector{UInt8},Nothing})
     check(ctx, ccall((:sgfhe_set_random_flatten_key, libsgfhe_hip), Int32,
-                     (Ptr{Cvoid}, Cint, Ptr{UInt8}), ctx, rng === nothing ? 0 : 1, key))
+                     (Ptr{Cvoid}, Cint, Ptr{UInt8}), ctx, key === nothing ? 0 : 1,
+                     key === nothing ? zeros(UInt8, 32) : key))
 end
 
 """
@@ -195,9 +198,9 @@ function SGFHE.bootstrap(hkey::HipBootstrapKey, rng::Union{AbstractRNG,Nothing},
     # new_repr = ModUInt, new_base_type = UInt64, new_modulus = params.r (src/utils.jl:116, src/fhe.jl:616-618)
     mk(x::UInt64) = ModUInt(x, p.r, _verbatim)
     res = Vector{NTuple{3,EncryptedBit}}(undef, batch)
-    # (the rng is read before the slot is taken: the caller's rng need not be task-safe beyond its own use)
+    fkey = flatten_key(rng)
     with_slot(hkey) do slot
-        set_flatten_mode(slot.ctx, rng)           # mode and call stay together on the slot's own ctx
+        set_flatten_mode(slot.ctx, fkey)          # mode and call stay together on the slot's own ctx
         length(slot.scratch) < batch * 3 * (n + 1) && resize!(slot.scratch, batch * 3 * (n + 1))
         out = slot.scratch
         rc = ccall((:sgfhe_bootstrap_batch, libsgfhe_hip), Int32,
@@ -247,8 +250,9 @@ function SGFHE.pack_encrypted_bits(hkey::HipBootstrapKey, rng::Union{AbstractRNG
     a, b = lwe_words(enc_bits, p.n)
     w = Vector{UInt64}(undef, p.m)
     v = Vector{UInt64}(undef, p.m)
+    fkey = flatten_key(rng)
     with_slot(hkey) do slot
-        set_flatten_mode(slot.ctx, rng)
+        set_flatten_mode(slot.ctx, fkey)
         rc = ccall((:sgfhe_pack_encrypted_bits, libsgfhe_hip), Int32,
                    (Ptr{Cvoid}, Ptr{UInt64}, Ptr{UInt64}, Csize_t, Ptr{UInt64}, Ptr{UInt64}),
                    slot.ctx, a, b, 1, w, v)
