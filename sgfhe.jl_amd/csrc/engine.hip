@@ -2329,34 +2329,32 @@ static int32_t coalesced_call(sgfhe_ctx *c, const uint64_t *a1, const uint64_t *
         rc = bootstrap_host(c, a1, b1, a2, b2, batch, out, flags, c->n, nullptr);
         c->call_fixed = -1;
     } else {
-        try {
+        // (the staging vectors may throw: no exception leaves an entry point of the C ABI)
+        auto gathered = [&]() -> int32_t {
+            int32_t r = SGFHE_OK;
             if (me.rnd) {   // the draw stream of every row of the combined call, on the device before its first kernel
                 (void)hipSetDevice(c->device);
-                rc = drain(c);
-                if (rc == SGFHE_OK && gates > c->rows_cap) {
+                if ((r = drain(c))) return r;
+                if (gates > c->rows_cap) {
                     if (c->d_rows) (void)hipFree(c->d_rows);
                     c->d_rows = nullptr;
                     c->rows_cap = 0;
                     const size_t cap = gates > co.gates_max ? gates : co.gates_max;
                     if (hipMalloc(&c->d_rows, cap * sizeof(RndRow)) != hipSuccess)
-                        rc = fail(c, SGFHE_ERR_OOM, "hipMalloc of the gathered call's draw-stream table failed");
-                    else
-                        c->rows_cap = cap;
+                        return fail(c, SGFHE_ERR_OOM, "hipMalloc of the gathered call's draw-stream table failed");
+                    c->rows_cap = cap;
                 }
-                if (rc == SGFHE_OK) {
-                    c->h_rows.clear();
-                    for (const Coalescer::Req *q : take)
-                        for (size_t t = 0; t < q->batch; t++) {
-                            RndRow r;
-                            memcpy(r.key.k, q->key, sizeof r.key.k);
-                            r.call = q->call;
-                            r.boot = (uint32_t)t;
-                            c->h_rows.push_back(r);
-                        }
-                    if (hipMemcpy(c->d_rows, c->h_rows.data(), gates * sizeof(RndRow), hipMemcpyHostToDevice) != hipSuccess)
-                        rc = fail(c, SGFHE_ERR_HIP, "copy of the gathered call's draw-stream table failed");
-                }
-                if (rc) throw rc;
+                c->h_rows.clear();
+                for (const Coalescer::Req *q : take)
+                    for (size_t t = 0; t < q->batch; t++) {
+                        RndRow row_of;
+                        memcpy(row_of.key.k, q->key, sizeof row_of.key.k);
+                        row_of.call = q->call;
+                        row_of.boot = (uint32_t)t;
+                        c->h_rows.push_back(row_of);
+                    }
+                if (hipMemcpy(c->d_rows, c->h_rows.data(), gates * sizeof(RndRow), hipMemcpyHostToDevice) != hipSuccess)
+                    return fail(c, SGFHE_ERR_HIP, "copy of the gathered call's draw-stream table failed");
                 c->gather_rows = c->d_rows;
             }
             std::vector<uint64_t> &g = c->co_buf;                          // [a1 | a2 | b1 | b2 | out] of all requests
@@ -2370,16 +2368,16 @@ static int32_t coalesced_call(sgfhe_ctx *c, const uint64_t *a1, const uint64_t *
                 memcpy(gb2 + r0, q->b2, q->batch * 8);
                 r0 += q->batch;
             }
-            rc = bootstrap_host(c, ga1, gb1, ga2, gb2, gates, gout, flags, c->n, nullptr);
-            c->gather_rows = nullptr;
+            if ((r = bootstrap_host(c, ga1, gb1, ga2, gb2, gates, gout, flags, c->n, nullptr))) return r;
             r0 = 0;
-            if (rc == SGFHE_OK)
-                for (const Coalescer::Req *q : take) {
-                    memcpy(q->out, gout + r0 * row, q->batch * row * 8);
-                    r0 += q->batch;
-                }
-        } catch (int32_t e) {
-            rc = e;                                     // (message already on the ctx)
+            for (const Coalescer::Req *q : take) {
+                memcpy(q->out, gout + r0 * row, q->batch * row * 8);
+                r0 += q->batch;
+            }
+            return SGFHE_OK;
+        };
+        try {
+            rc = gathered();
         } catch (...) {
             rc = fail(c, SGFHE_ERR_OOM, "out of host memory");
         }
