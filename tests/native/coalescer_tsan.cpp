@@ -9,8 +9,10 @@
 //     `running` flag protects);
 //   - a round never mixes flags or modes and never exceeds gates_max unless it is a single oversized request;
 //   - the statistics add up, and callers on their own are not delayed by the gathering window;
-//   - an error of the leader's run reaches every request of its round and nobody else.
-// Prints "ok <rounds> <requests>".  Any data race, lock-order inversion, use-after-return of a Req (they live on the
+//   - an error of the leader's run reaches every request of its round and nobody else;
+//   - the knobs change under the callers' feet (sgfhe_set_coalesce from another thread) while every caller asks
+//     wants() first, as sgfhe_bootstrap_batch does: requests it declines run on their own.
+// Prints "ok <rounds> <requests> <requests declined by wants()>".  Any data race, lock-order inversion, use-after-return of a Req (they live on the
 // callers' stacks) or leak aborts the run.
 #if defined(__SANITIZE_THREAD__)
 // ThreadSanitizer of this GCC does not intercept pthread_cond_clockwait, which libstdc++ uses for waits on the steady
@@ -85,7 +87,18 @@ int main() {
     co.gates_max = 24;
     co.window_us = 200;
     const int T = 12, K = 60;
-    std::atomic<uint64_t> served{0}, failed{0}, wrong{0};
+    std::atomic<uint64_t> served{0}, failed{0}, wrong{0}, alone{0};
+    std::atomic<bool> tuning{true};
+    std::thread tuner([&] {                                 // what sgfhe_set_coalesce does, every half millisecond
+        for (int i = 0; tuning.load(); i++) {
+            {
+                std::lock_guard<std::mutex> lk(co.mu);
+                co.req_max = (i & 1) ? 4 : 32;
+                co.window_us = (i & 2) ? 100 : 200;
+            }
+            std::this_thread::sleep_for(std::chrono::microseconds(500));
+        }
+    });
     std::vector<std::thread> th;
     for (int t = 0; t < T; t++)
         th.emplace_back([&, t] {
@@ -100,6 +113,10 @@ int main() {
                 std::vector<uint64_t> a(batch), out(batch, 0xDEADull);
                 for (auto &x : a) x = rnd64();
                 std::string err;
+                if (!co.wants(batch)) {                     // above the present req_max: the caller's own call
+                    alone++;
+                    continue;
+                }
                 const int32_t rc = call(co, &owner_tag, 77u + t, (uint32_t)k, rnd, flags, a.data(), batch, out.data(), poison, err);
                 if (rc) {
                     failed++;
@@ -115,6 +132,10 @@ int main() {
             co.forget(&owner_tag);
         });
     for (auto &x : th) x.join();
+    tuning = false;
+    tuner.join();
+    co.req_max = 32;
+    co.window_us = 200;
     // a caller on its own: no other caller seen in the last rounds, so no waiting for anybody
     int solo_tag = 0;
     std::vector<uint64_t> a(3, 5), out(3);
@@ -122,16 +143,18 @@ int main() {
     const auto t0 = std::chrono::steady_clock::now();
     for (int k = 0; k < 200; k++) call(co, &solo_tag, 1, k, false, 0, a.data(), 3, out.data(), false, err);
     const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    const bool ok = wrong == 0 && violations == 0 && served + failed == (uint64_t)T * K && co.n_reqs == (uint64_t)T * K + 200 &&
+    const bool ok = wrong == 0 && violations == 0 && served + failed + alone == (uint64_t)T * K && alone > 0 &&
+                    co.n_reqs == (uint64_t)T * K - alone + 200 &&
                     co.n_calls == rounds.load() && co.max_reqs >= 2 && co.pending.empty() && !co.running &&
                     ms < 200 * (0.15 + 0.06 + 0.25);                // 200 solo rounds of ~0.21 ms of stand-in work, no 0.2 ms windows
     if (!ok) {
-        printf("FAILED: wrong %llu violations %llu served %llu failed %llu n_reqs %llu n_calls %llu rounds %llu max %llu solo %.1f ms\n",
-               (unsigned long long)wrong.load(), (unsigned long long)violations.load(), (unsigned long long)served.load(),
+        printf("FAILED: alone %llu wrong %llu violations %llu served %llu failed %llu n_reqs %llu n_calls %llu rounds %llu max %llu solo %.1f ms\n",
+               (unsigned long long)alone.load(), (unsigned long long)wrong.load(), (unsigned long long)violations.load(),
+               (unsigned long long)served.load(),
                (unsigned long long)failed.load(), (unsigned long long)co.n_reqs, (unsigned long long)co.n_calls,
                (unsigned long long)rounds.load(), (unsigned long long)co.max_reqs, ms);
         return 1;
     }
-    printf("ok %llu %llu\n", (unsigned long long)co.n_calls, (unsigned long long)co.n_reqs);
+    printf("ok %llu %llu %llu\n", (unsigned long long)co.n_calls, (unsigned long long)co.n_reqs, (unsigned long long)alone.load());
     return 0;
 }

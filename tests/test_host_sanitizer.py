@@ -73,7 +73,7 @@ def test_coalescer_under_thread_and_address_sanitizers(tmp_path, san):
     sgfhe_set_coalesce) -- under ThreadSanitizer and under ASan / UBSan on the CPU, with a stand-in for the combined
     call (tests/native/coalescer_tsan.cpp): twelve threads of mixed requests; every request gets its own rows, rounds
     never overlap or mix modes, errors reach exactly their round, the statistics add up, a lone caller is not
-    delayed.  The requests live on their callers' stacks while another thread serves them: exactly what these tools
+    delayed, and the knobs change under the callers' feet as sgfhe_set_coalesce changes them.  The requests live on their callers' stacks while another thread serves them: exactly what these tools
     are for."""
     gxx = shutil.which("g++")
     if not gxx:
@@ -92,5 +92,6 @@ def test_coalescer_under_thread_and_address_sanitizers(tmp_path, san):
     env.pop("LD_PRELOAD", None)
     r = subprocess.run([exe], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
-    tag, n_calls, n_reqs = r.stdout.split()
-    assert tag == "ok" and int(n_reqs) == 12 * 60 + 200 and int(n_calls) < int(n_reqs)      # something was gathered
+    tag, n_calls, n_reqs, n_alone = r.stdout.split()
+    # something was gathered, and some requests were above the req_max another thread kept changing (wants())
+    assert tag == "ok" and int(n_reqs) + int(n_alone) == 12 * 60 + 200 and int(n_alone) > 0 and int(n_calls) < int(n_reqs)
